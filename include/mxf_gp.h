@@ -1,0 +1,179 @@
+/*
+ * mxf_gp.h -- C ABI of libmxf_gp.so: the MI355X (gfx950) implementation of MXFusion's
+ * Gaussian-process + SVI hot path.
+ *
+ * The reference (amzn/MXFusion v0.3.1) is pure Python on Apache MXNet; the arithmetic of this path
+ * lives in MXNet operators called from four Python files.  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).  The reference-side
+ * binding a maintainer would add (a ctypes stub inside the reference's kernel / module classes) is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain pointers and sizes; no C++ / torch types.
+ *   - return int status: 0 ok; <0 bad argument / runtime error (text via mxf_last_error);
+ *     LAPACK-style "first non-PD leading minor" is reported asynchronously through a device-side
+ *     int* info argument (never a host sync inside the library, like MXNet's lazy error).
+ *   - the CALLER owns every data buffer (device pointers); the library owns only the opaque handle
+ *     and its scratch workspace.  Row-major, leading sample axis S.  Strides are in ELEMENTS;
+ *     a sample stride of 0 broadcasts that operand over S (the reference physically broadcasts,
+ *     components/variables/runtime_variable.py:82-118).
+ *   - dtype: MXF_F32 or MXF_F64 for every array of the call.
+ *   - every call takes the hipStream_t (as void*) it is enqueued on and is asynchronous w.r.t. the host.
+ *   - one handle per (thread, device); calls on one handle are not re-entrant.
+ */
+#ifndef MXF_GP_H
+#define MXF_GP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mxf_ctx* mxf_handle;
+
+enum { MXF_F32 = 0, MXF_F64 = 1 };
+
+/* covariance-function kinds (components/distributions/gp/kernels/{rbf,matern,linear,static}.py) */
+enum { MXF_K_RBF = 0, MXF_K_MATERN12 = 1, MXF_K_MATERN32 = 2, MXF_K_MATERN52 = 3,
+       MXF_K_LINEAR = 4, MXF_K_BIAS = 5, MXF_K_WHITE = 6 };
+
+/* how mxf_gram combines with the existing contents of K_out:
+ * AddKernel / MultiplyKernel (kernels/add_kernel.py:44-68, multiply_kernel.py:44-67) */
+enum { MXF_WRITE = 0, MXF_ACC_ADD = 1, MXF_ACC_MUL = 2 };
+
+int mxf_version(void);
+int mxf_create(int device, mxf_handle* out);
+int mxf_destroy(mxf_handle h);
+const char* mxf_last_error(mxf_handle h);
+/* bytes of scratch currently held by the handle */
+int64_t mxf_workspace_bytes(mxf_handle h);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gram build.  Replaces Kernel.K -> _compute_K (kernels/kernel.py:96-123), i.e.
+ * StationaryKernel._compute_R2 (kernels/stationary.py:74-107) + RBF._compute_K (rbf.py:71-72) /
+ * Matern{12,32,52}._compute_K (matern.py:84-88,116-120,148-151) / Linear (linear.py:59-89) /
+ * Bias, White (static.py:56-74,125-150), fused into ONE pass that writes K once.
+ *   X  : (S|1, N,  Q)   X2 : (S|1, N2, Q) or NULL (=> X2 = X, square Gram)
+ *   lengthscale : (S|1, Q) if ard else (S|1, 1); for MXF_K_LINEAR it is `variances`; unused for BIAS/WHITE
+ *   variance    : (S|1, 1)                       (unused for MXF_K_LINEAR)
+ *   diag_add    : optional (S|1, 1) device scalar added to the diagonal (square Gram only):
+ *                 the "+ eye*noise_var" of gp_regression.py:55-57;  jitter: host scalar, same place
+ *                 (gp_regression.py:58-60, svgp_regression.py:70-72)
+ *   K_out : (S, N, N2) with row stride ldk.
+ * r^2 is evaluated as sum_q ((x_q - z_q)/l_q)^2 (difference form; the reference's expansion form
+ * agrees to rounding in float64 and is less accurate in float32).                                  */
+int mxf_gram(mxf_handle h, int kind, int dtype, int S, int64_t N, int64_t N2, int Q,
+             const void* X, int64_t strideS_X, const void* X2, int64_t strideS_X2,
+             const void* lengthscale, int ard, int64_t strideS_ls,
+             const void* variance, int64_t strideS_var,
+             const void* diag_add, int64_t strideS_diag, double jitter, int mode,
+             void* K_out, int64_t ldk, int64_t strideS_K, void* stream);
+
+/* Reverse mode of mxf_gram for the stationary kinds (what MXNet autograd does through
+ * stationary.py:92-106 + rbf.py:71-72 / matern.py): given dK (S,N,N2) accumulates
+ *   dX (S,N,Q), dX2 (S,N2,Q) [NULL when X2==NULL: both roles flow into dX], dls (S, Q|1), dvar (S,1).
+ * Outputs are ACCUMULATED INTO (caller zeroes them); any output pointer may be NULL.               */
+int mxf_gram_bwd(mxf_handle h, int kind, int dtype, int S, int64_t N, int64_t N2, int Q,
+                 const void* X, int64_t strideS_X, const void* X2, int64_t strideS_X2,
+                 const void* lengthscale, int ard, int64_t strideS_ls,
+                 const void* variance, int64_t strideS_var,
+                 const void* dK, int64_t lddk, int64_t strideS_dK,
+                 void* dX, void* dX2, void* dls, void* dvar, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense building blocks (MXNet linalg.* call sites).  All batched over S with strides.  */
+
+/* C = alpha*op(A)*op(B) + beta*C  -- linalg.gemm2 / linalg.syrk (svgp_regression.py:76,82,89,90 ...) */
+int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+             double alpha, const void* A, int64_t lda, int64_t strideA,
+             const void* B, int64_t ldb, int64_t strideB,
+             double beta, void* C, int64_t ldc, int64_t strideC, int batch, void* stream);
+
+/* in-place lower Cholesky, strictly-upper part zeroed -- linalg.potrf (gp_regression.py:61,
+ * svgp_regression.py:83-84).  info: device int[S], 0 or (1-based) index of the first bad pivot.   */
+int mxf_potrf(mxf_handle h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t strideS_A,
+              int* info, void* stream);
+
+/* B <- op(L)^-1 B, L lower (n x n), B (n x nrhs) -- linalg.trsm(L,B,transpose)
+ * (gp_regression.py:66,172; svgp_regression.py:85-87,153-156,164)                                   */
+int mxf_trsm(mxf_handle h, int dtype, int transpose, int S, int64_t n, int64_t nrhs,
+             const void* L, int64_t ldl, int64_t strideS_L, void* B, int64_t ldb, int64_t strideS_B,
+             void* stream);
+
+/* Linv <- L^-1 (lower) ; used for K^-1 = L^-T L^-1 in the closed-form gradients                    */
+int mxf_trtri(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t strideS_L,
+              void* Linv, int64_t ldi, int64_t strideS_I, void* stream);
+
+/* out[s] = sum_i log|L_ii| -- linalg.sumlogdiag(abs(L)) (gp_regression.py:67)                       */
+int mxf_sumlogdiag(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t strideS_L,
+                   void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise / reduction pieces of the MC-ELBO loop.                                             */
+
+/* y = log(1+exp(x)) and its reverse mode -- PositiveTransformation (var_trans.py:63-91)             */
+int mxf_softplus_fwd(mxf_handle h, int dtype, int64_t n, const void* x, void* y, void* stream);
+int mxf_softplus_bwd(mxf_handle h, int dtype, int64_t n, const void* x, const void* dy, void* dx_acc, void* stream);
+
+/* x[s,i] = mean[i] + eps[s,i]*sqrt(var[i]) -- Normal.draw_samples_impl (normal.py:72-92); eps is the
+ * caller-injected noise buffer (random_gen.py:26-28 seam).  n = elements per sample.               */
+int mxf_normal_reparam(mxf_handle h, int dtype, int S, int64_t n, const void* mean, const void* var,
+                       const void* eps, void* x, void* stream);
+
+/* out += scale * sum_{s,i} logN(x[s,i] | mean[i], var[i])  (normal.py:52-70 then
+ * factor_graph.py:223: sum(mean_S(.)) => scale = +-log_pdf_scaling/S), with wave-shuffle reductions;
+ * optional reverse mode accumulated into dx (S,n), dmean (n), dvar (n) (all scaled by `scale`).
+ * mean/var may be single-element broadcasts (n_mean, n_var in {1, n}).                            */
+int mxf_normal_logpdf(mxf_handle h, int dtype, int S, int64_t n, const void* x,
+                      const void* mean, int64_t n_mean, const void* var, int64_t n_var, double scale,
+                      void* out_acc, void* dx_acc, void* dmean_acc, void* dvar_acc, void* stream);
+
+/* reverse mode of mxf_normal_reparam: dmean += sum_s dx ; dvar += sum_s dx*eps/(2 sqrt(var))        */
+int mxf_normal_reparam_bwd(mxf_handle h, int dtype, int S, int64_t n, const void* var, const void* eps,
+                           const void* dx, void* dmean_acc, void* dvar_acc, void* stream);
+
+/* MXNet Adam as driven by gluon.Trainer.step (batch_loop.py:46-60, minibatch_loop.py:71-91):
+ * g*=rescale; m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)      */
+int mxf_adam_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* m, void* v,
+                  double lr, double beta1, double beta2, double epsilon, double rescale_grad, int t,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused composites: one call = one reference `compute` body, value AND reverse mode.               */
+
+/* GPRegressionLogPdf.compute (modules/gp_modules/gp_regression.py:42-76), stationary kernel.
+ *   X (S|1,N,Q)  Y (S|1,N,P) [already minus mean]  noise_var (S|1,1)
+ * outputs: logL (S);  L (S,N,N) and LinvY (S,N,P) (the posterior side effect of :72-75);
+ * if want_grad: dX (S,N,Q), dY (S,N,P), dnoise (S), dls (S,Q|1), dvar (S) = d logL[s] / d(.) , WRITTEN.
+ * info: device int[S].                                                                             */
+int mxf_gp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t N, int Q, int P,
+                  const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                  const void* noise_var, int64_t strideS_noise,
+                  const void* lengthscale, int ard, int64_t strideS_ls,
+                  const void* variance, int64_t strideS_var, double jitter,
+                  void* logL, void* L, void* LinvY, int* info, int want_grad,
+                  void* dX, void* dY, void* dnoise, void* dls, void* dvar, void* stream);
+
+/* SVGPRegressionLogPdf.compute (modules/gp_modules/svgp_regression.py:43-109), homoscedastic noise,
+ * stationary kernel, streaming sufficient-statistics form: Kuf is never the operand of a
+ * triangular solve; all (M x M) factorisation work is done once (not S times) in float64.
+ *   X (S|1,B,Q)  Y (S|1,B,P) [minus mean]  Z (M,Q)  noise_var (1)  qU_mean (M,P)  qU_cov_W (M,M)
+ *   qU_cov_diag (M) [positive]  lengthscale (Q|1)  variance (1); scaling = log_pdf_scaling (:108)
+ * outputs: logL (S) per-sample bound.  If want_grad: gradients of  sum_s gw[s]*logL[s]  (gw: host
+ * weights folded as a single scalar `gscale` applied to every sample, i.e. the mean_S of
+ * factor_graph.py:233 => gscale = 1/S): dX (S,B,Q) dY (S,B,P) dZ (M,Q) dnoise (1) dmu (M,P) dW (M,M)
+ * dSdiag (M) dls (Q|1) dvar (1), all WRITTEN.                                                      */
+int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                    const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                    const void* Z, const void* noise_var, const void* qU_mean, const void* qU_cov_W,
+                    const void* qU_cov_diag, const void* lengthscale, int ard, const void* variance,
+                    double jitter, double scaling, double gscale,
+                    void* logL, int* info, int want_grad,
+                    void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
+                    void* dls, void* dvar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXF_GP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libmxf_gp.so (include/mxf_gp.h).  There is NO CPU fallback: if the HIP library is
+missing or no GPU is present the product path raises."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmxf_gp.so')
+
+F32, F64 = 0, 1
+K_RBF, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_BIAS, K_WHITE = range(7)
+WRITE, ACC_ADD, ACC_MUL = 0, 1, 2
+
+_c = ctypes
+_vp, _i, _i64, _d = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double
+
+# name -> argtypes (after the handle); every entry point include/mxf_gp.h declares is listed here
+SIGNATURES = {
+    'mxf_gram': [_i, _i, _i, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i64, _d, _i,
+                 _vp, _i64, _i64, _vp],
+    'mxf_gram_bwd': [_i, _i, _i, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i64, _i64,
+                     _vp, _vp, _vp, _vp, _vp],
+    'mxf_gemm': [_i, _i, _i, _i64, _i64, _i64, _d, _vp, _i64, _i64, _vp, _i64, _i64, _d, _vp, _i64, _i64, _i, _vp],
+    'mxf_potrf': [_i, _i, _i64, _vp, _i64, _i64, _vp, _vp],
+    'mxf_trsm': [_i, _i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp],
+    'mxf_trtri': [_i, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp],
+    'mxf_sumlogdiag': [_i, _i, _i64, _vp, _i64, _i64, _vp, _vp],
+    'mxf_softplus_fwd': [_i, _i64, _vp, _vp, _vp],
+    'mxf_softplus_bwd': [_i, _i64, _vp, _vp, _vp, _vp],
+    'mxf_normal_reparam': [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp],
+    'mxf_normal_logpdf': [_i, _i, _i64, _vp, _vp, _i64, _vp, _i64, _d, _vp, _vp, _vp, _vp, _vp],
+    'mxf_normal_reparam_bwd': [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    'mxf_adam_step': [_i, _i64, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _i, _vp],
+    'mxf_gp_logpdf': [_i, _i, _i, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _d,
+                      _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    'mxf_svgp_logpdf': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp,
+                        _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+PLAIN = {  # entry points without the (handle, ...) -> int shape
+    'mxf_version': ([], _i),
+    'mxf_create': ([_i, _c.POINTER(_vp)], _i),
+    'mxf_destroy': ([_vp], _i),
+    'mxf_last_error': ([_vp], _c.c_char_p),
+    'mxf_workspace_bytes': ([_vp], _i64),
+}
+ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
+
+_lib = None
+_lock = threading.Lock()
+_handles = {}
+
+
+class MXFError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmxf_gp.so and declare prototypes.  Raises (loudly) when the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MXFError('libmxf_gp.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                           'g.build()"` (or make -C mxfusion_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in PLAIN.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise MXFError('libmxf_gp.so does not export %s' % name)
+            fn.argtypes, fn.restype = [_vp] + args, _i
+        _lib = lib
+    return _lib
+
+
+def handle(device_index):
+    """One library handle per (thread, device)."""
+    key = (threading.get_ident(), int(device_index))
+    h = _handles.get(key)
+    if h is None:
+        lib = load()
+        out = _vp()
+        rc = lib.mxf_create(int(device_index), ctypes.byref(out))
+        if rc != 0:
+            raise MXFError('mxf_create(device=%d) failed with %d: no usable MI355X visible. There is no CPU '
+                           'fallback.' % (device_index, rc))
+        h = out
+        _handles[key] = h
+    return h
+
+
+def call(name, h, *args):
+    lib = load()
+    rc = getattr(lib, name)(h, *args)
+    if rc != 0:
+        raise MXFError('%s failed (%d): %s' % (name, rc, lib.mxf_last_error(h).decode()))

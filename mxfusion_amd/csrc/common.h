@@ -1,0 +1,97 @@
+// Shared host/device infrastructure of libmxf_gp.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "../../include/mxf_gp.h"
+
+struct mxf_ctx {
+    int device = 0;
+    std::string err;
+    void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)
+    size_t ws_bytes = 0;
+};
+
+#define MXF_FAIL(h, code, ...)                                   \
+    do {                                                         \
+        char _b[512];                                            \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+        if (h) (h)->err = _b;                                    \
+        return (code);                                           \
+    } while (0)
+
+#define MXF_HIP(h, call)                                                                   \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess)                                                              \
+            MXF_FAIL(h, -100 - (int)_e, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MXF_LAUNCH_CHECK(h)                                                                \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess)                                                              \
+            MXF_FAIL(h, -100 - (int)_e, "%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+    } while (0)
+
+// scratch allocator: returns a pointer valid until the next call that needs more
+static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return h->ws;
+    if (h->ws) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(h->ws);
+        h->ws = nullptr;
+        h->ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2) + (1u << 20);
+    if (hipMalloc(&h->ws, want) != hipSuccess) {
+        h->ws = nullptr;
+        return nullptr;
+    }
+    h->ws_bytes = want;
+    return h->ws;
+}
+
+static inline size_t mxf_esize(int dtype) { return dtype == MXF_F64 ? 8 : 4; }
+static inline size_t mxf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- device helpers -------------------------------------------------------------------------
+template <typename T> struct Vec16;   // 16-byte vector of T
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <> struct Vec16<float> { typedef f32x4_t type; static constexpr int n = 4; };
+template <> struct Vec16<double> { typedef f64x2_t type; static constexpr int n = 2; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    T r = 0;
+    if (threadIdx.x < 64) {
+        r = (threadIdx.x < nw) ? smem[threadIdx.x] : (T)0;
+        r = wave_sum(r);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// C-ABI entry points implemented across translation units share these internal (typed) launchers

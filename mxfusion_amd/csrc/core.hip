@@ -1,0 +1,27 @@
+// Handle management for libmxf_gp.so.
+#include "common.h"
+
+extern "C" int mxf_version(void) { return 100; }
+
+extern "C" int mxf_create(int device, mxf_handle* out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return -2;
+    if (hipSetDevice(device) != hipSuccess) return -3;
+    mxf_ctx* h = new mxf_ctx();
+    h->device = device;
+    *out = h;
+    return 0;
+}
+
+extern "C" int mxf_destroy(mxf_handle h) {
+    if (!h) return -1;
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+    return 0;
+}
+
+extern "C" const char* mxf_last_error(mxf_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)h->ws_bytes : -1; }

@@ -1,0 +1,283 @@
+// Batched MFMA GEMM for gfx950:  C = alpha * op(A) * op(B) + beta * C   (row-major, f32 / f64).
+//
+// Replaces MXNet linalg.gemm2 / linalg.syrk call sites of the reference and is the
+// building block of the blocked Cholesky / triangular solves and of the SVGP contractions.
+//
+// Roofline: MFMA bound.  f32 uses v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = 157 TF chip
+// peak), f64 uses v_mfma_f64_16x16x4_f64.  At 1/16 of the bf16 MFMA rate the matrix pipe is the only
+// thing that matters: a 128x128x16 block tile (4 waves as 2x2, 64x64 per wave) needs just 32 LDS
+// fragment reads per 2048+ MFMA cycles, so operands are staged with plain guarded loads (any
+// alignment / ragged edge) into k-major LDS tiles and read with conflict-free ds_read_b32/b64.
+//   A-fragment (32x32x2): lane l -> A[i = l&31][k = l>>5];  B-fragment: B[k = l>>5][j = l&31]
+//   A-fragment (16x16x4 f64): lane l -> A[i = l&15][k = l>>4]; B[k = l>>4][j = l&15]
+//   C/D f32 32x32: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
+//   C/D f64 16x16: col = l&15, row = (l>>4) + 4*r, r in [0,4)
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Tile;
+template <> struct Tile<float> { static constexpr int LD = BM + 4; };    // row stride of the k-major LDS tiles
+template <> struct Tile<double> { static constexpr int LD = BM + 1; };
+
+template <typename T>
+struct GemmArgs {
+    const T* A; const T* B; T* C;
+    int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
+    T alpha, beta;
+    int splitk, lower_only, atomic;
+    int64_t kchunk;
+};
+
+// loads the op(A) (or op(B)) tile [BK x 128] for k in [k0,k0+BK) into registers, 8 elements / thread
+// KCONT: the matrix is stored with k contiguous (A not transposed / B transposed)
+template <typename T, bool KCONT>
+__device__ __forceinline__ void load_tile(T (&reg)[8], const T* __restrict__ P, int64_t ld, int64_t mn0, int64_t MN,
+                                          int64_t k0, int64_t kend, int tid) {
+    if (KCONT) {
+        const int k = tid & 15;
+        const int64_t kk = k0 + k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = mn0 + (tid >> 4) + 16 * j;
+            reg[j] = (i < MN && kk < kend) ? P[i * ld + kk] : (T)0;
+        }
+    } else {
+        const int i = tid & 127;
+        const int64_t ii = mn0 + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t kk = k0 + (tid >> 7) + 2 * j;
+            reg[j] = (ii < MN && kk < kend) ? P[kk * ld + ii] : (T)0;
+        }
+    }
+}
+
+template <typename T, bool KCONT>
+__device__ __forceinline__ void store_tile(const T (&reg)[8], T* __restrict__ S, int tid) {
+    constexpr int LD = Tile<T>::LD;
+    if (KCONT) {
+        const int k = tid & 15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[k * LD + (tid >> 4) + 16 * j] = reg[j];
+    } else {
+        const int i = tid & 127;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) S[((tid >> 7) + 2 * j) * LD + i] = reg[j];
+    }
+}
+
+template <typename T> struct Acc;
+template <> struct Acc<float> {
+    f32x16 c[2][2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
+    }
+    // one BK=16 slab from LDS
+    __device__ __forceinline__ void mma(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane) {
+        constexpr int LD = Tile<float>::LD;
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 2) {
+            float a0 = As[(ks + lk) * LD + wm + li], a1 = As[(ks + lk) * LD + wm + 32 + li];
+            float b0 = Bs[(ks + lk) * LD + wn + li], b1 = Bs[(ks + lk) * LD + wn + 32 + li];
+            c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c[0][0], 0, 0, 0);
+            c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c[0][1], 0, 0, 0);
+            c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c[1][0], 0, 0, 0);
+            c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c[1][1], 0, 0, 0);
+        }
+    }
+    template <typename F> __device__ __forceinline__ void for_each(int wm, int wn, int lane, F f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = wn + b * 32 + (lane & 31);
+                    f(row, col, c[a][b][r]);
+                }
+    }
+};
+template <> struct Acc<double> {
+    f64x4 c[4][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[a][b][r] = 0.0;
+    }
+    __device__ __forceinline__ void mma(const double* __restrict__ As, const double* __restrict__ Bs, int wm, int wn, int lane) {
+        constexpr int LD = Tile<double>::LD;
+        const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[(ks + lk) * LD + wm + 16 * t + li];
+                b[t] = Bs[(ks + lk) * LD + wn + 16 * t + li];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], c[x][y], 0, 0, 0);
+        }
+    }
+    template <typename F> __device__ __forceinline__ void for_each(int wm, int wn, int lane, F f) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm + a * 16 + (lane >> 4) + 4 * r;
+                    const int col = wn + b * 16 + (lane & 15);
+                    f(row, col, c[a][b][r]);
+                }
+    }
+};
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
+    constexpr int LD = Tile<T>::LD;
+    __shared__ __attribute__((aligned(16))) T smem[2][2][BK * LD];   // [buffer][A|B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    if (g.lower_only && n0 > m0 + (BM - 1)) return;   // block entirely above the diagonal
+    const int bz = blockIdx.z;
+    const int batch = bz / g.splitk, split = bz % g.splitk;
+
+    const T* __restrict__ A = g.A + (int64_t)batch * g.sA;
+    const T* __restrict__ B = g.B + (int64_t)batch * g.sB;
+    T* __restrict__ C = g.C + (int64_t)batch * g.sC;
+
+    const int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+
+    Acc<T> acc;
+    acc.zero();
+
+    T ra[8], rb[8];
+    if (kbeg < kend) {
+        load_tile<T, !TA>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
+        load_tile<T, TB>(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+        store_tile<T, !TA>(ra, smem[0][0], tid);
+        store_tile<T, TB>(rb, smem[0][1], tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK < kend);
+        if (more) {
+            load_tile<T, !TA>(ra, A, g.lda, m0, g.M, k0 + BK, kend, tid);
+            load_tile<T, TB>(rb, B, g.ldb, n0, g.N, k0 + BK, kend, tid);
+        }
+        acc.mma(smem[cur][0], smem[cur][1], wm, wn, lane);
+        if (more) {
+            store_tile<T, !TA>(ra, smem[cur ^ 1][0], tid);
+            store_tile<T, TB>(rb, smem[cur ^ 1][1], tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const T alpha = g.alpha, beta = g.beta;
+    const bool atomic = g.atomic != 0;
+    acc.for_each(wm, wn, lane, [&](int r, int c, T v) {
+        const int64_t row = m0 + r, col = n0 + c;
+        if (row < g.M && col < g.N && !(g.lower_only && col > row)) {
+            T* p = C + row * g.ldc + col;
+            if (atomic) atomic_add(p, alpha * v);
+            else *p = (beta == (T)0) ? alpha * v : alpha * v + beta * (*p);
+        }
+    });
+}
+
+// C *= beta (or C = 0) ahead of a split-K launch whose epilogue is atomicAdd
+template <typename T>
+__global__ void scale_kernel(T* C, int64_t M, int64_t N, int64_t ldc, int64_t sC, T beta, int lower_only) {
+    T* c = C + (int64_t)blockIdx.z * sC;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col < N && !(lower_only && col > row)) {
+        T* p = c + row * ldc + col;
+        *p = (beta == (T)0) ? (T)0 : beta * (*p);
+    }
+}
+
+template <typename T>
+int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
+               int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta, void* C, int64_t ldc, int64_t sC,
+               int batch, int lower_only, hipStream_t st) {
+    GemmArgs<T> g;
+    g.A = (const T*)A; g.B = (const T*)B; g.C = (T*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+    g.alpha = (T)alpha; g.beta = (T)beta; g.lower_only = lower_only;
+    const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    // split K when the output grid cannot fill 256 CUs and K is long
+    int64_t tiles = tm * tn * batch;
+    if (lower_only) tiles = (tiles + 1) / 2;
+    int splitk = 1;
+    if (tiles < 256 && K >= 1024) {
+        splitk = (int)((512 + tiles - 1) / tiles);
+        const int64_t maxsplit = K / 256;
+        if (splitk > maxsplit) splitk = (int)maxsplit;
+        if (splitk < 1) splitk = 1;
+    }
+    int64_t kchunk = (K + splitk - 1) / splitk;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    splitk = (int)((K + kchunk - 1) / kchunk);
+    if (K == 0) { splitk = 1; kchunk = BK; }
+    g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
+    if (tm > 65535 || (int64_t)batch * splitk > 65535) MXF_FAIL(h, -3, "mxf_gemm: grid too large (M=%lld batch=%d)", (long long)M, batch);
+    if (g.atomic) {
+        dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
+        if (M > 65535) MXF_FAIL(h, -3, "mxf_gemm: split-K path needs M<=65535");
+        hipLaunchKernelGGL((scale_kernel<T>), gs, dim3(256), 0, st, (T*)C, M, N, ldc, sC, (T)beta, lower_only);
+    }
+    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(batch * splitk));
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), 0, st, g);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+}  // namespace
+
+int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+                      const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
+                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (dtype == MXF_F32) return gemm_typed<float>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st);
+    if (dtype == MXF_F64) return gemm_typed<double>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st);
+    MXF_FAIL(h, -2, "mxf_gemm: bad dtype %d", dtype);
+}
+
+extern "C" int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                        double alpha, const void* A, int64_t lda, int64_t strideA,
+                        const void* B, int64_t ldb, int64_t strideB,
+                        double beta, void* C, int64_t ldc, int64_t strideC, int batch, void* stream) {
+    if (!h) return -1;
+    if (M < 0 || N < 0 || K < 0 || batch < 0) MXF_FAIL(h, -2, "mxf_gemm: negative dimension");
+    if ((M > 0 && N > 0 && batch > 0) && (!A || !B || !C) && K > 0) MXF_FAIL(h, -2, "mxf_gemm: null operand");
+    return mxf_gemm_internal(h, dtype, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc,
+                             strideC, batch, 0, (hipStream_t)stream);
+}
