@@ -1,0 +1,179 @@
+// Elementwise / reduction kernels of the Monte-Carlo ELBO loop (gfx950): softplus transform,
+// Normal log-pdf with fused reverse mode and wavefront-shuffle reductions, reparameterised sampling
+// and its reverse mode, MXNet-Adam.  All HBM-bound streaming kernels: 16-byte loads where the layout
+// allows, grid-stride, one atomic per block for the scalar sums.
+//
+// Replaces: PositiveTransformation (components/variables/var_trans.py:63-91), Normal.log_pdf_impl /
+// draw_samples_impl (components/distributions/normal.py:52-92) + the sum(mean_S(.)) of
+// models/factor_graph.py:223, and gluon.Trainer.step(adam) of inference/batch_loop.py:46-60.
+#include "common.h"
+
+namespace {
+
+constexpr double LOG2PI = 1.8378770664093453;
+
+template <typename T> __device__ __forceinline__ T softplus_f(T x) {
+    // log(1+exp(x)) = max(x,0) + log1p(exp(-|x|))  (overflow-safe form of MXNet's softrelu)
+    return fmax(x, (T)0) + log1p(exp(-fabs(x)));
+}
+template <typename T> __device__ __forceinline__ T sigmoid_f(T x) {
+    return x >= (T)0 ? (T)1 / ((T)1 + exp(-x)) : exp(x) / ((T)1 + exp(x));
+}
+
+template <typename T>
+__global__ void softplus_fwd_kernel(int64_t n, const T* __restrict__ x, T* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = softplus_f<T>(x[i]);
+}
+template <typename T>
+__global__ void softplus_bwd_kernel(int64_t n, const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] += dy[i] * sigmoid_f<T>(x[i]);
+}
+
+template <typename T>
+__global__ void reparam_kernel(int S, int64_t n, const T* __restrict__ mean, const T* __restrict__ var, const T* __restrict__ eps,
+                               T* __restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T m = mean[i], sd = sqrt(var[i]);
+        for (int s = 0; s < S; ++s) x[(int64_t)s * n + i] = fma(eps[(int64_t)s * n + i], sd, m);
+    }
+}
+
+template <typename T>
+__global__ void reparam_bwd_kernel(int S, int64_t n, const T* __restrict__ var, const T* __restrict__ eps, const T* __restrict__ dx,
+                                   T* __restrict__ dmean, T* __restrict__ dvar) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        T gm = 0, gv = 0;
+        for (int s = 0; s < S; ++s) {
+            const T g = dx[(int64_t)s * n + i];
+            gm += g;
+            gv = fma(g, eps[(int64_t)s * n + i], gv);
+        }
+        if (dmean) dmean[i] += gm;
+        if (dvar) dvar[i] += gv * (T)0.5 / sqrt(var[i]);
+    }
+}
+
+// out += scale * sum logN(x|mean,var); dx += scale * dlogN/dx ...; thread i owns element i for all S samples,
+// so dmean/dvar need no atomics when they are per-element; broadcast (single-element) mean/var are block-reduced.
+template <typename T>
+__global__ __launch_bounds__(256) void normal_logpdf_kernel(int S, int64_t n, const T* __restrict__ x, const T* __restrict__ mean,
+                                                            int64_t n_mean, const T* __restrict__ var, int64_t n_var, T scale,
+                                                            T* __restrict__ out, T* __restrict__ dx, T* __restrict__ dmean,
+                                                            T* __restrict__ dvar) {
+    __shared__ T red[16];
+    T acc = 0, gm_b = 0, gv_b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T m = mean[n_mean == 1 ? 0 : i], v = var[n_var == 1 ? 0 : i];
+        const T iv = (T)1 / v;
+        const T c = (T)(-0.5 * LOG2PI) - (T)0.5 * log(v);
+        T gm = 0, gv = 0;
+        for (int s = 0; s < S; ++s) {
+            const T d = x[(int64_t)s * n + i] - m;
+            acc += c - (T)0.5 * d * d * iv;
+            const T g = -d * iv * scale;                 // d/dx
+            if (dx) dx[(int64_t)s * n + i] += g;
+            gm -= g;                                      // d/dmean = -d/dx
+            gv += scale * (T)0.5 * (d * d * iv * iv - iv);   // d/dvar
+        }
+        if (dmean) { if (n_mean == 1) gm_b += gm; else dmean[i] += gm; }
+        if (dvar) { if (n_var == 1) gv_b += gv; else dvar[i] += gv; }
+    }
+    acc = block_sum<T>(acc, red);
+    if (threadIdx.x == 0 && out) atomic_add(out, acc * scale);
+    if (dmean && n_mean == 1) { gm_b = block_sum<T>(gm_b, red); if (threadIdx.x == 0) atomic_add(dmean, gm_b); }
+    if (dvar && n_var == 1) { gv_b = block_sum<T>(gv_b, red); if (threadIdx.x == 0) atomic_add(dvar, gv_b); }
+}
+
+template <typename T>
+__global__ void adam_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, T lr_t, T b1,
+                            T b2, T eps, T rescale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T gi = g[i] * rescale;
+        const T mi = b1 * m[i] + ((T)1 - b1) * gi;
+        const T vi = b2 * v[i] + ((T)1 - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] -= lr_t * mi / (sqrt(vi) + eps);
+    }
+}
+
+inline unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+#define DISPATCH(h, dtype, name, CALLF, CALLD)             \
+    do {                                                   \
+        if (dtype == MXF_F32) { CALLF; }                   \
+        else if (dtype == MXF_F64) { CALLD; }              \
+        else MXF_FAIL(h, -2, name ": bad dtype %d", dtype); \
+        MXF_LAUNCH_CHECK(h);                               \
+        return 0;                                          \
+    } while (0)
+
+extern "C" int mxf_softplus_fwd(mxf_handle h, int dtype, int64_t n, const void* x, void* y, void* stream) {
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_softplus_fwd",
+             hipLaunchKernelGGL((softplus_fwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, n, (const float*)x, (float*)y),
+             hipLaunchKernelGGL((softplus_fwd_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (const double*)x, (double*)y));
+}
+
+extern "C" int mxf_softplus_bwd(mxf_handle h, int dtype, int64_t n, const void* x, const void* dy, void* dx_acc, void* stream) {
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_softplus_bwd",
+             hipLaunchKernelGGL((softplus_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, n, (const float*)x, (const float*)dy, (float*)dx_acc),
+             hipLaunchKernelGGL((softplus_bwd_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (const double*)x, (const double*)dy, (double*)dx_acc));
+}
+
+extern "C" int mxf_normal_reparam(mxf_handle h, int dtype, int S, int64_t n, const void* mean, const void* var, const void* eps,
+                                  void* x, void* stream) {
+    if (!h) return -1;
+    if (n <= 0 || S <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_normal_reparam",
+             hipLaunchKernelGGL((reparam_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const float*)mean, (const float*)var, (const float*)eps, (float*)x),
+             hipLaunchKernelGGL((reparam_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const double*)mean, (const double*)var, (const double*)eps, (double*)x));
+}
+
+extern "C" int mxf_normal_reparam_bwd(mxf_handle h, int dtype, int S, int64_t n, const void* var, const void* eps, const void* dx,
+                                      void* dmean_acc, void* dvar_acc, void* stream) {
+    if (!h) return -1;
+    if (n <= 0 || S <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_normal_reparam_bwd",
+             hipLaunchKernelGGL((reparam_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const float*)var, (const float*)eps, (const float*)dx, (float*)dmean_acc, (float*)dvar_acc),
+             hipLaunchKernelGGL((reparam_bwd_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const double*)var, (const double*)eps, (const double*)dx, (double*)dmean_acc, (double*)dvar_acc));
+}
+
+extern "C" int mxf_normal_logpdf(mxf_handle h, int dtype, int S, int64_t n, const void* x, const void* mean, int64_t n_mean,
+                                 const void* var, int64_t n_var, double scale, void* out_acc, void* dx_acc, void* dmean_acc,
+                                 void* dvar_acc, void* stream) {
+    if (!h) return -1;
+    if (n <= 0 || S <= 0) return 0;
+    if ((n_mean != 1 && n_mean != n) || (n_var != 1 && n_var != n)) MXF_FAIL(h, -2, "mxf_normal_logpdf: mean/var must have 1 or n elements");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_normal_logpdf",
+             hipLaunchKernelGGL((normal_logpdf_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const float*)x, (const float*)mean, n_mean, (const float*)var, n_var, (float)scale, (float*)out_acc, (float*)dx_acc, (float*)dmean_acc, (float*)dvar_acc),
+             hipLaunchKernelGGL((normal_logpdf_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const double*)x, (const double*)mean, n_mean, (const double*)var, n_var, scale, (double*)out_acc, (double*)dx_acc, (double*)dmean_acc, (double*)dvar_acc));
+}
+
+extern "C" int mxf_adam_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* m, void* v, double lr, double beta1,
+                             double beta2, double epsilon, double rescale_grad, int t, void* stream) {
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    if (t < 1) MXF_FAIL(h, -2, "mxf_adam_step: t must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+    DISPATCH(h, dtype, "mxf_adam_step",
+             hipLaunchKernelGGL((adam_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, n, (float*)w, (const float*)g, (float*)m, (float*)v, (float)lr_t, (float)beta1, (float)beta2, (float)epsilon, (float)rescale_grad),
+             hipLaunchKernelGGL((adam_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)m, (double*)v, lr_t, beta1, beta2, epsilon, rescale_grad));
+}

@@ -6,3 +6,15 @@
 int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
                       void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st);
+
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st);
+// rhs_lower: B is block-lower-triangular (trtri); only columns < (k+1)*64 of block row k are touched
+int mxf_trsm_internal(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t nrhs, const void* L, int64_t ldl,
+                      int64_t sL, void* B, int64_t ldb, int64_t sB, int rhs_lower, hipStream_t st);
+int mxf_trtri_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t sL, void* Linv, int64_t ldi,
+                       int64_t sI, hipStream_t st);
+int mxf_sumlogdiag_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t sL, void* out, hipStream_t st);
+
+int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int64_t N2, int Q, const void* X, int64_t sX,
+                          const void* X2, int64_t sX2, const void* ls, int ard, int64_t sls, const void* var, int64_t svar,
+                          const void* dK, int64_t lddk, int64_t sdK, void* dX, void* dX2, void* dls, void* dvar, hipStream_t st);

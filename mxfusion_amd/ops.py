@@ -79,3 +79,103 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
     _lib.call('mxf_gemm', _h(A), _dt(A), int(transA), int(transB), M, N, K, float(alpha), _p(A), A.stride(-2), _ss(A),
               _p(B), B.stride(-2), _ss(B), float(beta), _p(out), out.stride(-2), out.stride(0), S, _stream())
     return out
+
+
+def gram_bwd(kind, X, X2, lengthscale, variance, ard, dK, need=('X', 'X2', 'ls', 'var')):
+    """Reverse mode of gram(); returns (dX, dX2, dls, dvar) shaped like their primals (summed over S for
+    broadcast operands)."""
+    X, X2, lengthscale, variance, dK = _c(X), _c(X2), _c(lengthscale), _c(variance), _c(dK)
+    S = dK.shape[0]
+    N, Q = X.shape[-2], X.shape[-1]
+    N2 = N if X2 is None else X2.shape[-2]
+    dX = torch.zeros_like(X) if 'X' in need else None
+    dX2 = torch.zeros_like(X2) if (X2 is not None and 'X2' in need) else None
+    dls = torch.zeros_like(lengthscale) if 'ls' in need else None
+    dvar = torch.zeros_like(variance) if 'var' in need else None
+    _lib.call('mxf_gram_bwd', _h(X), KIND[kind] if isinstance(kind, str) else kind, _dt(X), S, N, N2, Q,
+              _p(X), _ss(X), _p(X2), _ss(X2), _p(lengthscale), int(bool(ard)), _ss(lengthscale), _p(variance), _ss(variance),
+              _p(dK), dK.stride(-2), dK.stride(0), _p(dX), _p(dX2), _p(dls), _p(dvar), _stream())
+    return dX, dX2, dls, dvar
+
+
+def potrf_(A, info=None):
+    """in-place batched lower Cholesky of A (S,n,n); returns (A, info) with info an int32 device tensor."""
+    S, n = A.shape[0], A.shape[-1]
+    if info is None:
+        info = torch.zeros(S, dtype=torch.int32, device=A.device)
+    _lib.call('mxf_potrf', _h(A), _dt(A), S, n, _p(A), A.stride(-2), A.stride(0), _p(info), _stream())
+    return A, info
+
+
+def check_info(info, what='potrf'):
+    """Host sync + raise on a non-positive-definite matrix (MXNet raises lazily at the next blocking read)."""
+    bad = info.nonzero()
+    if bad.numel():
+        s = int(bad[0, 0])
+        raise _lib.MXFError('%s: matrix of sample %d is not positive definite (leading minor %d)'
+                            % (what, s, int(info[s])))
+
+
+def trsm_(L, B, transpose=False):
+    """B <- op(L)^-1 B in place; L (S|1,n,n) lower, B (S,n,nrhs)."""
+    L = _c(L)
+    S, n, nrhs = B.shape[0], B.shape[-2], B.shape[-1]
+    _lib.call('mxf_trsm', _h(B), _dt(B), int(bool(transpose)), S, n, nrhs, _p(L), L.stride(-2), _ss(L), _p(B), B.stride(-2),
+              B.stride(0), _stream())
+    return B
+
+
+def trtri(L):
+    L = _c(L)
+    S, n = L.shape[0], L.shape[-1]
+    out = torch.empty_like(L)
+    _lib.call('mxf_trtri', _h(L), _dt(L), S, n, _p(L), L.stride(-2), L.stride(0), _p(out), out.stride(-2), out.stride(0), _stream())
+    return out
+
+
+def sumlogdiag(L):
+    L = _c(L)
+    S, n = L.shape[0], L.shape[-1]
+    out = torch.empty(S, dtype=L.dtype, device=L.device)
+    _lib.call('mxf_sumlogdiag', _h(L), _dt(L), S, n, _p(L), L.stride(-2), L.stride(0), _p(out), _stream())
+    return out
+
+
+def softplus(x):
+    x = _c(x)
+    y = torch.empty_like(x)
+    _lib.call('mxf_softplus_fwd', _h(x), _dt(x), x.numel(), _p(x), _p(y), _stream())
+    return y
+
+
+def softplus_bwd_(x, dy, dx_acc):
+    _lib.call('mxf_softplus_bwd', _h(x), _dt(x), x.numel(), _p(_c(x)), _p(_c(dy)), _p(dx_acc), _stream())
+    return dx_acc
+
+
+def normal_reparam(mean, var, eps):
+    """x[s] = mean + eps[s]*sqrt(var); mean/var (n...), eps (S, n...)."""
+    mean, var, eps = _c(mean), _c(var), _c(eps)
+    x = torch.empty_like(eps)
+    _lib.call('mxf_normal_reparam', _h(eps), _dt(eps), eps.shape[0], mean.numel(), _p(mean), _p(var), _p(eps), _p(x), _stream())
+    return x
+
+
+def normal_reparam_bwd_(var, eps, dx, dmean_acc, dvar_acc):
+    _lib.call('mxf_normal_reparam_bwd', _h(eps), _dt(eps), eps.shape[0], var.numel(), _p(_c(var)), _p(_c(eps)), _p(_c(dx)),
+              _p(dmean_acc), _p(dvar_acc), _stream())
+
+
+def normal_logpdf_(x, mean, var, scale, out_acc, dx_acc=None, dmean_acc=None, dvar_acc=None):
+    """out_acc += scale * sum_{s,i} log N(x[s,i]|mean[i],var[i]) (+ reverse mode into the *_acc buffers)."""
+    x, mean, var = _c(x), _c(mean), _c(var)
+    S = x.shape[0]
+    n = x.numel() // S
+    _lib.call('mxf_normal_logpdf', _h(x), _dt(x), S, n, _p(x), _p(mean), mean.numel(), _p(var), var.numel(), float(scale),
+              _p(out_acc), _p(dx_acc), _p(dmean_acc), _p(dvar_acc), _stream())
+    return out_acc
+
+
+def adam_step_(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8, rescale_grad=1.0):
+    _lib.call('mxf_adam_step', _h(w), _dt(w), w.numel(), _p(w), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
+              float(epsilon), float(rescale_grad), int(t), _stream())

@@ -1,0 +1,138 @@
+"""GPU parity: blocked Cholesky / triangular solves / inverse / log-det / Gram reverse mode / elementwise
+kernels (through the C ABI) vs the CPU oracle (torch float64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _spd(rng, S, n, cond_shift=1.0):
+    A = rng.randn(S, n, n)
+    return A @ np.swapaxes(A, 1, 2) / n + cond_shift * np.eye(n)[None]
+
+
+def _dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize('S,n', [(1, 1), (2, 5), (1, 64), (3, 65), (1, 200), (2, 513), (1, 1100)])
+def test_potrf_trsm_trtri_logdet(dtype, tol, S, n):
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(n)
+    A = _spd(rng, S, n)
+    Lref = np.linalg.cholesky(A)
+    L, info = ops.potrf_(_dev(A, dtype))
+    assert int(info.abs().sum()) == 0
+    Lh = L.cpu().numpy()
+    assert np.allclose(Lh, Lref, rtol=tol, atol=tol)
+    assert np.all(np.triu(Lh, 1) == 0)          # MXNet potrf returns a clean lower triangle
+    sld = ops.sumlogdiag(L).cpu().numpy()
+    assert np.allclose(sld, np.log(np.diagonal(Lref, axis1=1, axis2=2)).sum(-1), rtol=tol, atol=tol * n)
+    for nrhs in (1, 3, 300):
+        B = rng.randn(S, n, nrhs)
+        for tr in (False, True):
+            Lt = np.swapaxes(Lref, 1, 2) if tr else Lref
+            ref = np.linalg.solve(Lt, B)
+            X = ops.trsm_(_dev(Lref, dtype), _dev(B, dtype), transpose=tr).cpu().numpy()
+            assert np.allclose(X, ref, rtol=tol * 10, atol=tol * 10 * np.abs(ref).max()), (nrhs, tr)
+    Li = ops.trtri(_dev(Lref, dtype)).cpu().numpy()
+    assert np.allclose(Li, np.linalg.inv(Lref), rtol=tol * 10, atol=tol * 10)
+    # L broadcast over samples (stride 0)
+    B = rng.randn(2, n, 4)
+    X = ops.trsm_(_dev(Lref[:1], dtype), _dev(B, dtype)).cpu().numpy()
+    assert np.allclose(X, np.linalg.solve(Lref[:1], B), rtol=tol * 10, atol=tol * 10 * np.abs(X).max())
+
+
+def test_potrf_not_positive_definite_reports_info():
+    from mxfusion_amd import ops, _lib
+    A = np.eye(70)[None].repeat(2, 0)
+    A[1, 66, 66] = -1.0
+    L, info = ops.potrf_(_dev(A))
+    assert info.cpu().tolist() == [0, 67]
+    with pytest.raises(_lib.MXFError):
+        ops.check_info(info)
+
+
+KINDS = {'rbf': O.RBF, 'matern12': O.Matern12, 'matern32': O.Matern32, 'matern52': O.Matern52}
+
+
+@pytest.mark.parametrize('kind', list(KINDS))
+@pytest.mark.parametrize('N,N2,Q,S,ard', [(7, 5, 3, 1, True), (70, 300, 8, 2, True), (130, None, 5, 2, False), (64, 257, 16, 1, True)])
+def test_gram_bwd_vs_autograd(kind, N, N2, Q, S, ard):
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(N + Q)
+    X = rng.uniform(-2, 2, (S, N, Q))
+    X2 = None if N2 is None else rng.uniform(-2, 2, (1, N2, Q))      # X2 broadcast over S: its gradient sums over S
+    ls = rng.rand(1, Q if ard else 1) + 0.8
+    var = rng.rand(1, 1) + 0.5
+    dK = rng.randn(S, N, N if N2 is None else N2)
+    k = KINDS[kind](Q, ARD=ard)
+    tX, tls, tvar = [O.T(a).clone().requires_grad_(True) for a in (X, ls, var)]
+    tX2 = None if X2 is None else O.T(X2).clone().requires_grad_(True)
+    K = k.K(tX, tX2, **{k.name + '_lengthscale': tls, k.name + '_variance': tvar})
+    (K * O.T(dK)).sum().backward()
+    dX, dX2, dls, dvar = ops.gram_bwd(kind, _dev(X), None if X2 is None else _dev(X2), _dev(ls), _dev(var), ard, _dev(dK))
+    for got, ref, name in ((dX, tX.grad, 'dX'), (dX2, None if tX2 is None else tX2.grad, 'dX2'), (dls, tls.grad, 'dls'),
+                           (dvar, tvar.grad, 'dvar')):
+        if ref is None:
+            assert got is None
+            continue
+        r = ref.numpy()
+        assert np.allclose(got.cpu().numpy(), r, rtol=1e-9, atol=1e-9 * max(1., np.abs(r).max())), name
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-12), (torch.float32, 1e-5)])
+def test_elementwise_kernels(dtype, tol):
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.randn(1000) * 3, [-80., -30., 0., 30., 80.]])
+    y = ops.softplus(_dev(x, dtype)).cpu().numpy()
+    assert np.allclose(y, O.softplus(O.T(x)).numpy(), rtol=tol, atol=1e-30)
+    dy = rng.randn(x.size)
+    dx = ops.softplus_bwd_(_dev(x, dtype), _dev(dy, dtype), torch.zeros(x.size, dtype=dtype).cuda()).cpu().numpy()
+    assert np.allclose(dx, dy / (1 + np.exp(-x)), rtol=tol, atol=tol)
+    # Normal reparameterisation + log-pdf with reverse mode (normal.py:52-92, factor_graph.py:223)
+    S, n = 5, 333
+    mean, var, eps = rng.randn(n), rng.rand(n) + 0.2, rng.randn(S, n)
+    tm, tv = O.T(mean).requires_grad_(True), O.T(var).requires_grad_(True)
+    xs = O.normal_draw(tm, tv, O.T(eps))
+    xg = ops.normal_reparam(_dev(mean, dtype), _dev(var, dtype), _dev(eps, dtype))
+    assert np.allclose(xg.cpu().numpy(), xs.detach().numpy(), rtol=tol, atol=tol)
+    xs_leaf = xs.detach().clone().requires_grad_(True)
+    pm, pv = O.T(rng.randn(n)).requires_grad_(True), O.T(rng.rand(n) + 0.3).requires_grad_(True)
+    lp = O.factor_sum(O.normal_log_pdf(pm, pv, xs_leaf)) * -1.0      # scale = -1/S (posterior term of variational.py:107)
+    lp.backward()
+    out = torch.zeros(1, dtype=dtype).cuda()
+    dxa, dma, dva = [torch.zeros(sh, dtype=dtype).cuda() for sh in ((S, n), (n,), (n,))]
+    ops.normal_logpdf_(_dev(xs_leaf.detach().numpy(), dtype), _dev(pm.detach().numpy(), dtype), _dev(pv.detach().numpy(), dtype),
+                       -1.0 / S, out, dxa, dma, dva)
+    assert np.allclose(out.cpu().numpy(), float(lp), rtol=max(tol, 1e-12) * 10)
+    assert np.allclose(dxa.cpu().numpy(), xs_leaf.grad.numpy(), rtol=tol * 10, atol=tol * 10)
+    assert np.allclose(dma.cpu().numpy(), pm.grad.numpy(), rtol=tol * 10, atol=tol * 10)
+    assert np.allclose(dva.cpu().numpy(), pv.grad.numpy(), rtol=tol * 100, atol=tol * 100)
+    # scalar (broadcast) prior mean/var as in Normal.define_variable(mean=0, variance=1)
+    out2 = torch.zeros(1, dtype=dtype).cuda()
+    ops.normal_logpdf_(xg, _dev([0.], dtype), _dev([1.], dtype), 1.0 / S, out2)
+    ref2 = float(O.factor_sum(O.normal_log_pdf(O.T([0.]), O.T([1.]), xs.detach())))
+    assert np.allclose(out2.cpu().numpy(), ref2, rtol=max(tol, 1e-12) * 10)
+    # reparam reverse mode
+    gx = rng.randn(S, n)
+    (xs * O.T(gx)).sum().backward()
+    dm, dv = torch.zeros(n, dtype=dtype).cuda(), torch.zeros(n, dtype=dtype).cuda()
+    ops.normal_reparam_bwd_(_dev(var, dtype), _dev(eps, dtype), _dev(gx, dtype), dm, dv)
+    assert np.allclose(dm.cpu().numpy(), tm.grad.numpy(), rtol=tol * 10, atol=tol * 10)
+    assert np.allclose(dv.cpu().numpy(), tv.grad.numpy(), rtol=tol * 10, atol=tol * 10)
+    # MXNet Adam, 3 steps vs the oracle's restatement
+    w = rng.randn(257)
+    opt = O.MXNetAdam(0.05)
+    wd, m, v = _dev(w, dtype), torch.zeros(257, dtype=dtype).cuda(), torch.zeros(257, dtype=dtype).cuda()
+    p = {'w': O.T(w)}
+    for t in range(1, 4):
+        g = rng.randn(257)
+        p = opt.step(p, {'w': O.T(g)}, batch_size=4)
+        ops.adam_step_(wd, _dev(g, dtype), m, v, 0.05, t, rescale_grad=0.25)
+    assert np.allclose(wd.cpu().numpy(), p['w'].numpy(), rtol=tol * 10, atol=tol * 10)
