@@ -1,0 +1,498 @@
+// Fused composites: one C-ABI call = one reference `compute` body (value + reverse mode), gfx950.
+//
+//   mxf_gp_logpdf   <- GPRegressionLogPdf.compute        (modules/gp_modules/gp_regression.py:42-76)
+//   mxf_svgp_logpdf <- SVGPRegressionLogPdf.compute      (modules/gp_modules/svgp_regression.py:43-109)
+//
+// The reference gets gradients from MXNet autograd through potrf/trsm; here the reverse mode is closed
+// form (matrix-calculus identities with K^-1 from the Cholesky factor), so every O(n^3) piece is an MFMA
+// GEMM and no reverse-mode Cholesky is needed.
+//
+// SVGP is evaluated in the streaming sufficient-statistics form.  With Ki = Kuu^-1,
+// H0 = Ki - Ki Su Ki,  w = Ki mu,  k_n = Kuf[:, n],  beta = 1/noise:
+//     l_s   = -B P/2 (log 2pi + log noise) - P beta B var/2 - beta/2 sum_n |y_n - w^T k_n|^2
+//             + P beta/2 sum_n k_n^T H0 k_n
+//     logL_s = scaling * l_s + negKL,
+//     negKL = P/2 (M + logdet Su - logdet Kuu - tr(Ki Su)) - 1/2 tr(mu^T Ki mu)
+// All samples' columns are laid side by side (Kuf_all : M x (S*B)), so the data term is TWO big MFMA
+// GEMMs ( [H0; w^T] * Kuf_all and Kuf_all * Kuf_all^T ) instead of S batched trsm/gemm2 pairs, and the
+// (M x M) factorisation work is done ONCE (not S times: runtime_variable.py:96-99 broadcast) in float64.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr double LOG2PI = 1.8378770664093453;
+
+// ------------------------------------------------------------------------------------ small kernels
+template <typename TI, typename TO>
+__global__ void convert_kernel(int64_t rows, int64_t cols, const TI* __restrict__ src, int64_t lds_, TO* __restrict__ dst, int64_t ldd) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[r * ldd + c] = (TO)src[r * lds_ + c];
+    }
+}
+// dst[c][r] = src[r][c]
+template <typename TI, typename TO>
+__global__ void transpose_convert_kernel(int64_t rows, int64_t cols, const TI* __restrict__ src, int64_t lds_, TO* __restrict__ dst, int64_t ldd) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[c * ldd + r] = (TO)src[r * lds_ + c];
+    }
+}
+// dst = a*x + b*y (elementwise, contiguous)
+template <typename T>
+__global__ void axpby_kernel(int64_t n, T a, const T* __restrict__ x, T b, const T* __restrict__ y, T* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = a * x[i] + (y ? b * y[i] : (T)0);
+}
+// dst(TO) (+)= a * (TO)src(TI)
+template <typename TI, typename TO>
+__global__ void add_convert_kernel(int64_t n, TO a, const TI* __restrict__ src, TO* __restrict__ dst, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (accumulate ? dst[i] : (TO)0) + a * (TO)src[i];
+}
+template <typename T>
+__global__ void diag_embed_kernel(int64_t n, const T* __restrict__ d, T* __restrict__ A) {   // A = diag(d)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += (int64_t)gridDim.x * blockDim.x)
+        A[i] = (i / n == i % n) ? d[i / n] : (T)0;
+}
+template <typename TI, typename TO>
+__global__ void diag_extract_kernel(int64_t n, const TI* __restrict__ A, int64_t lda, TO* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (TO)A[i * lda + i];
+}
+// out (+)= scale * sum_i x[i]*y[i]
+template <typename T>
+__global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T* __restrict__ x, const T* __restrict__ y, double scale, double* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += (double)x[i] * (double)y[i];
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) atomic_add(out, s * scale);
+}
+// copy lower triangle to upper (tiled transpose through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;   // tile (by, bx) of the LOWER part, bx <= by
+    if (bx > by) return;
+    T* a = A + (int64_t)blockIdx.z * sA;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t row = (int64_t)by * 32 + r, col = (int64_t)bx * 32 + tx;
+        tile[r][tx] = (row < n && col < n) ? a[row * lda + col] : (T)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t row = (int64_t)bx * 32 + r, col = (int64_t)by * 32 + tx;   // transposed position
+        if (row < n && col < n && col > row) a[row * lda + col] = tile[tx][r];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const T* __restrict__ x, int64_t sx, double* __restrict__ out) {
+    __shared__ double red[16];
+    const T* p = x + (int64_t)blockIdx.x * sx;
+    double s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)p[i] * (double)p[i];
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void trace_kernel(int64_t n, const T* __restrict__ A, int64_t lda, int64_t sA, T* __restrict__ out) {
+    __shared__ double red[16];
+    const T* a = A + (int64_t)blockIdx.x * sA;
+    double s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)a[i * lda + i];
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = (T)s;
+}
+template <typename T>
+__global__ void gp_finalize_kernel(int S, int64_t N, int P, const T* __restrict__ sld, const double* __restrict__ ss, T* __restrict__ logL) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) logL[s] = (T)(-(double)P * (double)sld[s] - 0.5 * (ss[s] + (double)N * P * LOG2PI));
+}
+// Y (S|1,n) -> dst (S,n), optionally negated
+template <typename T>
+__global__ void bcast_copy_kernel(int S, int64_t n, const T* __restrict__ src, int64_t ssrc, T* __restrict__ dst, T scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = scale * src[(i / n) * ssrc + (i % n)];
+}
+
+inline unsigned gridn(int64_t n) { int64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; }
+
+struct Carver {   // bump allocator over the handle's scratch
+    char* base; size_t off = 0;
+    explicit Carver(void* p) : base((char*)p) {}
+    template <typename U> U* take(size_t n) { U* p = (U*)(base + off); off += mxf_align(n * sizeof(U)); return p; }
+};
+
+// ================================================================================================ exact GP
+template <typename T>
+int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, int P, const T* X, int64_t sX, const T* Y, int64_t sY,
+                    const T* noise, int64_t snoise, const T* ls, int ard, int64_t sls, const T* var, int64_t svar, double jitter,
+                    T* logL, T* L, T* LinvY, int* info, int want_grad, T* dX, T* dY, T* dnoise, T* dls, T* dvar, hipStream_t st) {
+    const int64_t NN = N * N, NP = N * P;
+    size_t need = mxf_align(S * sizeof(T)) + mxf_align(S * sizeof(double));
+    if (want_grad) need += 2 * mxf_align((size_t)S * NN * sizeof(T)) + mxf_align((size_t)S * NP * sizeof(T));
+    void* ws = mxf_ws(h, need);
+    if (!ws) MXF_FAIL(h, -4, "mxf_gp_logpdf: cannot allocate %zu bytes of scratch", need);
+    Carver cv(ws);
+    T* sld = cv.take<T>(S);
+    double* ss = cv.take<double>(S);
+    int rc;
+    // K = k(X,X) + (noise + jitter) I   (gp_regression.py:55-60), built straight into the L buffer
+    rc = mxf_gram(h, kind, dtype, S, N, N, Q, X, sX, nullptr, 0, ls, ard, sls, var, svar, noise, snoise, jitter, MXF_WRITE, L, N, NN, st);
+    if (rc) return rc;
+    rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st);                        // :61
+    if (rc) return rc;
+    hipLaunchKernelGGL((bcast_copy_kernel<T>), dim3(gridn(S * NP)), dim3(256), 0, st, S, NP, Y, sY, LinvY, (T)1);
+    rc = mxf_trsm_internal(h, dtype, 0, S, N, P, L, N, NN, LinvY, P, NP, 0, st);        // :66
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, dtype, S, N, L, N, NN, sld, st);                    // :67
+    if (rc) return rc;
+    hipLaunchKernelGGL((sumsq_kernel<T>), dim3(S), dim3(256), 0, st, NP, LinvY, NP, ss);
+    hipLaunchKernelGGL((gp_finalize_kernel<T>), dim3((S + 63) / 64), dim3(64), 0, st, S, N, P, sld, ss, logL);   // :68-70
+    MXF_LAUNCH_CHECK(h);
+    if (!want_grad) return 0;
+
+    // reverse mode: dlogL/dK = 1/2 (alpha alpha^T - P K^-1), alpha = K^-1 Y; dlogL/dY = -alpha
+    T* Linv = cv.take<T>((size_t)S * NN);
+    T* dK = cv.take<T>((size_t)S * NN);
+    T* alpha = cv.take<T>((size_t)S * NP);
+    rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 1, 0, N, P, N, 1.0, Linv, N, NN, LinvY, P, NP, 0.0, alpha, P, NP, S, 0, st);   // alpha = Linv^T LinvY
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 0, 1, N, N, P, 0.5, alpha, P, NP, alpha, P, NP, 0.0, dK, N, NN, S, 1, st);     // 1/2 alpha alpha^T (lower)
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 1, 0, N, N, N, -0.5 * P, Linv, N, NN, Linv, N, NN, 1.0, dK, N, NN, S, 1, st);  // - P/2 Linv^T Linv (lower)
+    if (rc) return rc;
+    hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32), S), dim3(256), 0, st, dK, N, N, NN);
+    if (dY) hipLaunchKernelGGL((bcast_copy_kernel<T>), dim3(gridn(S * NP)), dim3(256), 0, st, S, NP, (const T*)alpha, NP, dY, (T)-1);
+    if (dnoise) hipLaunchKernelGGL((trace_kernel<T>), dim3(S), dim3(256), 0, st, N, (const T*)dK, N, NN, dnoise);
+    const int lsn = ard ? Q : 1;
+    if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * S * N * Q, st));
+    if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * S * lsn, st));
+    if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T) * S, st));
+    // outputs are per sample (S, ...) even when the primal is broadcast: use per-sample strides for the outputs
+    // by running one sample at a time when the primal stride is 0
+    for (int s = 0; s < S; ++s) {
+        rc = mxf_gram_bwd_internal(h, kind, dtype, 1, N, N, Q, X + (int64_t)s * sX, 0, nullptr, 0, ls + (int64_t)s * sls, ard, 0,
+                                   var + (int64_t)s * svar, 0, dK + (int64_t)s * NN, N, NN,
+                                   dX ? dX + (int64_t)s * N * Q : nullptr, nullptr, dls ? dls + (int64_t)s * lsn : nullptr,
+                                   dvar ? dvar + s : nullptr, st);
+        if (rc) return rc;
+    }
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+// ================================================================================================ SVGP
+// per column n (of all S*B columns): e = y - u, q = k^T (H0 k); T <- a1*beta*(P*T + w e); partial sums per sample
+template <typename T>
+__global__ __launch_bounds__(256) void svgp_mid_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf,
+                                                       T* __restrict__ Text, const T* __restrict__ Y, int64_t sY,
+                                                       const T* __restrict__ w /* M x P */, const T* __restrict__ noise, double a1,
+                                                       int want_grad, T* __restrict__ E /* SB x P */, T* __restrict__ dY, int dY_shared,
+                                                       double* __restrict__ scal /* [S][2] : sum q, sum e^2 */) {
+    __shared__ double red[16];
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = n < SB;
+    const int64_t s = valid ? n / B : 0, nb = valid ? n % B : 0;
+    const T beta = (T)1 / noise[0];
+    constexpr int PMAX = 8;
+    T e[PMAX];
+    double e2 = 0;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        e[p] = 0;
+        if (p < P && valid) {
+            e[p] = Y[s * sY + nb * P + p] - Text[(M + p) * SB + n];
+            e2 += (double)e[p] * (double)e[p];
+            if (E) E[n * P + p] = e[p];
+            if (want_grad && dY) {
+                const T g = (T)(-a1) * beta * e[p];
+                if (dY_shared) atomic_add(dY + nb * P + p, g); else dY[n * P + p] = g;
+            }
+        }
+    }
+    T q = 0;
+    const T c1 = (T)a1 * beta, cP = (T)P;
+    if (valid) {
+        for (int64_t m = 0; m < M; ++m) {
+            const T k = Kuf[m * SB + n], t = Text[m * SB + n];
+            q = fma(k, t, q);
+            if (want_grad) {
+                T we = 0;
+#pragma unroll
+                for (int p = 0; p < PMAX; ++p) if (p < P) we = fma(w[m * P + p], e[p], we);
+                Text[m * SB + n] = c1 * (cP * t + we);
+            }
+        }
+    }
+    // blocks never straddle... they may: reduce per sample with a segmented approach (block spans <= 2 samples when B>=256;
+    // general case: per-thread atomics when the block straddles)
+    const int64_t n0 = (int64_t)blockIdx.x * 256, n1 = (n0 + 255 < SB - 1) ? n0 + 255 : SB - 1;
+    if (n0 / B == n1 / B) {
+        double qs = block_sum<double>((double)q, red);
+        double es = block_sum<double>(e2, red);
+        if (threadIdx.x == 0) { atomic_add(scal + 2 * (n0 / B), qs); atomic_add(scal + 2 * (n0 / B) + 1, es); }
+    } else if (valid) {
+        atomic_add(scal + 2 * s, (double)q);
+        atomic_add(scal + 2 * s + 1, e2);
+    }
+}
+
+// A_Ki = (G - T1 - T1^T) + 1/2 (Gw mu^T + mu Gw^T) - b (P/2 Su + 1/2 mu mu^T)
+__global__ void aki_kernel(int64_t M, int P, const double* __restrict__ G, const double* __restrict__ T1, const double* __restrict__ Gw,
+                           const double* __restrict__ mu, const double* __restrict__ Su, double b, double* __restrict__ A) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * M; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / M, j = idx % M;
+        double v = G[idx] - T1[idx] - T1[j * M + i];
+        double r1 = 0, mm = 0;
+        for (int p = 0; p < P; ++p) { r1 += Gw[i * P + p] * mu[j * P + p] + mu[i * P + p] * Gw[j * P + p]; mm += mu[i * P + p] * mu[j * P + p]; }
+        A[idx] = v + 0.5 * r1 - b * (0.5 * P * Su[idx] + 0.5 * mm);
+    }
+}
+// G' = (P/2 * a1 * beta) * Psi2 ; Gw = a1*beta*R   (beta on device)
+template <typename T>
+__global__ void scale_beta_kernel(int64_t n, const T* __restrict__ src, const double* __restrict__ noise, double c, double* __restrict__ dst) {
+    const double beta = 1.0 / noise[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = c * beta * (double)src[i];
+}
+// logL[s], and the direct (non-Gram) gradient terms w.r.t. noise and kernel variance
+template <typename T>
+__global__ void svgp_finalize_kernel(int S, int64_t B, int64_t M, int P, const double* __restrict__ scal, const double* __restrict__ noise,
+                                     const double* __restrict__ var, const double* __restrict__ sldL, const double* __restrict__ sldLs,
+                                     const double* __restrict__ trKiSu, const double* __restrict__ muw, double scaling, double a1,
+                                     T* __restrict__ logL, double* __restrict__ dnoise, double* __restrict__ dvar_direct) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double s2 = noise[0], beta = 1.0 / s2, vk = var[0];
+    const double negKL = 0.5 * P * ((double)M + 2.0 * sldLs[0] - 2.0 * sldL[0] - trKiSu[0]) - 0.5 * muw[0];
+    double dn = 0;
+    for (int s = 0; s < S; ++s) {
+        const double Q0 = scal[2 * s], E2 = scal[2 * s + 1];
+        const double l = -0.5 * (double)B * P * (LOG2PI + log(s2)) - 0.5 * P * beta * (double)B * vk - 0.5 * beta * E2 + 0.5 * P * beta * Q0;
+        logL[s] = (T)(scaling * l + negKL);
+        dn += 0.5 * (double)B * P / beta - 0.5 * P * (double)B * vk - 0.5 * E2 + 0.5 * P * Q0;
+    }
+    if (dnoise) dnoise[0] = a1 * (-beta * beta) * dn;
+    if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * P * beta * (double)B);
+}
+
+template <typename T>
+int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P, const T* X, int64_t sX, const T* Y,
+                      int64_t sY, const T* Z, const T* noise, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
+                      double jitter, double scaling, double gscale, T* logL, int* info, int want_grad, T* dX, T* dY, T* dZ, T* dnoise,
+                      T* dmu, T* dW, T* dSdiag, T* dls, T* dvar, hipStream_t st) {
+    if (P > 8) MXF_FAIL(h, -3, "mxf_svgp_logpdf: P > 8 outputs not supported");
+    if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
+    const int SS = (sX == 0 && sY == 0) ? 1 : S;   // samples that need their own columns
+    // when X is shared but Y is sampled we still lay S copies of the columns (rare); X columns repeat
+    if (SS > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: sampled Y with shared X not supported in the fused path");
+    const int64_t SB = (int64_t)SS * B, MM = M * M, MP = M * P;
+    const int lsn = ard ? Q : 1;
+    const double a1 = gscale * scaling, bw = gscale * (double)S;
+    typedef double D;
+
+    size_t need = 0;
+    auto acc = [&](size_t n, size_t es) { need += mxf_align(n * es); };
+    acc(M * Q, 8); acc(lsn, 8); acc(1, 8); acc(1, 8); acc(MP, 8); acc(MM, 8); acc(M, 8);   // f64 copies of the parameters
+    for (int i = 0; i < 9; ++i) acc(MM, 8);   // L, Linv, Ki, Su(Ls), Lsinv, Sui, KiSu, H0, tmp
+    acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
+    acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
+    acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB * P, sizeof(T));
+    if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
+    void* ws = mxf_ws(h, need);
+    if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
+    Carver cv(ws);
+    D* Zd = cv.take<D>(M * Q); D* lsd = cv.take<D>(lsn); D* vard = cv.take<D>(1); D* noised = cv.take<D>(1);
+    D* mud = cv.take<D>(MP); D* Wd = cv.take<D>(MM); D* sd = cv.take<D>(M);
+    D* Lm = cv.take<D>(MM); D* Linv = cv.take<D>(MM); D* Ki = cv.take<D>(MM); D* Su = cv.take<D>(MM); D* Lsinv = cv.take<D>(MM);
+    D* Sui = cv.take<D>(MM); D* KiSu = cv.take<D>(MM); D* H0 = cv.take<D>(MM); D* tmp = cv.take<D>(MM);
+    D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
+    T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
+    T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB); T* E = cv.take<T>((size_t)SB * P);
+    // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
+
+#define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
+    CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
+#undef CONV
+    MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
+    MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
+    int rc;
+    // ---- core, float64, once -------------------------------------------------------------------------
+    rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu (+jitter) :69-72
+    if (rc) return rc;
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
+    if (rc) return rc;
+    rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
+    if (rc) return rc;
+    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, M, (const D*)sd, Su);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, st);        // Su = W W^T + diag(s) :76
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
+    if (rc) return rc;
+    MXF_HIP(h, hipMemcpyAsync(H0, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
+    if (rc) return rc;
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
+    if (rc) return rc;
+    // Ls = chol(Su) (needed for logdet Su; its inverse for d/dSu)           :84
+    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, st);
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, st);
+    if (rc) return rc;
+    if (want_grad) {
+        rc = mxf_trtri_internal(h, MXF_F64, 1, M, tmp, M, MM, Lsinv, M, MM, st);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, st);
+        if (rc) return rc;
+    }
+    // A_ext = [H0 ; w^T] in the streaming dtype
+    hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
+    hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
+    hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);
+
+    // ---- streaming part -----------------------------------------------------------------------------------
+    // Kuf_all = k(Z, X_all): M x SB                                          :73
+    rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, st);
+    if (rc) return rc;
+    // [T; U] = [H0; w^T] Kuf_all
+    rc = mxf_gemm_internal(h, dtype, 0, 0, M + P, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);
+    if (rc) return rc;
+    const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
+    if (want_grad && dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
+    hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
+                       (const T*)wT, noise, a1, want_grad, want_grad ? E : (T*)nullptr, dY, dY_shared, scal);
+    D* dnz = nullptr; D* dvdir = nullptr;
+    if (want_grad) { dnz = sc + 4; dvdir = sc + 5; }
+    // when X and Y are shared by all samples the S per-sample values are identical: replicate
+    if (SS == 1 && S > 1) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X");
+    hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
+                       (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
+    MXF_LAUNCH_CHECK(h);
+    if (!want_grad) return 0;
+
+    T* Psi2 = cv.take<T>(MM); T* R = cv.take<T>(MP);
+    D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
+    D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
+    // Kuf-side reverse mode: Text[0:M] now holds dJ/dKuf_all
+    T* dZs = dZ; T* dlss = dls; T* dvs = dvar;
+    if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
+    if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
+    if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
+    if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
+    rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, Text, SB, 0, dZs, dX, dlss, dvs, st);
+    if (rc) return rc;
+    // Psi2 = Kuf Kuf^T (split-K MFMA), R = Kuf E
+    rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Kuf, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, SB, 1.0, Kuf, SB, 0, E, P, 0, 0.0, R, P, 0, 1, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
+    hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
+    // ---- core reverse mode (float64) ---------------------------------------------------------------------
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, st);           // T1 = G Ki Su
+    if (rc) return rc;
+    hipLaunchKernelGGL(aki_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)G, (const D*)T1, (const D*)Gw, (const D*)mud, (const D*)Su, bw, AKi);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, AKi, M, 0, 0.0, T2, M, 0, 1, 0, st);           // T2 = Ki A_Ki
+    if (rc) return rc;
+    MXF_HIP(h, hipMemcpyAsync(dKuu, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);   // dKuu = -Ki A Ki - b P/2 Ki
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, T2, M, 0, 1, 0, st);             // T3 = Ki G  (reuse T2)
+    if (rc) return rc;
+    hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, 1.0, (const D*)Sui, -1.0, (const D*)Ki, dSu);   // Sui - Ki
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, 0.5 * bw * P, dSu, M, 0, 1, 0, st);  // dSu = -Ki G Ki + bP/2 (Sui - Ki)
+    if (rc) return rc;
+    hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);           // dmu = Ki Gw - b w
+    if (rc) return rc;
+    if (dmu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (T)1, (const D*)dmud, dmu, 0);
+    if (dW) {
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, T1, M, 0, 1, 0, st);        // dW = 2 dSu W
+        if (rc) return rc;
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (T)1, (const D*)T1, dW, 0);
+    }
+    if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, st, M, (const D*)dSu, M, dSdiag);
+    // Kuu-side reverse mode in float64, then added to the streaming-side gradients
+    MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
+    MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
+    MXF_HIP(h, hipMemsetAsync(dvc, 0, sizeof(D) * 4, st));
+    rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
+    if (rc) return rc;
+    if (dZ) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(M * Q)), dim3(256), 0, st, M * Q, (T)1, (const D*)dZc, dZ, 1);
+    if (dls) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(lsn)), dim3(64), 0, st, (int64_t)lsn, (T)1, (const D*)dlsc, dls, 1);
+    if (dvar) {
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
+    }
+    if (dnoise) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mxf_gp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t N, int Q, int P,
+                             const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                             const void* noise_var, int64_t strideS_noise,
+                             const void* lengthscale, int ard, int64_t strideS_ls,
+                             const void* variance, int64_t strideS_var, double jitter,
+                             void* logL, void* L, void* LinvY, int* info, int want_grad,
+                             void* dX, void* dY, void* dnoise, void* dls, void* dvar, void* stream) {
+    if (!h) return -1;
+    if (S <= 0 || N <= 0 || Q <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_gp_logpdf: bad shape");
+    if (!X || !Y || !noise_var || !lengthscale || !variance || !logL || !L || !LinvY) MXF_FAIL(h, -2, "mxf_gp_logpdf: null argument");
+    if (kind > MXF_K_MATERN52) MXF_FAIL(h, -2, "mxf_gp_logpdf: stationary kernels only");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MXF_F32)
+        return gp_logpdf_typed<float>(h, kind, dtype, S, N, Q, P, (const float*)X, strideS_X, (const float*)Y, strideS_Y, (const float*)noise_var,
+                                      strideS_noise, (const float*)lengthscale, ard, strideS_ls, (const float*)variance, strideS_var, jitter,
+                                      (float*)logL, (float*)L, (float*)LinvY, info, want_grad, (float*)dX, (float*)dY, (float*)dnoise,
+                                      (float*)dls, (float*)dvar, st);
+    if (dtype == MXF_F64)
+        return gp_logpdf_typed<double>(h, kind, dtype, S, N, Q, P, (const double*)X, strideS_X, (const double*)Y, strideS_Y, (const double*)noise_var,
+                                       strideS_noise, (const double*)lengthscale, ard, strideS_ls, (const double*)variance, strideS_var, jitter,
+                                       (double*)logL, (double*)L, (double*)LinvY, info, want_grad, (double*)dX, (double*)dY, (double*)dnoise,
+                                       (double*)dls, (double*)dvar, st);
+    MXF_FAIL(h, -2, "mxf_gp_logpdf: bad dtype %d", dtype);
+}
+
+extern "C" int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                               const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                               const void* Z, const void* noise_var, const void* qU_mean, const void* qU_cov_W,
+                               const void* qU_cov_diag, const void* lengthscale, int ard, const void* variance,
+                               double jitter, double scaling, double gscale,
+                               void* logL, int* info, int want_grad,
+                               void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
+                               void* dls, void* dvar, void* stream) {
+    if (!h) return -1;
+    if (S <= 0 || B <= 0 || M <= 0 || Q <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf: bad shape");
+    if (!X || !Y || !Z || !noise_var || !qU_mean || !qU_cov_W || !qU_cov_diag || !lengthscale || !variance || !logL)
+        MXF_FAIL(h, -2, "mxf_svgp_logpdf: null argument");
+    if (kind > MXF_K_MATERN52) MXF_FAIL(h, -2, "mxf_svgp_logpdf: stationary kernels only");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MXF_F32)
+        return svgp_logpdf_typed<float>(h, kind, dtype, S, B, M, Q, P, (const float*)X, strideS_X, (const float*)Y, strideS_Y, (const float*)Z,
+                                        (const float*)noise_var, (const float*)qU_mean, (const float*)qU_cov_W, (const float*)qU_cov_diag,
+                                        (const float*)lengthscale, ard, (const float*)variance, jitter, scaling, gscale, (float*)logL, info,
+                                        want_grad, (float*)dX, (float*)dY, (float*)dZ, (float*)dnoise, (float*)dmu, (float*)dW, (float*)dSdiag,
+                                        (float*)dls, (float*)dvar, st);
+    if (dtype == MXF_F64)
+        return svgp_logpdf_typed<double>(h, kind, dtype, S, B, M, Q, P, (const double*)X, strideS_X, (const double*)Y, strideS_Y, (const double*)Z,
+                                         (const double*)noise_var, (const double*)qU_mean, (const double*)qU_cov_W, (const double*)qU_cov_diag,
+                                         (const double*)lengthscale, ard, (const double*)variance, jitter, scaling, gscale, (double*)logL, info,
+                                         want_grad, (double*)dX, (double*)dY, (double*)dZ, (double*)dnoise, (double*)dmu, (double*)dW,
+                                         (double*)dSdiag, (double*)dls, (double*)dvar, st);
+    MXF_FAIL(h, -2, "mxf_svgp_logpdf: bad dtype %d", dtype);
+}

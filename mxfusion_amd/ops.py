@@ -179,3 +179,50 @@ def normal_logpdf_(x, mean, var, scale, out_acc, dx_acc=None, dmean_acc=None, dv
 def adam_step_(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8, rescale_grad=1.0):
     _lib.call('mxf_adam_step', _h(w), _dt(w), w.numel(), _p(w), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
               float(epsilon), float(rescale_grad), int(t), _stream())
+
+
+def gp_logpdf(kind, X, Y, noise_var, lengthscale, variance, ard, jitter=0.0, want_grad=False):
+    """GPRegressionLogPdf.compute (gp_regression.py:42-76).  X (S|1,N,Q), Y (S|1,N,P) [minus mean], noise_var (S|1,1),
+    lengthscale (S|1,Q|1), variance (S|1,1).  Returns dict(logL (S,), L (S,N,N), LinvY (S,N,P), info, grads...)."""
+    X, Y, noise_var, lengthscale, variance = _c(X), _c(Y), _c(noise_var), _c(lengthscale), _c(variance)
+    S = num_samples(X, Y, noise_var, lengthscale, variance)
+    N, Q, P = X.shape[-2], X.shape[-1], Y.shape[-1]
+    dev, dt = X.device, X.dtype
+    out = {'logL': torch.empty(S, dtype=dt, device=dev), 'L': torch.empty((S, N, N), dtype=dt, device=dev),
+           'LinvY': torch.empty((S, N, P), dtype=dt, device=dev), 'info': torch.zeros(S, dtype=torch.int32, device=dev)}
+    g = {}
+    if want_grad:
+        g = {'dX': torch.empty((S, N, Q), dtype=dt, device=dev), 'dY': torch.empty((S, N, P), dtype=dt, device=dev),
+             'dnoise': torch.empty((S, 1), dtype=dt, device=dev),
+             'dls': torch.empty((S, lengthscale.shape[-1]), dtype=dt, device=dev), 'dvar': torch.empty((S, 1), dtype=dt, device=dev)}
+    _lib.call('mxf_gp_logpdf', _h(X), KIND[kind], _dt(X), S, N, Q, P, _p(X), _ss(X), _p(Y), _ss(Y), _p(noise_var), _ss(noise_var),
+              _p(lengthscale), int(bool(ard)), _ss(lengthscale), _p(variance), _ss(variance), float(jitter),
+              _p(out['logL']), _p(out['L']), _p(out['LinvY']), _p(out['info']), int(want_grad),
+              _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dnoise')), _p(g.get('dls')), _p(g.get('dvar')), _stream())
+    out.update(g)
+    return out
+
+
+def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance, ard, jitter=0.0,
+                scaling=1.0, gscale=1.0, want_grad=False):
+    """SVGPRegressionLogPdf.compute (svgp_regression.py:43-109), homoscedastic.  X (S|1,B,Q), Y (S|1,B,P) [minus mean],
+    Z (M,Q), noise_var (1,), qU_mean (M,P), qU_cov_W (M,M), qU_cov_diag (M,) [positive], lengthscale (Q|1,), variance (1,).
+    Returns dict(logL (S,), info, and -- if want_grad -- the gradients of gscale*sum_s logL[s])."""
+    X, Y, Z = _c(X), _c(Y), _c(Z)
+    noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance = [_c(t) for t in (noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance)]
+    S = num_samples(X, Y)
+    B, Q, P, M = X.shape[-2], X.shape[-1], Y.shape[-1], Z.shape[-2]
+    dev, dt = X.device, X.dtype
+    out = {'logL': torch.empty(S, dtype=dt, device=dev), 'info': torch.zeros(1, dtype=torch.int32, device=dev)}
+    g = {}
+    if want_grad:
+        E = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
+        g = {'dX': E(*X.shape), 'dY': E(*Y.shape), 'dZ': E(M, Q), 'dnoise': E(1), 'dmu': E(M, P), 'dW': E(M, M), 'dSdiag': E(M),
+             'dls': E(lengthscale.numel()), 'dvar': E(1)}
+    _lib.call('mxf_svgp_logpdf', _h(X), KIND[kind], _dt(X), S, B, M, Q, P, _p(X), _ss(X), _p(Y), _ss(Y), _p(Z), _p(noise_var),
+              _p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), _p(lengthscale), int(bool(ard)), _p(variance), float(jitter),
+              float(scaling), float(gscale), _p(out['logL']), _p(out['info']), int(want_grad),
+              _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dZ')), _p(g.get('dnoise')), _p(g.get('dmu')), _p(g.get('dW')),
+              _p(g.get('dSdiag')), _p(g.get('dls')), _p(g.get('dvar')), _stream())
+    out.update(g)
+    return out

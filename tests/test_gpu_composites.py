@@ -1,0 +1,115 @@
+"""GPU parity of the fused composites (C ABI) vs the CPU oracle: exact-GP log marginal and SVGP bound,
+values and reverse mode, on the golden fixtures (reference tests' inputs) and on larger seeded problems."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+KINDS = {'rbf': O.RBF, 'matern12': O.Matern12, 'matern32': O.Matern32, 'matern52': O.Matern52}
+
+
+def _dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+def _close(got, ref, rtol, name=''):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.allclose(got, ref, rtol=rtol, atol=rtol * scale), (name, np.abs(got - ref).max(), scale)
+
+
+def test_gp_logpdf_golden(golden_dir):
+    """KAT-GP: testing/modules/gpregression_test.py:40-48 inputs, value asserted by the reference vs GPy (:96)."""
+    from mxfusion_amd import ops
+    g = np.load(os.path.join(golden_dir, 'kat_gp.npz'))
+    r = ops.gp_logpdf('rbf', _dev(g['X'][None]), _dev(g['Y'][None]), _dev(g['noise'][None]), _dev(g['ls'][None]),
+                      _dev(g['var'][None]), True, want_grad=True)
+    _close(r['logL'], g['logL'], 1e-12, 'logL')
+    assert abs(float(r['logL'][0]) - (-18.814420362103)) < 1e-9
+    _close(r['L'][0], g['L'], 1e-11, 'L')
+    _close(r['LinvY'][0], g['LinvY'], 1e-11, 'LinvY')
+    for n, k in (('dX', 'd_X'), ('dY', 'd_Y'), ('dnoise', 'd_noise'), ('dls', 'd_ls'), ('dvar', 'd_var')):
+        _close(r[n][0].reshape(g[k].shape), g[k], 1e-9, n)
+
+
+@pytest.mark.parametrize('kind', ['rbf', 'matern52', 'matern32'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize('N,Q,P,S', [(200, 4, 2, 1), (700, 8, 1, 2)])
+def test_gp_logpdf_vs_oracle(kind, dtype, tol, N, Q, P, S):
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(N)
+    X = rng.uniform(-3, 3, (S, N, Q))
+    Y = rng.randn(1, N, P)
+    ls = rng.rand(1, Q) + 1.0
+    var = rng.rand(1, 1) + 0.5
+    noise = np.array([[0.3]])
+    k = KINDS[kind](Q, ARD=True)
+    leaves = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=X, Y=Y, ls=ls, var=var, noise=noise).items()}
+    logL = O.gp_log_pdf(k, leaves['X'], leaves['Y'], leaves['noise'], {k.name + '_lengthscale': leaves['ls'], k.name + '_variance': leaves['var']}, jitter=1e-6)
+    r = ops.gp_logpdf(kind, _dev(X, dtype), _dev(Y, dtype), _dev(noise, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')
+    for s in range(S):
+        grads = torch.autograd.grad(logL[s], [leaves[n] for n in ('X', 'Y', 'noise', 'ls', 'var')], retain_graph=True)
+        _close(r['dX'][s], grads[0][s], tol * 20, 'dX')
+        _close(r['dY'][s], grads[1][0], tol * 20, 'dY')
+        _close(r['dnoise'][s], grads[2][0], tol * 20, 'dnoise')
+        _close(r['dls'][s], grads[3][0], tol * 20, 'dls')
+        _close(r['dvar'][s], grads[4][0], tol * 20, 'dvar')
+
+
+def test_svgp_logpdf_golden(golden_dir):
+    """KAT-SVGP: testing/modules/svgpregression_test.py:41-56,68 inputs; reference asserts the value vs GPy (:115)."""
+    from mxfusion_amd import ops
+    g = np.load(os.path.join(golden_dir, 'kat_svgp.npz'))
+    a = [_dev(g[n]) for n in ('Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')]
+    r = ops.svgp_logpdf('rbf', _dev(g['X'][None]), _dev(g['Y'][None]), *a, True, jitter=1e-8)
+    assert abs(float(r['logL'][0]) - (-32.725635407458)) < 1e-8
+    _close(r['logL'], g['logL'], 1e-11, 'logL')
+    r = ops.svgp_logpdf('rbf', _dev(g['X'][None]), _dev(g['Y'][None]), *a, True, jitter=1e-8, scaling=3.5, want_grad=True)
+    _close(r['logL'], g['logL_scaled'], 1e-11, 'logL_scaled')
+    for n, k in (('dX', 'd_X'), ('dY', 'd_Y'), ('dZ', 'd_Z'), ('dnoise', 'd_noise'), ('dmu', 'd_qm'), ('dW', 'd_qW'),
+                 ('dSdiag', 'd_qd'), ('dls', 'd_ls'), ('dvar', 'd_var')):
+        _close(r[n].reshape(g[k].shape), g[k], 1e-8, n)
+
+
+@pytest.mark.parametrize('kind', ['rbf', 'matern52'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('B,M,Q,P,S', [(300, 20, 3, 1, 1), (1000, 130, 8, 2, 3)])
+def test_svgp_logpdf_vs_oracle(kind, dtype, tol, B, M, Q, P, S):
+    """sampled inputs X (S,B,Q) (the latent-input model of svgpregression_test.py:357-385), shared Y."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(B + M)
+    X = rng.uniform(-2, 2, (S, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm = rng.randn(M, P) * 0.3
+    qW = rng.randn(M, M) * 0.1
+    qd = rng.rand(M) + 0.5
+    # float32 streams Kuf through the explicit-inverse form, whose rounding error scales with cond(Kuu) * 6e-8
+    # (DESIGN.md "precision"): exercise it on a well-conditioned Kuu (short lengthscale); float64 on the hard one
+    ls = rng.rand(Q) * 0.5 + (1.0 if dtype == torch.float64 else 0.25)
+    var = np.array([1.3])
+    noise = np.array([0.05])
+    k = KINDS[kind](Q, ARD=True)
+    names = ('X', 'Y', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    vals = dict(X=X, Y=Y, Z=Z, noise=noise, qm=qm, qW=qW, qd=qd, ls=ls, var=var)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    logL = O.svgp_log_pdf(k, lv['X'], lv['Y'][None], lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-6, log_pdf_scaling=2.0)
+    obj = logL.mean()
+    grads = torch.autograd.grad(obj, [lv[n] for n in names])
+    r = ops.svgp_logpdf(kind, _dev(X, dtype), _dev(Y[None], dtype), _dev(Z, dtype), _dev(noise, dtype), _dev(qm, dtype), _dev(qW, dtype),
+                        _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=2.0, gscale=1.0 / S, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')          # north_star: 1e-5 relative on the ELBO
+    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
