@@ -109,6 +109,11 @@ int mxf_trtri(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t 
 int mxf_sumlogdiag(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t strideS_L,
                    void* out, void* stream);
 
+/* out[s][n] = sum_m A[s][m][n]*B[s][m][n] -- F.sum(A*B, axis=-2) of the predictive variances
+ * (gp_regression.py:181, svgp_regression.py:166-169, sparsegp_regression.py:153-155)                */
+int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, const void* A, int64_t lda, int64_t strideS_A,
+               const void* B, int64_t ldb, int64_t strideS_B, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Elementwise / reduction pieces of the MC-ELBO loop.                                             */
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     'mxf_trsm': [_i, _i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp],
     'mxf_trtri': [_i, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp],
     'mxf_sumlogdiag': [_i, _i, _i64, _vp, _i64, _i64, _vp, _vp],
+    'mxf_coldot': [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
     'mxf_softplus_fwd': [_i, _i64, _vp, _vp, _vp],
     'mxf_softplus_bwd': [_i, _i64, _vp, _vp, _vp, _vp],
     'mxf_normal_reparam': [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp],

@@ -302,7 +302,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     for (int i = 0; i < 9; ++i) acc(MM, 8);   // L, Linv, Ki, Su(Ls), Lsinv, Sui, KiSu, H0, tmp
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
-    acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB * P, sizeof(T));
+    acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T));
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
@@ -313,7 +313,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* Sui = cv.take<D>(MM); D* KiSu = cv.take<D>(MM); D* H0 = cv.take<D>(MM); D* tmp = cv.take<D>(MM);
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
-    T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB); T* E = cv.take<T>((size_t)SB * P);
+    T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB);
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
@@ -370,33 +370,35 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_gemm_internal(h, dtype, 0, 0, M + P, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);
     if (rc) return rc;
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
-    if (want_grad && dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
-    hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
-                       (const T*)wT, noise, a1, want_grad, want_grad ? E : (T*)nullptr, dY, dY_shared, scal);
+    if (S > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X (loop over samples on the host otherwise)");
     D* dnz = nullptr; D* dvdir = nullptr;
-    if (want_grad) { dnz = sc + 4; dvdir = sc + 5; }
-    // when X and Y are shared by all samples the S per-sample values are identical: replicate
-    if (SS == 1 && S > 1) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X");
+    T* Psi2 = nullptr; T* R = nullptr;
+    if (!want_grad) {
+        hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
+                           (const T*)wT, noise, a1, 0, (T*)nullptr, (T*)nullptr, 0, scal);
+    } else {
+        dnz = sc + 4; dvdir = sc + 5;
+        Psi2 = cv.take<T>(MM); R = cv.take<T>(MP);
+        if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
+        if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
+        if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
+        if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
+        if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
+        MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
+        // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
+        rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
+                                         dY, dY_shared, R, scal, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
                        (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
     MXF_LAUNCH_CHECK(h);
     if (!want_grad) return 0;
 
-    T* Psi2 = cv.take<T>(MM); T* R = cv.take<T>(MP);
     D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
     D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
-    // Kuf-side reverse mode: Text[0:M] now holds dJ/dKuf_all
-    T* dZs = dZ; T* dlss = dls; T* dvs = dvar;
-    if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
-    if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
-    if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
-    if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
-    rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, Text, SB, 0, dZs, dX, dlss, dvs, st);
-    if (rc) return rc;
-    // Psi2 = Kuf Kuf^T (split-K MFMA), R = Kuf E
+    // Psi2 = Kuf Kuf^T (split-K MFMA)
     rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Kuf, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
-    if (rc) return rc;
-    rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, SB, 1.0, Kuf, SB, 0, E, P, 0, 0.0, R, P, 0, 1, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);

@@ -98,6 +98,19 @@ __global__ void adam_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ 
     }
 }
 
+// out[s][n] = sum_m A[s][m][n] * B[s][m][n]   (F.sum(A*B, axis=-2): gp_regression.py:181, svgp_regression.py:166-169)
+template <typename T>
+__global__ void coldot_kernel(int64_t M, int64_t N, const T* __restrict__ A, int64_t lda, int64_t sA, const T* __restrict__ B, int64_t ldb,
+                              int64_t sB, T* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const T* a = A + (int64_t)blockIdx.y * sA;
+    const T* b = B + (int64_t)blockIdx.y * sB;
+    T acc = 0;
+    for (int64_t m = 0; m < M; ++m) acc = fma(a[m * lda + n], b[m * ldb + n], acc);
+    out[(int64_t)blockIdx.y * N + n] = acc;
+}
+
 inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -176,4 +189,15 @@ extern "C" int mxf_adam_step(mxf_handle h, int dtype, int64_t n, void* w, const 
     DISPATCH(h, dtype, "mxf_adam_step",
              hipLaunchKernelGGL((adam_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, n, (float*)w, (const float*)g, (float*)m, (float*)v, (float)lr_t, (float)beta1, (float)beta2, (float)epsilon, (float)rescale_grad),
              hipLaunchKernelGGL((adam_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)m, (double*)v, lr_t, beta1, beta2, epsilon, rescale_grad));
+}
+
+extern "C" int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, const void* A, int64_t lda, int64_t strideS_A,
+                          const void* B, int64_t ldb, int64_t strideS_B, void* out, void* stream) {
+    if (!h) return -1;
+    if (S <= 0 || N <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((unsigned)((N + 255) / 256), (unsigned)S);
+    DISPATCH(h, dtype, "mxf_coldot",
+             hipLaunchKernelGGL((coldot_kernel<float>), g, dim3(256), 0, st, M, N, (const float*)A, lda, strideS_A, (const float*)B, ldb, strideS_B, (float*)out),
+             hipLaunchKernelGGL((coldot_kernel<double>), g, dim3(256), 0, st, M, N, (const double*)A, lda, strideS_A, (const double*)B, ldb, strideS_B, (double*)out));
 }

@@ -18,3 +18,9 @@ int mxf_sumlogdiag_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void*
 int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int64_t N2, int Q, const void* X, int64_t sX,
                           const void* X2, int64_t sX2, const void* ls, int ard, int64_t sls, const void* var, int64_t svar,
                           const void* dK, int64_t lddk, int64_t sdK, void* dX, void* dX2, void* dls, void* dvar, hipStream_t st);
+
+// SVGP-fused reverse pass over Text = [H0; w^T] Kuf_all (never materialises dKuf); see gram_bwd.hip
+int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
+                                const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
+                                int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
+                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st);

@@ -1,0 +1,10 @@
+from .inference import Inference, TransferInference  # noqa: F401
+from .grad_based_inference import GradBasedInference  # noqa: F401
+from .inference_alg import InferenceAlgorithm, SamplingAlgorithm  # noqa: F401
+from .variational import VariationalInference, StochasticVariationalInference  # noqa: F401
+from .map import MAP  # noqa: F401
+from .meanfield import create_Gaussian_meanfield  # noqa: F401
+from .batch_loop import BatchInferenceLoop, DistributedBatchInferenceLoop  # noqa: F401
+from .minibatch_loop import MinibatchInferenceLoop  # noqa: F401
+from .prediction import ModulePredictionAlgorithm  # noqa: F401
+from .forward_sampling import ForwardSamplingAlgorithm  # noqa: F401

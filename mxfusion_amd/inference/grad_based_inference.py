@@ -1,0 +1,35 @@
+"""GradBasedInference (mxfusion/inference/grad_based_inference.py:22-140)."""
+import torch
+
+from ..common import config
+from .batch_loop import BatchInferenceLoop
+from .inference import Inference, discover_shape_constants
+from .minibatch_loop import MinibatchInferenceLoop
+
+
+class GradBasedInference(Inference):
+    def __init__(self, inference_algorithm, grad_loop=None, constants=None, hybridize=False, dtype=None, context=None):
+        if grad_loop is None:
+            grad_loop = BatchInferenceLoop()
+        super(GradBasedInference, self).__init__(inference_algorithm=inference_algorithm, constants=constants, hybridize=hybridize,
+                                                 dtype=dtype, context=context)
+        self._grad_loop = grad_loop
+
+    def create_executor(self):
+        rv_scaling = self._grad_loop.rv_scaling if isinstance(self._grad_loop, MinibatchInferenceLoop) else None
+        return self._inference_algorithm.create_executor(data_def=self.observed_variable_UUIDs, params=self.params,
+                                                         var_ties=self.params.var_ties, rv_scaling=rv_scaling)
+
+    def run(self, optimizer='adam', learning_rate=1e-3, max_iter=2000, verbose=False, **kwargs):
+        data = [self._to_device(kwargs[v]) for v in self.observed_variable_names]
+        self.initialize(**kwargs)
+        infr = self.create_executor()
+        if isinstance(self._grad_loop, MinibatchInferenceLoop):
+            def update_shape_constants(data_batch):
+                shapes = {i: tuple(d.shape) for i, d in zip(self.observed_variable_UUIDs, data_batch)}
+                self.params.update_constants(discover_shape_constants(shapes, self._graphs))
+            return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
+                                       optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
+                                       update_shape_constants=update_shape_constants)
+        return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
+                                   optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)

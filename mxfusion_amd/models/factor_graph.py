@@ -1,0 +1,169 @@
+"""FactorGraph runtime (mxfusion/models/factor_graph.py:28-297): registration of named variables and the
+topological walks log_pdf (:192-238) / draw_samples (:240-297).  Graph cloning / reconciliation / JSON
+(:325-643) is bookkeeping outside the hot path and is not re-created."""
+from ..common.exceptions import ModelSpecificationError
+from ..components.factor import Factor
+from ..components.variables.variable import Variable, VariableType
+from ..components.variables.runtime_variable import expectation
+
+
+class FactorGraph(object):
+    def __init__(self, name='graph', verbose=False):
+        object.__setattr__(self, '_names', {})        # attribute name -> component
+        object.__setattr__(self, '_variables', {})    # uuid -> Variable
+        object.__setattr__(self, '_factors', [])      # registration order
+        object.__setattr__(self, 'name', name)
+        object.__setattr__(self, '_verbose', verbose)
+
+    # ---- registration -------------------------------------------------------------------------
+    def __setattr__(self, name, value):
+        if isinstance(value, Variable):
+            value.name = name if value.name is None else value.name
+            self._names[name] = value
+            self._register_variable(value)
+            if self._verbose:
+                print('Variable %s (%s) registered' % (name, value.uuid))
+        elif isinstance(value, Factor):
+            self._names[name] = value
+            self._register_factor(value)
+        object.__setattr__(self, name, value)
+
+    def _register_variable(self, v):
+        if v.uuid in self._variables and self._variables[v.uuid] is v:
+            return
+        self._variables[v.uuid] = v
+        if v.graph is None:
+            v.graph = self
+        for s in (v.shape or ()):
+            if isinstance(s, Variable):
+                self._register_variable(s)
+        if v.factor is not None:
+            self._register_factor(v.factor)
+
+    def _register_factor(self, f):
+        if any(f is g for g in self._factors):
+            return
+        self._factors.append(f)
+        f.graph = self if f.graph is None else f.graph
+        for _, v in f.inputs:
+            self._register_variable(v)
+        for _, v in f.outputs:
+            self._register_variable(v)
+        for v in getattr(f, 'extra_parameters', lambda: [])():
+            self._register_variable(v)
+
+    def __getitem__(self, key):
+        uuid = key.uuid if isinstance(key, Variable) else key
+        return self._variables[uuid]
+
+    def __contains__(self, key):
+        uuid = key.uuid if isinstance(key, Variable) else key
+        return uuid in self._variables
+
+    @property
+    def variables(self):
+        return self._variables
+
+    @property
+    def components(self):
+        return dict(self._names)
+
+    # ---- structure ------------------------------------------------------------------------------
+    @property
+    def ordered_factors(self):
+        """Topological order: a factor comes after the factors producing its inputs."""
+        order, done = [], set()
+
+        def visit(f):
+            if id(f) in done:
+                return
+            done.add(id(f))
+            for _, v in f.inputs:
+                g = self._variables.get(v.uuid, v).factor
+                if g is not None and any(g is h for h in self._factors):
+                    visit(g)
+            order.append(f)
+        for f in self._factors:
+            visit(f)
+        return order
+
+    def get_latent_variables(self, observed):
+        obs = {(o.uuid if isinstance(o, Variable) else o) for o in observed}
+        return [v for v in self._variables.values() if v.type == VariableType.RANDVAR and v.uuid not in obs]
+
+    def get_parameters(self, excluded=None, include_inherited=True):
+        excluded = excluded or set()
+        out = []
+        for v in self._variables.values():
+            if v.type == VariableType.PARAMETER and v.uuid not in excluded and (include_inherited or not v.isInherited):
+                out.append(v)
+        return out
+
+    def get_constants(self):
+        return [v for v in self._variables.values() if v.type == VariableType.CONSTANT]
+
+    # ---- runtime ---------------------------------------------------------------------------------
+    def log_pdf(self, F, variables, targets=None):
+        """factor_graph.py:192-238: logL = sum over factors of sum(mean_S(log_pdf))."""
+        from ..components.distributions.distribution import Distribution
+        from ..components.functions.function_evaluation import FunctionEvaluation
+        from ..modules.module import Module
+        if targets is not None:
+            targets = {t.uuid if isinstance(t, Variable) else t for t in targets}
+        logL = 0.
+        for f in self.ordered_factors:
+            if isinstance(f, FunctionEvaluation):
+                outcome = f.eval(F=F, variables=variables, always_return_tuple=True)
+                for v, (_, ov) in zip(outcome, f.outputs):
+                    variables[ov.uuid] = v
+            elif isinstance(f, Distribution):
+                if targets is None or f.random_variable.uuid in targets:
+                    if hasattr(f, 'log_pdf_sum'):
+                        logL = logL + f.log_pdf_sum(F, variables)          # fused sum(mean_S(.)) kernel
+                    else:
+                        logL = logL + expectation(F, f.log_pdf(F=F, variables=variables)).sum()
+            elif isinstance(f, Module):
+                if targets is None:
+                    module_targets = [v.uuid for _, v in f.outputs if v.uuid in variables]
+                else:
+                    module_targets = [v.uuid for _, v in f.outputs if v.uuid in targets]
+                if len(module_targets) > 0:
+                    logL = logL + expectation(F, f.log_pdf(F=F, variables=variables, targets=module_targets)).sum()
+            else:
+                raise ModelSpecificationError("There is an object in the factor graph that isn't a factor.")
+        return logL
+
+    def draw_samples(self, F, variables, num_samples=1, targets=None):
+        """factor_graph.py:240-297."""
+        from ..components.distributions.distribution import Distribution
+        from ..components.functions.function_evaluation import FunctionEvaluation
+        from ..modules.module import Module
+        samples = {}
+        for f in self.ordered_factors:
+            if isinstance(f, FunctionEvaluation):
+                outcome = f.eval(F=F, variables=variables, always_return_tuple=True)
+                for v, (_, ov) in zip(outcome, f.outputs):
+                    variables[ov.uuid] = v
+                    samples[ov.uuid] = v
+            elif isinstance(f, Distribution):
+                known = [v.uuid in variables for _, v in f.outputs]
+                if all(known):
+                    continue
+                outcome = f.draw_samples(F=F, variables=variables, num_samples=num_samples, always_return_tuple=True)
+                for v, (_, ov) in zip(outcome, f.outputs):
+                    variables[ov.uuid] = v
+                    samples[ov.uuid] = v
+            elif isinstance(f, Module):
+                outcome_uuid = [v.uuid for _, v in f.outputs]
+                if all(u in variables for u in outcome_uuid):
+                    continue
+                outcome = f.draw_samples(F=F, variables=variables, num_samples=num_samples, targets=outcome_uuid)
+                for v, u in zip(outcome, outcome_uuid):
+                    variables[u] = v
+                    samples[u] = v
+            else:
+                raise ModelSpecificationError("There is an object in the factor graph that isn't a factor.")
+        if targets:
+            targets = [t.uuid if isinstance(t, Variable) else t for t in targets]
+            return {u: samples[u] for u in targets if u in samples}
+        return samples

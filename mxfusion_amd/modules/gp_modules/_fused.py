@@ -1,0 +1,57 @@
+"""autograd bridges to the fused C-ABI composites (value + reverse mode in one call)."""
+import torch
+
+from ... import ops
+
+
+class GPLogPdfFn(torch.autograd.Function):
+    """mxf_gp_logpdf: logL (S,), and the posterior side products L, LinvY (gp_regression.py:72-75)."""
+
+    @staticmethod
+    def forward(ctx, kind, ard, jitter, X, Y, noise, ls, var):
+        want = any(ctx.needs_input_grad[3:])
+        r = ops.gp_logpdf(kind, X, Y, noise, ls, var, ard, jitter=jitter, want_grad=want)
+        ctx.want = want
+        if want:
+            ctx.grads = (r['dX'], r['dY'], r['dnoise'], r['dls'], r['dvar'])
+            ctx.shapes = tuple(t.shape for t in (X, Y, noise, ls, var))
+        ctx.mark_non_differentiable(r['L'], r['LinvY'], r['info'])
+        return r['logL'], r['L'], r['LinvY'], r['info']
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        out = []
+        for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[3:]):
+            if not need:
+                out.append(None)
+                continue
+            gg = grad.reshape((grad.shape[0],) + tuple(shp[1:])) * g.reshape((-1,) + (1,) * (len(shp) - 1))
+            if shp[0] == 1 and gg.shape[0] > 1:      # primal broadcast over S: its gradient sums over samples
+                gg = gg.sum(0, keepdim=True)
+            out.append(gg)
+        return (None, None, None) + tuple(out)
+
+
+class SVGPLogPdfFn(torch.autograd.Function):
+    """mxf_svgp_logpdf.  Gradients are produced for mean_S(logL) (the only reduction the reference applies to a
+    module's log-pdf, factor_graph.py:233) and scaled by sum(grad_output) in backward."""
+
+    @staticmethod
+    def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
+        want = any(ctx.needs_input_grad[4:])
+        S = max(X.shape[0], Y.shape[0])
+        r = ops.svgp_logpdf(kind, X, Y, Z[0], noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1), ard,
+                            jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+        if want:
+            ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'], r['dls'], r['dvar'])
+            ctx.shapes = tuple(t.shape for t in (X, Y, Z, noise, mu, W, sdiag, ls, var))
+        ctx.mark_non_differentiable(r['info'])
+        return r['logL'], r['info']
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        c = g.sum()
+        out = []
+        for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:]):
+            out.append((grad.reshape(shp) * c) if need else None)
+        return (None, None, None, None) + tuple(out)

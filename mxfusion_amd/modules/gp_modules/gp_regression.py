@@ -1,0 +1,268 @@
+"""GPRegression module and its algorithms (mxfusion/modules/gp_modules/gp_regression.py:31-428).
+
+Same classes, constructor signatures, attributes (`jitter`, `noise_free`, `diagonal_variance`) and
+`compute(F, variables)` contract as the reference; the bodies call the MI355X kernels through the C ABI:
+  GPRegressionLogPdf.compute                 -> mxf_gp_logpdf (fused Gram + potrf + trsm + log-det + reverse mode)
+  GPRegressionMeanVariancePrediction.compute -> mxf_gram + mxf_trsm + mxf_gemm
+  GPRegressionSampling / SamplingPrediction  -> mxf_gram + mxf_potrf + mxf_gemm (trmm)
+"""
+from types import SimpleNamespace
+
+import torch
+
+from ... import ops
+from ...common import config
+from ...components.variables.variable import Variable
+from ...components.variables.runtime_variable import arrays_as_samples
+from ...inference.inference_alg import SamplingAlgorithm
+from ...inference.variational import VariationalInference
+from ..module import Module, ModuleGraph
+from ._fused import GPLogPdfFn
+
+
+def _chol_logpdf_generic(F, K, Y):
+    """log N(Y | 0, K) per sample from an explicit K (any kernel with an autograd-capable K()): value via
+    mxf_potrf / mxf_trsm, reverse mode via dK = 1/2 (alpha alpha^T - P K^-1)."""
+    return _CholLogPdfFn.apply(K, Y)
+
+
+class _CholLogPdfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, K, Y):
+        import math
+        S, N, P = K.shape[0], K.shape[-1], Y.shape[-1]
+        L, info = ops.potrf_(K.clone())
+        LinvY = ops.trsm_(L, Y.expand(S, N, P).clone())
+        logL = -P * ops.sumlogdiag(L) - 0.5 * ((LinvY ** 2).reshape(S, -1).sum(-1) + N * P * math.log(2 * math.pi))
+        if any(ctx.needs_input_grad):
+            Linv = ops.trtri(L)
+            alpha = ops.gemm(Linv, LinvY, transA=True)
+            dK = ops.gemm(alpha, alpha, transB=True, alpha=0.5)
+            ops.gemm(Linv, Linv, transA=True, alpha=-0.5 * P, beta=1.0, out=dK)
+            ctx.save_for_backward(dK, alpha)
+            ctx.yshape = Y.shape
+        ctx.mark_non_differentiable(L, LinvY, info)
+        return logL, L, LinvY, info
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        dK, alpha = ctx.saved_tensors
+        gK = dK * g.reshape(-1, 1, 1)
+        gY = -alpha * g.reshape(-1, 1, 1)
+        if ctx.yshape[0] == 1 and gY.shape[0] > 1:
+            gY = gY.sum(0, keepdim=True)
+        return gK, gY
+
+
+class GPRegressionLogPdf(VariationalInference):
+    """gp_regression.py:31-76."""
+
+    def __init__(self, model, posterior, observed, jitter=0.):
+        super(GPRegressionLogPdf, self).__init__(model=model, posterior=posterior, observed=observed)
+        self.log_pdf_scaling = 1     # set but unused by the reference as well
+        self.jitter = jitter
+
+    def compute(self, F, variables):
+        has_mean = self.model.F.factor.has_mean
+        X = variables[self.model.X]
+        Y = variables[self.model.Y]
+        noise_var = variables[self.model.noise_var]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        if has_mean:
+            Y = Y - variables[self.model.mean]
+        spec = kern.fused_spec()
+        if spec is not None:
+            kind, ard = spec
+            ls = kern_params[kern.name + '_lengthscale']
+            var = kern_params[kern.name + '_variance']
+            logL, L, LinvY, info = GPLogPdfFn.apply(kind, ard, float(self.jitter), X, Y, noise_var, ls, var)
+            Xs = X
+        else:   # combination kernels: K through the kernel's own (HIP, autograd-capable) K(), then Cholesky
+            X, Y, noise_var, kern_params = arrays_as_samples(F, [X, Y, noise_var, kern_params])
+            N = X.shape[-2]
+            eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)
+            K = kern.K(F, X, **kern_params) + eye * (noise_var.unsqueeze(-2) + self.jitter)
+            logL, L, LinvY, info = _chol_logpdf_generic(F, K, Y)
+            Xs = X
+        self._last_info = info
+        with torch.no_grad():      # gp_regression.py:72-75: only sample 0 is persisted
+            self.set_parameter(variables, self.posterior.X, Xs[0].detach())
+            self.set_parameter(variables, self.posterior.L, L[0])
+            self.set_parameter(variables, self.posterior.LinvY, LinvY[0])
+        return logL
+
+
+class GPRegressionSampling(SamplingAlgorithm):
+    """gp_regression.py:79-135: prior draws Y = L eps (+ mean)."""
+
+    def __init__(self, model, observed, num_samples=1, target_variables=None, rand_gen=None):
+        super(GPRegressionSampling, self).__init__(model=model, observed=observed, num_samples=num_samples, target_variables=target_variables)
+        from ...components.distributions.random_gen import TorchRandomGenerator
+        self._rand_gen = TorchRandomGenerator if rand_gen is None else rand_gen
+
+    def compute(self, F, variables):
+        has_mean = self.model.F.factor.has_mean
+        X = variables[self.model.X]
+        noise_var = variables[self.model.noise_var]
+        N = X.shape[-2]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        X, noise_var, kern_params = arrays_as_samples(F, [X, noise_var, kern_params])
+        with torch.no_grad():
+            K = kern.K(F, X, **kern_params) + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+            L, _ = ops.potrf_(K.contiguous().clone())
+            Y_shape = (N, int(self.model.Y.shape[-1]))
+            out_shape = (self.num_samples,) + Y_shape
+            die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
+            y_samples = ops.gemm(L, die)          # trmm: L is lower with a clean upper triangle
+        if has_mean:
+            y_samples = y_samples + variables[self.model.mean]
+        samples = {self.model.Y.uuid: y_samples}
+        if self.target_variables:
+            return tuple(samples[v] for v in self.target_variables)
+        return samples
+
+
+class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
+    """gp_regression.py:138-196."""
+
+    def __init__(self, model, posterior, observed, noise_free=True, diagonal_variance=True):
+        super(GPRegressionMeanVariancePrediction, self).__init__(model=model, observed=observed, extra_graphs=[posterior])
+        self.noise_free = noise_free
+        self.diagonal_variance = diagonal_variance
+
+    def _mean_and_V(self, F, variables):
+        X = variables[self.model.X]
+        noise_var = variables[self.model.noise_var]
+        X_cond = variables[self.graphs[1].X]
+        L = variables[self.graphs[1].L]
+        LinvY = variables[self.graphs[1].LinvY]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        Kxt = kern.K(F, X_cond, X, **kern_params)                    # (S, N, Nt)
+        LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())             # V = L^-1 Kxt
+        S = LinvKxt.shape[0]
+        mu = ops.gemm(LinvKxt, LinvY, transA=True)                   # V^T LinvY (LinvY broadcast over S by stride 0)
+        if self.model.F.factor.has_mean:
+            mu = mu + variables[self.model.mean]
+        return X, noise_var, kern, kern_params, LinvKxt, mu
+
+    def compute(self, F, variables):
+        with torch.no_grad():
+            X, noise_var, kern, kern_params, LinvKxt, mu = self._mean_and_V(F, variables)
+            N = X.shape[-2]
+            if self.diagonal_variance:
+                Ktt = kern.Kdiag(F, X, **kern_params)
+                var = Ktt - ops.coldot(LinvKxt, LinvKxt)
+                if not self.noise_free:
+                    var = var + noise_var
+            else:
+                Ktt = kern.K(F, X, **kern_params)
+                var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt.contiguous().clone())
+                if not self.noise_free:
+                    var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+        outcomes = {self.model.Y.uuid: (mu, var)}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
+class GPRegressionSamplingPrediction(GPRegressionMeanVariancePrediction):
+    """gp_regression.py:199-275."""
+
+    def __init__(self, model, posterior, observed, rand_gen=None, noise_free=True, diagonal_variance=True, jitter=0.):
+        super(GPRegressionSamplingPrediction, self).__init__(model, posterior, observed, noise_free, diagonal_variance)
+        from ...components.distributions.random_gen import TorchRandomGenerator
+        self._rand_gen = TorchRandomGenerator if rand_gen is None else rand_gen
+        self.jitter = jitter
+
+    def compute(self, F, variables):
+        with torch.no_grad():
+            X, noise_var, kern, kern_params, LinvKxt, mu = self._mean_and_V(F, variables)
+            N = X.shape[-2]
+            out_shape = (self.num_samples,) + tuple(mu.shape[1:])
+            die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
+            if self.diagonal_variance:
+                var = kern.Kdiag(F, X, **kern_params) - ops.coldot(LinvKxt, LinvKxt)
+                if not self.noise_free:
+                    var = var + noise_var
+                samples = mu + die * torch.sqrt(var.unsqueeze(-1))
+            else:
+                cov = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=kern.K(F, X, **kern_params).contiguous().clone())
+                eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)
+                if not self.noise_free:
+                    cov = cov + eye * noise_var.unsqueeze(-2)
+                if self.jitter > 0.:
+                    cov = cov + eye * self.jitter
+                Lc, _ = ops.potrf_(cov.contiguous())
+                samples = mu + ops.gemm(Lc, die)
+        outcomes = {self.model.Y.uuid: samples}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
+class GPRegression(Module):
+    """gp_regression.py:278-428."""
+
+    def __init__(self, X, kernel, noise_var, mean=None, rand_gen=None, dtype=None, ctx=None):
+        if not isinstance(X, Variable):
+            X = Variable(value=X)
+        if not isinstance(noise_var, Variable):
+            noise_var = Variable(value=noise_var)
+        inputs = [('X', X), ('noise_var', noise_var)]
+        if mean is not None:
+            inputs.append(('mean', mean))
+        self._has_mean = mean is not None
+        object.__setattr__(self, 'kernel', kernel)
+        super(GPRegression, self).__init__(inputs=inputs, outputs=None, input_names=[k for k, _ in inputs],
+                                           output_names=['random_variable'], rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+
+    def _generate_outputs(self, output_shapes):
+        shape = output_shapes['random_variable']
+        Y_shape = tuple(self.X.shape[:-1]) + (1,) if shape is None else shape
+        self.set_outputs([Variable(shape=Y_shape)])
+
+    def _build_module_graphs(self):
+        Y = self.random_variable
+        graph = ModuleGraph(name='gp_regression')
+        graph.X = self.X
+        graph.noise_var = self.noise_var
+        if self._has_mean:
+            graph.mean = self.mean
+        graph.F = SimpleNamespace(factor=SimpleNamespace(has_mean=self._has_mean, dtype=self.dtype, kernel=self.kernel))
+        graph.Y = Y
+        graph.kernel = self.kernel
+        for n, v in self.kernel.parameters.items():
+            setattr(graph, n, v)
+        post = ModuleGraph(name='gp_regression_posterior')      # stores what prediction needs (:355-359)
+        post.L = Variable(shape=tuple(self.X.shape[:-1]) + tuple(self.X.shape[-2:-1]))
+        post.LinvY = Variable(shape=tuple(self.X.shape[:-1]) + tuple(Y.shape[-1:]))
+        post.X = Variable(shape=self.X.shape)
+        for v in (post.L, post.LinvY, post.X):
+            v.is_posterior_cache = True
+        return graph, [post]
+
+    def _attach_default_inference_algorithms(self):
+        observed = [v for _, v in self.inputs] + [v for _, v in self.outputs]
+        self.attach_log_pdf_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                       algorithm=GPRegressionLogPdf(self._module_graph, self._extra_graphs[0], observed),
+                                       alg_name='gp_log_pdf')
+        observed = [v for _, v in self.inputs]
+        self.attach_draw_samples_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                            algorithm=GPRegressionSampling(self._module_graph, observed, rand_gen=self._rand_gen),
+                                            alg_name='gp_sampling')
+        self.attach_prediction_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                          algorithm=GPRegressionMeanVariancePrediction(self._module_graph, self._extra_graphs[0], observed),
+                                          alg_name='gp_predict')
+
+    @staticmethod
+    def define_variable(X, kernel, noise_var, shape=None, mean=None, rand_gen=None, dtype=None, ctx=None):
+        gp = GPRegression(X=X, kernel=kernel, noise_var=noise_var, mean=mean, rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+        gp._generate_outputs({'random_variable': shape})
+        return gp.random_variable
+
+    @property
+    def random_variable(self):
+        return self._outputs[0][1]

@@ -1,0 +1,227 @@
+"""SVGPRegression module and its algorithms (mxfusion/modules/gp_modules/svgp_regression.py:32-457).
+
+  SVGPRegressionLogPdf.compute                 -> mxf_svgp_logpdf: streaming sufficient-statistics bound + reverse mode,
+                                                  (M x M) factorisations once in float64 (composite.hip)
+  SVGPRegressionMeanVariancePrediction.compute -> mxf_gram + mxf_potrf + mxf_trsm + mxf_gemm + mxf_coldot
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...components.variables.variable import Variable
+from ...components.variables.var_trans import PositiveTransformation
+from ...inference.inference_alg import SamplingAlgorithm
+from ...inference.variational import VariationalInference
+from ..module import Module, ModuleGraph
+from ._fused import SVGPLogPdfFn
+
+
+def _S(t):
+    return t.shape[0]
+
+
+class SVGPRegressionLogPdf(VariationalInference):
+    """svgp_regression.py:32-109."""
+
+    def __init__(self, model, posterior, observed, jitter=0.):
+        super(SVGPRegressionLogPdf, self).__init__(model=model, posterior=posterior, observed=observed)
+        self.log_pdf_scaling = 1
+        self.jitter = jitter
+
+    def compute(self, F, variables):
+        has_mean = self.model.F.factor.has_mean
+        X = variables[self.model.X]
+        Y = variables[self.model.Y]
+        Z = variables[self.model.inducing_inputs]
+        noise_var = variables[self.model.noise_var]
+        mu = variables[self.posterior.qU_mean]
+        S_W = variables[self.posterior.qU_cov_W]
+        S_diag = variables[self.posterior.qU_cov_diag]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        spec = kern.fused_spec()
+        if spec is None:
+            raise NotImplementedError('SVGPRegressionLogPdf on MI355X supports a single stationary kernel '
+                                      '(RBF / Matern12/32/52); combination kernels are a next-row item (SURVEY 8f)')
+        if noise_var.dim() > 2 and noise_var.shape[-2] > 1:
+            raise NotImplementedError('heteroscedastic noise (svgp_regression.py:61-67) is not implemented in the fused path')
+        kind, ard = spec
+        ls = kern_params[kern.name + '_lengthscale']
+        var = kern_params[kern.name + '_variance']
+        if has_mean:
+            Y = Y - variables[self.model.mean]
+        shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
+        scaling = float(self.log_pdf_scaling)
+        if all(_S(t) == 1 for t in shared) and not (_S(X) == 1 and _S(Y) > 1):
+            logL, info = SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
+        else:
+            # sampled hyper-parameters / inducing inputs (runtime_variable.py:102-118 broadcast semantics): one fused
+            # call per sample, each with its own parameter slice
+            S = max(_S(t) for t in (X, Y) + shared)
+            pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
+            outs = [SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, pick(X, s), pick(Y, s), *[pick(t, s) for t in shared])
+                    for s in range(S)]
+            logL = torch.cat([o[0] for o in outs])
+            info = torch.stack([o[1] for o in outs]).sum(0)
+        self._last_info = info
+        return logL
+
+
+class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
+    """svgp_regression.py:112-189 (note: no arrays_as_samples; var gets a trailing unit axis, :170)."""
+
+    def __init__(self, model, posterior, observed, noise_free=True, diagonal_variance=True, jitter=0.):
+        super(SVGPRegressionMeanVariancePrediction, self).__init__(model=model, observed=observed, extra_graphs=[posterior])
+        self.jitter = jitter
+        self.noise_free = noise_free
+        self.diagonal_variance = diagonal_variance
+
+    def _moments(self, F, variables):
+        X = variables[self.model.X]
+        N = X.shape[-2]
+        Z = variables[self.model.inducing_inputs]
+        noise_var = variables[self.model.noise_var]
+        mu = variables[self.graphs[1].qU_mean]
+        S_W = variables[self.graphs[1].qU_cov_W]
+        S_diag = variables[self.graphs[1].qU_cov_diag]
+        M = Z.shape[-2]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        S = ops.gemm(S_W, S_W, transB=True) + torch.diag_embed(S_diag)                  # :145
+        Kuu = kern.K(F, Z, **kern_params).contiguous().clone()
+        if self.jitter > 0.:
+            Kuu = Kuu + torch.eye(M, dtype=Z.dtype, device=Z.device) * self.jitter
+        L, _ = ops.potrf_(Kuu)
+        Ls, _ = ops.potrf_(S)
+        LinvLs = ops.trsm_(L, Ls.clone())
+        Linvmu = ops.trsm_(L, mu.contiguous().clone())
+        LinvSLinvT = ops.gemm(LinvLs, LinvLs, transB=True)
+        wv = ops.trsm_(L, Linvmu.clone(), transpose=True)
+        Kxt = kern.K(F, Z, X, **kern_params)
+        mu_t = ops.gemm(Kxt, wv, transA=True)
+        if self.model.F.factor.has_mean:
+            mu_t = mu_t + variables[self.model.mean]
+        LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())
+        tmp = ops.gemm(LinvSLinvT, LinvKxt)
+        if self.diagonal_variance:
+            Ktt = kern.Kdiag(F, X, **kern_params)
+            var = Ktt - ops.coldot(LinvKxt, LinvKxt) + ops.coldot(tmp, LinvKxt)
+            var = var.unsqueeze(-1)
+            if not self.noise_free:
+                var = var + noise_var
+        else:
+            Ktt = kern.K(F, X, **kern_params).contiguous().clone()
+            var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt)
+            var = ops.gemm(LinvKxt, tmp, transA=True, alpha=1.0, beta=1.0, out=var)
+            var = var.unsqueeze(-1)
+            if not self.noise_free:
+                var = var + torch.eye(N, dtype=X.dtype, device=X.device).reshape(1, N, N, 1) * noise_var.unsqueeze(-2)
+        return mu_t, var
+
+    def compute(self, F, variables):
+        with torch.no_grad():
+            mu, var = self._moments(F, variables)
+        outcomes = {self.model.Y.uuid: (mu, var)}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
+class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
+    """svgp_regression.py:192-280."""
+
+    def __init__(self, model, posterior, observed, rand_gen=None, noise_free=True, diagonal_variance=True, jitter=0.):
+        super(SVGPRegressionSamplingPrediction, self).__init__(model, posterior, observed, noise_free, diagonal_variance, jitter)
+        from ...components.distributions.random_gen import TorchRandomGenerator
+        self._rand_gen = TorchRandomGenerator if rand_gen is None else rand_gen
+
+    def compute(self, F, variables):
+        with torch.no_grad():
+            jit, self.jitter = self.jitter, 0.      # the reference adds `jitter` to the predictive covariance here (:268-270)
+            try:
+                mu, var = self._moments(F, variables)
+            finally:
+                self.jitter = jit
+            out_shape = (self.num_samples,) + tuple(mu.shape[1:])
+            die = self._rand_gen.sample_normal(shape=out_shape, dtype=mu.dtype, ctx=mu.device)
+            if self.diagonal_variance:
+                samples = mu + die * torch.sqrt(var)
+            else:
+                cov = var[..., 0]
+                N = cov.shape[-1]
+                if self.jitter > 0.:
+                    cov = cov + torch.eye(N, dtype=cov.dtype, device=cov.device).unsqueeze(0) * self.jitter
+                Lc, _ = ops.potrf_(cov.contiguous().clone())
+                samples = mu + ops.gemm(Lc, die)
+        outcomes = {self.model.Y.uuid: samples}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
+class SVGPRegression(Module):
+    """svgp_regression.py:283-457."""
+
+    def __init__(self, X, kernel, noise_var, inducing_inputs=None, num_inducing=10, mean=None, rand_gen=None, dtype=None, ctx=None):
+        if not isinstance(X, Variable):
+            X = Variable(value=X)
+        if not isinstance(noise_var, Variable):
+            noise_var = Variable(value=noise_var)
+        if inducing_inputs is None:   # :317-320: global NumPy RNG at model-definition time
+            inducing_inputs = Variable(shape=(num_inducing, kernel.input_dim), initial_value=np.random.randn(num_inducing, kernel.input_dim))
+        inputs = [('X', X), ('inducing_inputs', inducing_inputs), ('noise_var', noise_var)]
+        if mean is not None:
+            inputs.append(('mean', mean))
+        self._has_mean = mean is not None
+        object.__setattr__(self, 'kernel', kernel)
+        super(SVGPRegression, self).__init__(inputs=inputs, outputs=None, input_names=[k for k, _ in inputs],
+                                             output_names=['random_variable'], rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+
+    def _generate_outputs(self, output_shapes=None):
+        shape = output_shapes['random_variable']
+        Y_shape = tuple(self.X.shape[:-1]) + (1,) if shape is None else shape
+        self.set_outputs([Variable(shape=Y_shape)])
+
+    def _build_module_graphs(self):
+        Y = self.random_variable
+        graph = ModuleGraph(name='sparsegp_regression')
+        graph.X = self.X
+        graph.inducing_inputs = self.inducing_inputs
+        M = self.inducing_inputs.shape[0]
+        graph.noise_var = self.noise_var
+        if self._has_mean:
+            graph.mean = self.mean
+        graph.F = SimpleNamespace(factor=SimpleNamespace(has_mean=self._has_mean, dtype=self.dtype, kernel=self.kernel))
+        graph.Y = Y
+        graph.kernel = self.kernel
+        for n, v in self.kernel.parameters.items():
+            setattr(graph, n, v)
+        post = ModuleGraph(name='svgp_posterior')      # :377-380
+        post.qU_cov_diag = Variable(shape=(M,), transformation=PositiveTransformation())
+        post.qU_cov_W = Variable(shape=(M, M))
+        post.qU_mean = Variable(shape=(M, Y.shape[-1]))
+        return graph, [post]
+
+    def _attach_default_inference_algorithms(self):
+        observed = [v for _, v in self.inputs] + [v for _, v in self.outputs]
+        self.attach_log_pdf_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                       algorithm=SVGPRegressionLogPdf(self._module_graph, self._extra_graphs[0], observed),
+                                       alg_name='svgp_log_pdf')
+        observed = [v for _, v in self.inputs]
+        self.attach_prediction_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                          algorithm=SVGPRegressionMeanVariancePrediction(self._module_graph, self._extra_graphs[0], observed),
+                                          alg_name='svgp_predict')
+
+    @staticmethod
+    def define_variable(X, kernel, noise_var, shape=None, inducing_inputs=None, num_inducing=10, mean=None, rand_gen=None,
+                        dtype=None, ctx=None):
+        gp = SVGPRegression(X=X, kernel=kernel, noise_var=noise_var, inducing_inputs=inducing_inputs, num_inducing=num_inducing,
+                            mean=mean, rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+        gp._generate_outputs({'random_variable': shape})
+        return gp.random_variable
+
+    @property
+    def random_variable(self):
+        return self._outputs[0][1]

@@ -226,3 +226,12 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
               _p(g.get('dSdiag')), _p(g.get('dls')), _p(g.get('dvar')), _stream())
     out.update(g)
     return out
+
+
+def coldot(A, B):
+    """out[s, n] = sum_m A[s, m, n] * B[s, m, n]  (F.sum(A*B, axis=-2))."""
+    A, B = _c(A), _c(B)
+    S, M, N = max(A.shape[0], B.shape[0]), A.shape[-2], A.shape[-1]
+    out = torch.empty((S, N), dtype=A.dtype, device=A.device)
+    _lib.call('mxf_coldot', _h(A), _dt(A), S, M, N, _p(A), A.stride(-2), _ss(A), _p(B), B.stride(-2), _ss(B), _p(out), _stream())
+    return out
