@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the GP + SVI hot path on MI355X.
+
+A "step" = one full SVI step (reparameterised draw of S latent-input samples, Monte-Carlo SVGP ELBO, its
+reverse mode, the data-parallel gradient exchange, one Adam update) of BASELINE.json configs[2]:
+    SVGPRegression, RBF(ARD), N=65536, Q=8, M=1024 inducing points, S=32 MC samples,
+    StochasticVariationalInference, latent-input model of testing/modules/svgpregression_test.py:357-385,
+run through the mxfusion_amd API (Model / SVGPRegression / GradBasedInference) -> C ABI -> HIP kernels.
+At --gpus N>1 (one process per GPU, torch.distributed 'nccl' == RCCL) the S samples are sharded S/N per rank and
+the flat gradient is summed with ONE all-reduce per step (strong scaling: the total work is fixed).
+
+Prints ONE JSON line (rank 0).  `roofline` is the RBF Gram build at N=65536, Q=8 (HBM-write bound, the kernel
+BASELINE.json's target names); `roofline_mfma` is the dominant MFMA kernel of the step; `cpu_baseline` is the oracle
+(CPU restatement of the reference's op sequence, fwd+bwd+Adam) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synth(N, Q, M, seed=0):
+    """SURVEY 8(d) synthetic inputs."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-3., 3., (N, Q))
+    w = rng.standard_normal(Q)
+    Y = np.sin(X @ w)[:, None] + 0.05 * rng.standard_normal((N, 1))
+    Z = X[rng.permutation(N)[:M]].copy()
+    return X, Y, Z
+
+
+def build(N, Q, M, S_local, dtype, X, Y, Z, distributed):
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, create_Gaussian_meanfield, \
+        BatchInferenceLoop, DistributedBatchInferenceLoop
+    m = Model()
+    m.N = Variable()
+    m.X = Normal.define_variable(mean=0, variance=1, shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=Z)
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    kernel = RBF(input_dim=Q, ARD=True, variance=1., lengthscale=np.ones(Q), dtype=dtype)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=dtype)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    q = create_Gaussian_meanfield(model=m, observed=[m.Y], dtype=dtype)
+    loop = DistributedBatchInferenceLoop() if distributed else BatchInferenceLoop()
+    infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S_local, observed=[m.Y]),
+                              grad_loop=loop, dtype=dtype)
+    infr.initialize(Y=(N, 1))
+    post = gp._extra_graphs[0]
+    dev = infr.mxnet_context
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    infr.params[post.qU_mean] = torch.zeros(M, 1, dtype=td, device=dev)
+    infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td, device=dev)
+    infr.params[post.qU_cov_diag] = torch.ones(M, dtype=td, device=dev)
+    qX = q[m.X].factor
+    infr.params[qX.mean] = torch.as_tensor(X, dtype=td).to(dev)
+    infr.params[qX.variance] = torch.full((N, Q), 1e-2, dtype=td, device=dev)
+    return m, q, infr, loop, qX
+
+
+def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
+    from mxfusion_amd.inference.batch_loop import _Adam
+    import torch.distributed as dist
+    executor = infr.create_executor()
+    trainer = _Adam(infr.params, lr)
+    loss = None
+    for _ in range(warmup):
+        loss = loop.step(executor, [Yd], infr.params)
+        trainer.step(batch_size=1)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = loop.step(executor, [Yd], infr.params)
+        trainer.step(batch_size=1)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(loss.detach())
+
+
+def gram_roofline(N, Q, dtype, reps=10):
+    """RBF Gram at N x N, Q: algorithmic bytes = N*N*sizeof written + 2*N*Q*sizeof read, timed with HIP
+    events on the stream the kernel is launched on (torch's current stream)."""
+    from mxfusion_amd import ops
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    X = torch.rand(1, N, Q, device='cuda', dtype=td) * 6 - 3
+    ls = torch.ones(1, Q, device='cuda', dtype=td)
+    var = torch.ones(1, 1, device='cuda', dtype=td)
+    out = torch.empty(1, N, N, device='cuda', dtype=td)
+    for _ in range(2):
+        ops.gram('rbf', X, None, ls, var, True, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gram('rbf', X, None, ls, var, True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = (N * N + 2 * N * Q) * out.element_size()
+    del out
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "gram_kernel<%s,8,RBF> N=%d Q=%d" % (dtype, N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": nbytes}
+
+
+def mfma_roofline(M, SB, dtype, reps=3):
+    """The dominant MFMA kernel of the step: T = [H0; w^T] Kuf_all  ((M+1) x M x SB GEMM)."""
+    from mxfusion_amd import ops
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    A = torch.randn(1, M + 1, M, device='cuda', dtype=td)
+    B = torch.randn(1, M, SB, device='cuda', dtype=td)
+    out = torch.empty(1, M + 1, SB, device='cuda', dtype=td)
+    ops.gemm(A, B, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm(A, B, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * (M + 1) * M * SB
+    peak = 157.3 if dtype == 'float32' else 78.6
+    del A, B, out
+    torch.cuda.empty_cache()
+    return {"bound": "mfma", "kernel": "gemm_kernel<%s,NN> %dx%dx%d" % (dtype, M + 1, SB, M), "achieved": fl / ms / 1e9, "peak": peak,
+            "unit": "TFLOP/s", "frac": fl / ms / 1e9 / peak, "traffic": None, "ms_per_launch": ms, "algorithmic_flops": fl}
+
+
+def cpu_baseline(N, Q, M, S, X, Y, Z):
+    """The oracle (float64 CPU restatement of the reference op sequence incl. autograd backward + MXNet-Adam) on this
+    box's host cores, on a bounded sample: one SVI step at S=1, B=8192 rows; the full step is S * N/B such sub-steps
+    (linear in S and B: BASELINE.md 3), so steps/s = 1 / (t_sub * S * N/B).  The BLAS thread count is calibrated on a
+    small problem first (all 256 hardware threads is far from the fastest setting) and reported as `cores`."""
+    from oracle import gp_oracle as O
+    T = O.T
+    kern = O.RBF(Q, ARD=True)
+    rng = np.random.default_rng(1)
+
+    def substep(Bs, reps):
+        raw = {'qX_mean': T(X[:Bs]), 'qX_var': O.inv_softplus(T(np.full((Bs, Q), 1e-2))), 'noise_var': O.inv_softplus(T([0.01])),
+               'lengthscale': O.inv_softplus(T(np.ones(Q))), 'variance': O.inv_softplus(T([1.0])), 'qU_mean': T(np.zeros((M, 1))),
+               'qU_cov_W': T(np.zeros((M, M))), 'qU_cov_diag': O.inv_softplus(T(np.ones(M))), 'Z': T(Z)}
+        opt = O.MXNetAdam(1e-3)
+        times = []
+        for it in range(reps):
+            eps = T(rng.standard_normal((1, Bs, Q)))
+            t0 = time.perf_counter()
+            lv = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+            loss = O.svi_latent_svgp_loss(kern, T(Y[:Bs]), lv['Z'], lv, eps, jitter=1e-6, log_pdf_scaling=N / Bs)
+            loss.backward()
+            raw = opt.step({k: v.detach() for k, v in lv.items()}, {k: v.grad for k, v in lv.items()})
+            times.append(time.perf_counter() - t0)
+        return min(times)
+
+    hw = os.cpu_count() or 1
+    best_t, best_th = None, 1
+    for th in sorted({min(hw, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(th)
+        t = substep(min(1024, N), 2)
+        if best_t is None or t < best_t:
+            best_t, best_th = t, th
+    torch.set_num_threads(best_th)
+    Bs = min(8192, N)
+    t_sub = substep(Bs, 3)
+    full = t_sub * S * (N / Bs)
+    return {"value": 1.0 / full, "unit": "ELBO-steps/sec", "cores": best_th, "kind": "port",
+            "sample": "oracle SVI sub-step (fwd+autograd bwd+Adam, float64, torch-CPU BLAS, %d threads = fastest of 8..128 on this "
+                      "%d-thread host) at S=1, B=%d of N=%d, M=%d: %.3f s; full step = S*N/B = %d sub-steps (linear extrapolation)"
+                      % (best_th, hw, Bs, N, M, t_sub, int(S * N / Bs)),
+            "seconds_per_substep": t_sub}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
+    ap.add_argument('--N', type=int, default=65536)
+    ap.add_argument('--Q', type=int, default=8)
+    ap.add_argument('--M', type=int, default=1024)
+    ap.add_argument('--samples', type=int, default=32)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.samples % world:
+        raise SystemExit('--samples must be divisible by the number of GPUs')
+    S_local = args.samples // world
+    torch.manual_seed(1234 + rank)
+
+    N, Q, M = args.N, args.Q, args.M
+    X, Y, Z = synth(N, Q, M)
+    m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed)
+    td = torch.float32 if args.dtype == 'float32' else torch.float64
+    Yd = torch.as_tensor(Y, dtype=td).cuda()
+    dt, last_loss = time_steps(infr, loop, Yd, args.steps, args.warmup, args.lr, distributed)
+
+    out = {
+        "metric": "ELBO-steps/sec + RBF Gram GB/s, SVGP N=65k D=8 M=1024, 1->8 MI355X",
+        "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
+        "config": {"workload": "SVGPRegression RBF-ARD N=%d Q=%d M=%d, %d MC samples (latent-input model), "
+                               "StochasticVariationalInference step = draw + ELBO + reverse mode + grad all-reduce + Adam" % (N, Q, M, args.samples),
+                   "samples_per_gpu": S_local, "parallelism": "mc-samples sharded x%d, 1 RCCL all-reduce of the flat gradient/step" % world,
+                   "core_precision": "float64 (M x M factorisations), streaming %s" % args.dtype},
+        "last_loss": last_loss,
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        del infr, m, q
+        torch.cuda.empty_cache()
+        out["roofline"] = gram_roofline(N, Q, args.dtype)
+        out["roofline_mfma"] = mfma_roofline(M, N * S_local, args.dtype)
+        other = 'float64' if args.dtype == 'float32' else 'float32'
+        out["roofline_" + ("f64" if other == 'float64' else "f32")] = gram_roofline(N, Q, other)
+        # the same step in the other precision (f64 = the parity precision of the reference's tests), plus the
+        # agreement of the two ELBO values on identical parameters and noise
+        torch.manual_seed(1234)
+        m2, q2, infr2, loop2, _ = build(N, Q, M, S_local, other, X, Y, Z, False)
+        Y2 = torch.as_tensor(Y, dtype=torch.float64 if other == 'float64' else torch.float32).cuda()
+        dt2, loss2 = time_steps(infr2, loop2, Y2, max(2, args.steps // 3), 1, args.lr, False)
+        out["other_dtype"] = {"dtype": "f64" if other == 'float64' else "f32", "value": max(2, args.steps // 3) / dt2, "unit": "ELBO-steps/sec"}
+        del infr2, m2, q2
+        torch.cuda.empty_cache()
+        from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+        vals = {}
+        eps64 = torch.randn(4, N, Q, dtype=torch.float64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
+        for dname in ('float32', 'float64'):
+            tdd = torch.float32 if dname == 'float32' else torch.float64
+            mm, qq, ii, ll, qx = build(N, Q, M, 4, dname, X, Y, Z, False)
+            qx._rand_gen = MockRandomGenerator(eps64.to(tdd))     # identical injected noise in both precisions
+            ex = ii.create_executor()
+            with torch.no_grad():
+                vals[dname] = float(ex(torch.as_tensor(Y, dtype=tdd).cuda())[0])
+            del mm, qq, ii, ex
+            torch.cuda.empty_cache()
+        out["elbo_f32_vs_f64_rel"] = abs(vals['float32'] - vals['float64']) / abs(vals['float64'])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, Q, M, args.samples, X, Y, Z)
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -39,10 +39,12 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, int6
         const T rs = (T)1 / sqrt(d);
         if (tid >= j && tid < nb) col[tid] = (tid == j) ? d * rs : a[tid][j] * rs;
         __syncthreads();
-        const int m = nb - j - 1;
-        for (int e = tid; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i) a[i][c] -= col[i] * col[c];
+        {   // trailing update of the lower triangle: thread (tid&63) owns a column, rows strided by 4
+            const int c = j + 1 + (tid & 63);
+            if (c < nb) {
+                const T cc = col[c];
+                for (int i = c + (tid >> 6); i < nb; i += 4) a[i][c] -= col[i] * cc;
+            }
         }
         if (tid >= j && tid < nb) a[tid][j] = col[tid];
         __syncthreads();
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(128) void solve_rows_kernel(T* __restrict__ A, int6
 #pragma unroll
         for (int k = 0; k < j; ++k) s = fma(-x[k], l[j][k], s);
         x[j] = s / l[j][j];
+        __builtin_amdgcn_sched_barrier(0);   // keep the 2016 broadcast LDS reads from being hoisted (register blow-up)
     }
     __syncthreads();
 #pragma unroll
@@ -113,19 +116,35 @@ __global__ __launch_bounds__(256) void solve_cols_kernel(const T* __restrict__ L
     __syncthreads();
     const int64_t c = c0 + (int64_t)blockIdx.x * 256 + tid;
     if (c >= c0 + ncols) return;
-    T x[NB];
+    // forward substitution in chunks of 8 rows: solved rows are written back to B (in place) and re-read from
+    // L1/L2 by later chunks (coalesced across lanes), so only 8 values are live in registers at a time
+    constexpr int CH = 8;
+    for (int ib = 0; ib < nb; ib += CH) {
+        T sacc[CH];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int gi = TRANS ? nb - 1 - i : i;
-        T s = (i < nb) ? Bk[(int64_t)gi * ldb + c] : (T)0;
+        for (int r = 0; r < CH; ++r) {
+            const int i = ib + r;
+            const int gi = TRANS ? nb - 1 - i : i;
+            sacc[r] = (i < nb) ? Bk[(int64_t)gi * ldb + c] : (T)0;
+        }
+        for (int m = 0; m < ib; ++m) {
+            const int gm = TRANS ? nb - 1 - m : m;
+            const T xm = Bk[(int64_t)gm * ldb + c];
 #pragma unroll
-        for (int m = 0; m < i; ++m) s = fma(-x[m], l[i][m], s);
-        x[i] = s / l[i][i];
-    }
+            for (int r = 0; r < CH; ++r) sacc[r] = fma(-xm, l[ib + r][m], sacc[r]);
+        }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int gi = TRANS ? nb - 1 - i : i;
-        if (i < nb) Bk[(int64_t)gi * ldb + c] = x[i];
+        for (int r = 0; r < CH; ++r) {
+#pragma unroll
+            for (int m = 0; m < r; ++m) sacc[r] = fma(-sacc[m], l[ib + r][ib + m], sacc[r]);
+            sacc[r] = sacc[r] / l[ib + r][ib + r];
+        }
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            const int i = ib + r;
+            const int gi = TRANS ? nb - 1 - i : i;
+            if (i < nb) Bk[(int64_t)gi * ldb + c] = sacc[r];
+        }
     }
 }
 

@@ -75,6 +75,33 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// wave64 sum with DPP (no LDS traffic); the total is valid in LANE 63 only.
+// quad butterflies, row_half_mirror, row_mirror give every lane of a 16-lane row its row sum; row_bcast:15 / :31 fold rows.
+#define MXF_DPP_F(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += MXF_DPP_F(v, 0xB1, 0xf);    // quad_perm [1,0,3,2]
+    v += MXF_DPP_F(v, 0x4E, 0xf);    // quad_perm [2,3,0,1]
+    v += MXF_DPP_F(v, 0x141, 0xf);   // row_half_mirror
+    v += MXF_DPP_F(v, 0x140, 0xf);   // row_mirror
+    v += MXF_DPP_F(v, 0x142, 0xa);   // row_bcast:15 -> rows 1,3
+    v += MXF_DPP_F(v, 0x143, 0xc);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+#define MXF_DPP_D(v, ctrl, rmask)                                                                                  \
+    __builtin_bit_cast(double, (((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(                        \
+                                     0, (int)(__builtin_bit_cast(unsigned long long, (v)) >> 32), (ctrl), (rmask), 0xf, false)) << 32) | \
+                                (unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(                         \
+                                    0, (int)(__builtin_bit_cast(unsigned long long, (v)) & 0xffffffffull), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ double wave_sum63(double v) {
+    v += MXF_DPP_D(v, 0xB1, 0xf);
+    v += MXF_DPP_D(v, 0x4E, 0xf);
+    v += MXF_DPP_D(v, 0x141, 0xf);
+    v += MXF_DPP_D(v, 0x140, 0xf);
+    v += MXF_DPP_D(v, 0x142, 0xa);
+    v += MXF_DPP_D(v, 0x143, 0xc);
+    return v;
+}
+
 // block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {

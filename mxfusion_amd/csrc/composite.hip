@@ -398,8 +398,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
     D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
     // Psi2 = Kuf Kuf^T (split-K MFMA)
-    rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Kuf, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
+    rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Kuf, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 1, st);   // lower blocks only
     if (rc) return rc;
+    hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, Psi2, M, M, MM);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
     // ---- core reverse mode (float64) ---------------------------------------------------------------------

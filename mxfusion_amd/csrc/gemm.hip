@@ -17,42 +17,45 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Tile;
-template <> struct Tile<float> { static constexpr int LD = BM + 4; };    // row stride of the k-major LDS tiles
-template <> struct Tile<double> { static constexpr int LD = BM + 1; };
+template <> struct Tile<float> { static constexpr int LD = BM + 4; };    // row stride of the k-major LDS tiles (16-B aligned rows)
+template <> struct Tile<double> { static constexpr int LD = BM + 2; };
 
 template <typename T>
 struct GemmArgs {
     const T* A; const T* B; T* C;
     int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
     T alpha, beta;
-    int splitk, lower_only, atomic;
+    int splitk, lower_only, atomic, vecA, vecB;
     int64_t kchunk;
+    int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
 };
 
-// loads the op(A) (or op(B)) tile [BK x 128] for k in [k0,k0+BK) into registers, 8 elements / thread
+constexpr int EPT = BK * 128 / 256;   // elements of one operand tile per thread
+
+// ---- generic (guarded, any alignment) tile loaders: [BK x 128] tile, EPT scalars per thread ------------------
 // KCONT: the matrix is stored with k contiguous (A not transposed / B transposed)
 template <typename T, bool KCONT>
-__device__ __forceinline__ void load_tile(T (&reg)[8], const T* __restrict__ P, int64_t ld, int64_t mn0, int64_t MN,
+__device__ __forceinline__ void load_tile(T (&reg)[EPT], const T* __restrict__ P, int64_t ld, int64_t mn0, int64_t MN,
                                           int64_t k0, int64_t kend, int tid) {
     if (KCONT) {
-        const int k = tid & 15;
+        const int k = tid & (BK - 1);
         const int64_t kk = k0 + k;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t i = mn0 + (tid >> 4) + 16 * j;
+        for (int j = 0; j < EPT; ++j) {
+            const int64_t i = mn0 + (tid / BK) + (256 / BK) * j;
             reg[j] = (i < MN && kk < kend) ? P[i * ld + kk] : (T)0;
         }
     } else {
         const int i = tid & 127;
         const int64_t ii = mn0 + i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < EPT; ++j) {
             const int64_t kk = k0 + (tid >> 7) + 2 * j;
             reg[j] = (ii < MN && kk < kend) ? P[kk * ld + ii] : (T)0;
         }
@@ -60,16 +63,63 @@ __device__ __forceinline__ void load_tile(T (&reg)[8], const T* __restrict__ P, 
 }
 
 template <typename T, bool KCONT>
-__device__ __forceinline__ void store_tile(const T (&reg)[8], T* __restrict__ S, int tid) {
+__device__ __forceinline__ void store_tile(const T (&reg)[EPT], T* __restrict__ S, int tid) {
     constexpr int LD = Tile<T>::LD;
     if (KCONT) {
-        const int k = tid & 15;
+        const int k = tid & (BK - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) S[k * LD + (tid >> 4) + 16 * j] = reg[j];
+        for (int j = 0; j < EPT; ++j) S[k * LD + (tid / BK) + (256 / BK) * j] = reg[j];
     } else {
         const int i = tid & 127;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) S[((tid >> 7) + 2 * j) * LD + i] = reg[j];
+        for (int j = 0; j < EPT; ++j) S[((tid >> 7) + 2 * j) * LD + i] = reg[j];
+    }
+}
+
+// ---- fast (interior, 16-byte aligned) tile loaders: EPT/VEC 16-byte vectors per thread ----------------------------
+template <typename T, bool KCONT>
+__device__ __forceinline__ void load_tile_vec(T (&reg)[EPT], const T* __restrict__ P, int64_t ld, int64_t mn0, int64_t k0, int tid) {
+    constexpr int VEC = Vec16<T>::n;
+    typedef typename Vec16<T>::type V;
+    constexpr int NV = EPT / VEC;
+    if (KCONT) {
+        constexpr int VPR = BK / VEC;                 // vectors per row (k direction)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + 256 * j, i = v / VPR, kc = v % VPR;
+            *reinterpret_cast<V*>(&reg[j * VEC]) = *reinterpret_cast<const V*>(P + (mn0 + i) * ld + k0 + kc * VEC);
+        }
+    } else {
+        constexpr int VPR = 128 / VEC;                // vectors per k-row (mn direction)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + 256 * j, kr = v / VPR, c = v % VPR;
+            *reinterpret_cast<V*>(&reg[j * VEC]) = *reinterpret_cast<const V*>(P + (k0 + kr) * ld + mn0 + c * VEC);
+        }
+    }
+}
+
+template <typename T, bool KCONT>
+__device__ __forceinline__ void store_tile_vec(const T (&reg)[EPT], T* __restrict__ S, int tid) {
+    constexpr int LD = Tile<T>::LD;
+    constexpr int VEC = Vec16<T>::n;
+    typedef typename Vec16<T>::type V;
+    constexpr int NV = EPT / VEC;
+    if (KCONT) {
+        constexpr int VPR = BK / VEC;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + 256 * j, i = v / VPR, kc = v % VPR;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) S[(kc * VEC + e) * LD + i] = reg[j * VEC + e];
+        }
+    } else {
+        constexpr int VPR = 128 / VEC;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = tid + 256 * j, kr = v / VPR, c = v % VPR;
+            *reinterpret_cast<V*>(S + kr * LD + c * VEC) = *reinterpret_cast<const V*>(&reg[j * VEC]);
+        }
     }
 }
 
@@ -159,10 +209,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    if (g.lower_only && n0 > m0 + (BM - 1)) return;   // block entirely above the diagonal
-    const int bz = blockIdx.z;
-    const int batch = bz / g.splitk, split = bz % g.splitk;
+    // XCD-aware 1-D work mapping.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness): give
+    // each XCD a CONTIGUOUS range of work ids so that tiles sharing an operand panel hit the same private L2, and
+    // enumerate only the tiles that exist (lower_only: compact triangular decode) so every XCD gets the same load.
+    int64_t wid = blockIdx.x;
+    {
+        const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t zs = wid / g.ntiles;            // (batch, split) slowest
+    int64_t t = wid % g.ntiles;
+    int64_t tile_m, tile_n;
+    if (g.lower_only) {                           // t -> (row, col), col <= row
+        int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        tile_m = row; tile_n = t - row * (row + 1) / 2;
+    } else {                                      // row tiles fastest: consecutive ids share the B (column) panel
+        tile_m = t % g.tm; tile_n = t / g.tm;
+    }
+    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const int batch = (int)(zs / g.splitk), split = (int)(zs % g.splitk);
 
     const T* __restrict__ A = g.A + (int64_t)batch * g.sA;
     const T* __restrict__ B = g.B + (int64_t)batch * g.sB;
@@ -174,29 +241,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
     Acc<T> acc;
     acc.zero();
 
-    T ra[8], rb[8];
+    T ra[EPT], rb[EPT];
+    // interior, 16-byte-aligned tiles take the vector loaders (block-uniform choice)
+    const bool fullk = ((kend - kbeg) % BK) == 0;
+    const bool fastA = g.vecA && fullk && (m0 + BM <= g.M);
+    const bool fastB = g.vecB && fullk && (n0 + BN <= g.N);
+#define LOAD_A(k0) do { if (fastA) load_tile_vec<T, !TA>(ra, A, g.lda, m0, (k0), tid); else load_tile<T, !TA>(ra, A, g.lda, m0, g.M, (k0), kend, tid); } while (0)
+#define LOAD_B(k0) do { if (fastB) load_tile_vec<T, TB>(rb, B, g.ldb, n0, (k0), tid); else load_tile<T, TB>(rb, B, g.ldb, n0, g.N, (k0), kend, tid); } while (0)
+#define STORE_A(buf) do { if (fastA) store_tile_vec<T, !TA>(ra, smem[buf][0], tid); else store_tile<T, !TA>(ra, smem[buf][0], tid); } while (0)
+#define STORE_B(buf) do { if (fastB) store_tile_vec<T, TB>(rb, smem[buf][1], tid); else store_tile<T, TB>(rb, smem[buf][1], tid); } while (0)
     if (kbeg < kend) {
-        load_tile<T, !TA>(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
-        load_tile<T, TB>(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
-        store_tile<T, !TA>(ra, smem[0][0], tid);
-        store_tile<T, TB>(rb, smem[0][1], tid);
+        LOAD_A(kbeg); LOAD_B(kbeg);
+        STORE_A(0); STORE_B(0);
     }
     __syncthreads();
     int cur = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK < kend);
-        if (more) {
-            load_tile<T, !TA>(ra, A, g.lda, m0, g.M, k0 + BK, kend, tid);
-            load_tile<T, TB>(rb, B, g.ldb, n0, g.N, k0 + BK, kend, tid);
-        }
+        if (more) { LOAD_A(k0 + BK); LOAD_B(k0 + BK); }
         acc.mma(smem[cur][0], smem[cur][1], wm, wn, lane);
-        if (more) {
-            store_tile<T, !TA>(ra, smem[cur ^ 1][0], tid);
-            store_tile<T, TB>(rb, smem[cur ^ 1][1], tid);
-        }
+        if (more) { STORE_A(cur ^ 1); STORE_B(cur ^ 1); }
         __syncthreads();
         cur ^= 1;
     }
+#undef LOAD_A
+#undef LOAD_B
+#undef STORE_A
+#undef STORE_B
 
     const T alpha = g.alpha, beta = g.beta;
     const bool atomic = g.atomic != 0;
@@ -229,6 +300,11 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     g.A = (const T*)A; g.B = (const T*)B; g.C = (T*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.alpha = (T)alpha; g.beta = (T)beta; g.lower_only = lower_only;
+    {
+        constexpr int VEC = Vec16<T>::n;
+        auto ok = [&](const void* p, int64_t ld, int64_t st) { return ((uintptr_t)p % 16 == 0) && (ld % VEC == 0) && (st % VEC == 0); };
+        g.vecA = ok(A, lda, sA); g.vecB = ok(B, ldb, sB);
+    }
     const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     // split K when the output grid cannot fill 256 CUs and K is long
     int64_t tiles = tm * tn * batch;
@@ -245,13 +321,17 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     splitk = (int)((K + kchunk - 1) / kchunk);
     if (K == 0) { splitk = 1; kchunk = BK; }
     g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
-    if (tm > 65535 || (int64_t)batch * splitk > 65535) MXF_FAIL(h, -3, "mxf_gemm: grid too large (M=%lld batch=%d)", (long long)M, batch);
+    if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm: lower_only needs a square output");
+    g.tm = tm; g.tn = tn;
+    g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    g.nwg = g.ntiles * batch * splitk;
+    if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm: grid too large");
     if (g.atomic) {
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
         if (M > 65535) MXF_FAIL(h, -3, "mxf_gemm: split-K path needs M<=65535");
         hipLaunchKernelGGL((scale_kernel<T>), gs, dim3(256), 0, st, (T*)C, M, N, ldc, sC, (T)beta, lower_only);
     }
-    dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(batch * splitk));
+    dim3 grid((unsigned)g.nwg, 1, 1);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), 0, st, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), 0, st, g);

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                     gz[q] -= t;
                     gl[q] = fma(-t, d[q], gl[q]);       // dL/dl_q * l_q
                     if (a.dX) {
-                        const T rs = wave_sum(t);
-                        if (lane == 0 && q < Q) lds_add(ra + q, rs);
+                        const T rs = wave_sum63(t);
+                        if (lane == 63 && q < Q) lds_add(ra + q, rs);
                     }
                 }
                 if (FUSED && a.R) {
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
 #pragma unroll
                     for (int p = 0; p < PMAX; ++p) {
                         if (p < P) {
-                            const T rs = wave_sum(kv * e[p]);
-                            if (lane == 0) lds_add(ra + QT + p, rs);
+                            const T rs = wave_sum63(kv * e[p]);
+                            if (lane == 63) lds_add(ra + QT + p, rs);
                         }
                     }
                 }

@@ -31,16 +31,22 @@ class BatchInferenceLoop(GradLoop):
         trainer = _Adam(param_dict, learning_rate, optimizer)
         iter_step = max(max_iter // n_prints, 1)
         for i in range(max_iter):
-            loss, loss_for_gradient = infr_executor(*data)
-            loss_for_gradient.backward()
-            self._exchange(param_dict)
+            loss = self.step(infr_executor, data, param_dict)
             if verbose:
                 print('\rIteration {} loss: {}\t\t\t\t'.format(i + 1, float(loss)), end='')
                 if ((i + 1) % iter_step == 0 and i > 0) or i == max_iter - 1:
                     print()
             trainer.step(batch_size=1)
+        self._trainer = trainer
         with torch.no_grad():                      # batch_loop.py:61: one extra forward, discarded
             infr_executor(*data)
+
+    def step(self, infr_executor, data, param_dict):
+        """record -> forward -> backward (batch_loop.py:52-54) + the gradient exchange hook; returns the loss."""
+        loss, loss_for_gradient = infr_executor(*data)
+        loss_for_gradient.backward()
+        self._exchange(param_dict)
+        return loss
 
     def _exchange(self, param_dict):
         pass
