@@ -5,7 +5,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmxf_gp.so')
+LIB_PATH = os.environ.get('MXF_GP_LIB', os.path.join(_HERE, 'libmxf_gp.so'))   # env override: A/B builds of the kernels
 
 F32, F64 = 0, 1
 K_RBF, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_BIAS, K_WHITE = range(7)

@@ -12,6 +12,8 @@ struct mxf_ctx {
     std::string err;
     void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)
     size_t ws_bytes = 0;
+    void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
+    size_t gram_ws_bytes = 0;
 };
 
 #define MXF_FAIL(h, code, ...)                                   \
@@ -52,6 +54,20 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
     }
     h->ws_bytes = want;
     return h->ws;
+}
+
+static inline void* mxf_gram_ws(mxf_ctx* h, size_t bytes) {
+    if (bytes <= h->gram_ws_bytes) return h->gram_ws;
+    if (h->gram_ws) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(h->gram_ws);
+        h->gram_ws = nullptr;
+        h->gram_ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2) + (1u << 16);
+    if (hipMalloc(&h->gram_ws, want) != hipSuccess) { h->gram_ws = nullptr; return nullptr; }
+    h->gram_ws_bytes = want;
+    return h->gram_ws;
 }
 
 static inline size_t mxf_esize(int dtype) { return dtype == MXF_F64 ? 8 : 4; }

@@ -18,10 +18,11 @@ extern "C" int mxf_create(int device, mxf_handle* out) {
 extern "C" int mxf_destroy(mxf_handle h) {
     if (!h) return -1;
     if (h->ws) (void)hipFree(h->ws);
+    if (h->gram_ws) (void)hipFree(h->gram_ws);
     delete h;
     return 0;
 }
 
 extern "C" const char* mxf_last_error(mxf_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)h->ws_bytes : -1; }
+extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)(h->ws_bytes + h->gram_ws_bytes) : -1; }

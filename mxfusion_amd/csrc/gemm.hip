@@ -17,7 +17,13 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef MXF_GEMM_BK
+#define MXF_GEMM_BK 32
+#endif
+#ifndef MXF_GEMM_WPS
+#define MXF_GEMM_WPS 2
+#endif
+constexpr int BM = 128, BN = 128, BK = MXF_GEMM_BK;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -203,7 +209,7 @@ template <> struct Acc<double> {
 };
 
 template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? MXF_GEMM_WPS : 1)) void gemm_kernel(GemmArgs<T> g) {
     constexpr int LD = Tile<T>::LD;
     __shared__ __attribute__((aligned(16))) T smem[2][2][BK * LD];   // [buffer][A|B]
 
@@ -309,12 +315,18 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     // split K when the output grid cannot fill 256 CUs and K is long
     int64_t tiles = tm * tn * batch;
     if (lower_only) tiles = (tiles + 1) / 2;
+    // split K when the output grid cannot fill the chip.  Resident slots: 256 CUs x (2 workgroups f32 | 1 f64); pick the
+    // split so that the grid is (just under) a whole number of rounds -- 576 workgroups on 512 slots would run a
+    // half-empty second round (measured: Psi2 33 ms -> 19 ms with 504).
     int splitk = 1;
-    if (tiles < 256 && K >= 1024) {
-        splitk = (int)((512 + tiles - 1) / tiles);
-        const int64_t maxsplit = K / 256;
-        if (splitk > maxsplit) splitk = (int)maxsplit;
-        if (splitk < 1) splitk = 1;
+    const int64_t slots = 256 * (sizeof(T) == 4 ? 2 : 1);
+    if (tiles < slots && K >= 256) {
+        const int64_t maxsplit = K / 128 > 0 ? K / 128 : 1;     // small latency-bound GEMMs of the (M x M) core split too
+        int64_t sk = slots / tiles;
+        if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;   // one round would leave >25% of the slots idle: use two
+        if (sk > maxsplit) sk = maxsplit;
+        if (sk < 1) sk = 1;
+        splitk = (int)sk;
     }
     int64_t kchunk = (K + splitk - 1) / splitk;
     kchunk = (kchunk + BK - 1) / BK * BK;

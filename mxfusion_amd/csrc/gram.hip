@@ -13,6 +13,7 @@
 //     1 KiB of one output row per instruction (full-line, fully coalesced), non-temporal (written once,
 //     never re-read by this kernel).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -21,10 +22,12 @@ constexpr int TR = 64;   // rows of X per block
 template <typename T>
 struct GramArgs {
     const T* X; const T* X2; const T* ls; const T* var; const T* dadd;
+    const T* Xs; const T* Zs; int64_t sXs, sZs;   // pre-scaled, zero-padded coordinates [S|1][pad][QT] (prescale_kernel)
     T* K;
     int64_t N, N2, ldk;
     int64_t sX, sX2, sls, svar, sdadd, sK;
-    int Q, ard, square, mode, vecst;
+    int Q, ard, square, mode, vecst, tr, nt;
+    unsigned ncb;          // column blocks (grid.x = ncb * row blocks, column block fastest)
     T jitter;
 };
 
@@ -69,50 +72,31 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.z;
-    const int64_t row0 = (int64_t)blockIdx.y * TR;
-    const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (64 * VEC) + (int64_t)lane * VEC;
+    const int TRr = a.tr;                       // rows per block (<= TR)
+    const int64_t row0 = (int64_t)(blockIdx.x / a.ncb) * TRr;
+    const int64_t col0 = ((int64_t)(blockIdx.x % a.ncb) * 4 + wave) * (64 * VEC) + (int64_t)lane * VEC;
 
-    const T* __restrict__ X = a.X + (int64_t)s * a.sX;
-    const T* __restrict__ X2 = a.X2 + (int64_t)s * a.sX2;
-    const T* __restrict__ ls = a.ls + (int64_t)s * a.sls;
     const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : a.var[(int64_t)s * a.svar];
     T* __restrict__ K = a.K + (int64_t)s * a.sK;
-    const int Q = a.Q;
 
-    // per-dimension multiplier: 1/l_q (stationary) or sqrt(v_q) (linear), folded with the exp2 constant
-    T mult[QT];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) {
-        if (KIND == MXF_K_BIAS || KIND == MXF_K_WHITE) { mult[q] = (T)0; continue; }
-        T l = (q < Q) ? ls[a.ard ? q : 0] : (T)1;
-        if (KIND == MXF_K_LINEAR) mult[q] = (q < Q) ? t_sqrt<T>(l) : (T)0;
-        else mult[q] = (q < Q) ? coord_scale<T, KIND>() / l : (T)0;
-    }
-
-    if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {
-        for (int i = tid; i < TR * QT; i += 256) {
-            const int r = i / QT, q = i % QT;
-            const int64_t row = row0 + r;
-            T l = (q < Q) ? ls[a.ard ? q : 0] : (T)1;
-            T m = (KIND == MXF_K_LINEAR) ? t_sqrt<T>(l) : coord_scale<T, KIND>() / l;
-            xs[i] = (row < a.N && q < Q) ? X[row * Q + q] * m : (T)0;
-        }
-    }
+    // prologue: unguarded 16-byte copies of the PRE-SCALED, zero-padded coordinates (prescale_kernel): the x tile of this
+    // block's rows into LDS, the VEC z-vectors of this lane's columns into VGPRs.
     T z[VEC][QT];
     if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {
+        const T* __restrict__ Xs = a.Xs + (int64_t)s * a.sXs + row0 * QT;
+        for (int i = tid * VEC; i < TRr * QT; i += 256 * VEC)
+            *reinterpret_cast<V*>(&xs[i]) = *reinterpret_cast<const V*>(Xs + i);
+        const T* __restrict__ Zs = a.Zs + (int64_t)s * a.sZs + col0 * QT;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const int64_t col = col0 + v;
-#pragma unroll
-            for (int q = 0; q < QT; ++q) z[v][q] = (col < a.N2 && q < Q) ? X2[col * Q + q] * mult[q] : (T)0;
-        }
+        for (int i = 0; i < VEC * QT; i += VEC)
+            *reinterpret_cast<V*>(&z[0][0] + i) = *reinterpret_cast<const V*>(Zs + i);
     }
     __syncthreads();
     if (col0 >= a.N2) return;
 
     const T dadd = a.square ? ((a.dadd ? a.dadd[(int64_t)s * a.sdadd] : (T)0) + a.jitter) : (T)0;
     const bool full = VECST && (col0 + VEC <= a.N2);
-    const int64_t rmax = (a.N - row0) < TR ? (a.N - row0) : TR;
+    const int64_t rmax = (a.N - row0) < TRr ? (a.N - row0) : TRr;
 
 #pragma unroll 2
     for (int r = 0; r < rmax; ++r) {
@@ -128,6 +112,23 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
             T x[QT];
 #pragma unroll
             for (int q = 0; q < QT; ++q) x[q] = xs[r * QT + q];
+            if constexpr (sizeof(T) == 4 && KIND != MXF_K_LINEAR) {
+                // float: two outputs per v_pk_add_f32 / v_pk_fma_f32 (halves the VALU issue slots of the distance loop)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int p = 0; p < VEC / 2; ++p) {
+                    f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const f32x2 xx = {(float)x[q], (float)x[q]};
+                        const f32x2 zz = {(float)z[2 * p][q], (float)z[2 * p + 1][q]};
+                        const f32x2 d = xx - zz;
+                        acc2 = __builtin_elementwise_fma(d, d, acc2);
+                    }
+                    kv[2 * p] = cov_from<T, KIND>((T)acc2.x, variance);
+                    kv[2 * p + 1] = cov_from<T, KIND>((T)acc2.y, variance);
+                }
+            } else
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 T acc = 0;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
             T* po = reinterpret_cast<T*>(&out);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) po[v] = kv[v];
-            if (MODE == MXF_WRITE) __builtin_nontemporal_store(out, reinterpret_cast<V*>(dst));
+            if (MODE == MXF_WRITE && a.nt) __builtin_nontemporal_store(out, reinterpret_cast<V*>(dst));
             else *reinterpret_cast<V*>(dst) = out;
         } else {
 #pragma unroll
@@ -171,6 +172,24 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
             }
         }
     }
+}
+
+// out[s][row][q] = X[s][row][q] * m_q for row < N, q < Q, else 0  (row < pad, q < QT);  m_q = c/l_q or sqrt(v_q)
+template <typename T, int QT, int KIND>
+__global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __restrict__ ls, int64_t sls, int ard, int64_t N, int Q,
+                                int64_t pad, T* __restrict__ out) {
+    const int s = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pad * QT) return;
+    const int64_t row = i / QT;
+    const int q = (int)(i % QT);
+    T v = (T)0;
+    if (row < N && q < Q) {
+        const T l = ls[(int64_t)s * sls + (ard ? q : 0)];
+        const T m = (KIND == MXF_K_LINEAR) ? t_sqrt<T>(l) : coord_scale<T, KIND>() / l;
+        v = X[(int64_t)s * sX + row * Q + q] * m;
+    }
+    out[(int64_t)s * pad * QT + i] = v;
 }
 
 // generic fallback for Q > 16: one output per thread, q-loop over global memory
@@ -215,9 +234,39 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
         return 0;
     }
     a.vecst = (a.ldk % VEC == 0) && (a.sK % VEC == 0) && (((uintptr_t)a.K) % 16 == 0);
-    dim3 g((unsigned)((a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC)), (unsigned)((a.N + TR - 1) / TR), (unsigned)S);
-    if (g.y > 65535u) MXF_FAIL(h, -3, "mxf_gram: N too large for one launch");
-#define GO(QT) hipLaunchKernelGGL((gram_kernel<T, QT, KIND>), g, dim3(256), 0, st, a)
+    {   // tuning knobs (debug / A-B probes only): rows per block and the store flavour
+        static const int tr_env = getenv("MXF_GRAM_TR") ? atoi(getenv("MXF_GRAM_TR")) : 0;
+        static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
+        // measured on MI355X (N=65536,Q=8): f32 RBF is fastest with 16-row blocks (5.38 vs 5.15 TB/s), the heavier epilogues with 64
+        a.tr = (tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((sizeof(T) == 4 && KIND == MXF_K_RBF) ? 16 : TR);
+        a.nt = (nt_env >= 0) ? nt_env : 1;
+    }
+    a.ncb = (unsigned)((a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC));
+    const int64_t nblk = (int64_t)a.ncb * ((a.N + a.tr - 1) / a.tr);
+    if (nblk > 2147483647LL) MXF_FAIL(h, -3, "mxf_gram: problem too large for one launch");
+    dim3 g((unsigned)nblk, 1, (unsigned)S);
+#define GO(QT)                                                                                                        \
+    do {                                                                                                              \
+        if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {                                                              \
+            const int64_t padr = (a.N + TR - 1) / TR * TR, padc = (a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC) * (4 * 64 * VEC); \
+            const int Sx = (a.sX == 0 && a.sls == 0) ? 1 : S, Sz = (a.sX2 == 0 && a.sls == 0) ? 1 : S;                \
+            const int64_t padx = a.square ? (padr > padc ? padr : padc) : padr;                                       \
+            const size_t need = ((size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc)) * QT * sizeof(T);           \
+            T* buf = (T*)mxf_gram_ws(h, need);                                                                        \
+            if (!buf) MXF_FAIL(h, -4, "mxf_gram: cannot allocate %zu bytes for the pre-scaled coordinates", need);    \
+            hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padx * QT + 255) / 256), Sx), dim3(256), 0, st, a.X, a.sX, \
+                               a.ls, a.sls, a.ard, a.N, a.Q, padx, buf);                                              \
+            a.Xs = buf; a.sXs = (Sx == 1) ? 0 : padx * QT;                                                            \
+            if (a.square) { a.Zs = buf; a.sZs = a.sXs; }                                                              \
+            else {                                                                                                    \
+                T* bz = buf + (size_t)Sx * padx * QT;                                                                 \
+                hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padc * QT + 255) / 256), Sz), dim3(256), 0, st, a.X2, \
+                                   a.sX2, a.ls, a.sls, a.ard, a.N2, a.Q, padc, bz);                                   \
+                a.Zs = bz; a.sZs = (Sz == 1) ? 0 : padc * QT;                                                         \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((gram_kernel<T, QT, KIND>), g, dim3(256), 0, st, a);                                       \
+    } while (0)
     if (KIND == MXF_K_BIAS || KIND == MXF_K_WHITE) GO(2);
     else if (a.Q <= 2) GO(2);
     else if (a.Q <= 4) GO(4);

@@ -243,6 +243,10 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     if (rb < TRB) rb = TRB;
     const int64_t npad = (a.N + TRB - 1) / TRB * TRB;
     if (rb > npad) rb = npad;
+    {   // small problems (the M x M core Gram): split the rows into bands so that the grid still fills the chip
+        const int64_t tiles0 = (a.N2 + 255) / 256;
+        while (rb > TRB && tiles0 * ((a.N + rb - 1) / rb) * S < 512) rb = (rb / 2 + TRB - 1) / TRB * TRB;
+    }
     a.RB = rb;
     const int64_t rblocks = (a.N + rb - 1) / rb;
     const int64_t tiles = (a.N2 + 255) / 256;

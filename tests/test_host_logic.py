@@ -1,0 +1,122 @@
+"""CPU tests of the host-side mirror of the reference API (no kernels are launched): graph construction, variable
+roles, the Module algorithm registry (modules/module.py:193-302), parameter storage, minibatch 'rollover' indexing."""
+import numpy as np
+import pytest
+import torch
+
+from mxfusion_amd import Model, Variable
+from mxfusion_amd.components.variables import PositiveTransformation, VariableType
+from mxfusion_amd.components.distributions import Normal
+from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+from mxfusion_amd.modules.gp_modules import GPRegression, SVGPRegression
+from mxfusion_amd.modules.gp_modules.gp_regression import GPRegressionSamplingPrediction, GPRegressionMeanVariancePrediction
+from mxfusion_amd.inference import MAP, StochasticVariationalInference, create_Gaussian_meanfield
+from mxfusion_amd.inference.inference_parameters import InferenceParameters
+from mxfusion_amd.common.exceptions import ModelSpecificationError
+
+
+def _gp():
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 3))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.kernel = RBF(input_dim=3, ARD=True, variance=1., lengthscale=np.ones(3))
+    m.Y = GPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, shape=(m.N, 2))
+    return m
+
+
+def test_model_graph_and_variable_roles():
+    m = _gp()
+    assert m.Y.type == VariableType.RANDVAR and m.X.type == VariableType.PARAMETER
+    gp = m.Y.factor
+    assert gp.input_names == ['X', 'noise_var'] and gp.output_names == ['random_variable']
+    assert gp.X is m.X and gp.random_variable is m.Y                       # factor.py:76-99 name lookup
+    assert set(gp.kernel.parameters) == {'rbf_lengthscale', 'rbf_variance'}
+    hidden = gp.extra_parameters()
+    assert m.kernel.lengthscale in hidden and m.kernel.variance in hidden      # kernel parameters are hidden module parameters
+    assert m.ordered_factors == [gp]
+    assert [v.name for v in m.get_latent_variables([m.X, m.Y])] == []
+    assert MAP(model=m, observed=[m.X, m.Y]).observed_variable_names == ['X', 'Y']
+
+
+def test_module_algorithm_registry_is_the_plugin_point():
+    m = _gp()
+    gp = m.Y.factor
+    assert isinstance(gp.gp_predict, GPRegressionMeanVariancePrediction)
+    # swap the prediction algorithm exactly like testing/modules/gpregression_test.py:270-278 / the GP notebook cell 24
+    alg = GPRegressionSamplingPrediction(gp._module_graph, gp._extra_graphs[0], [gp._module_graph.X])
+    gp.attach_prediction_algorithms(targets=gp.output_names, conditionals=gp.input_names, algorithm=alg, alg_name='gp_predict')
+    assert gp.gp_predict is alg
+    assert len(gp._prediction_algorithms[('X', 'noise_var')]) == 1                # replaced, not appended (module.py:262-302)
+    got = gp._get_algorithm_for_target_conditional_pair(gp._prediction_algorithms, ('random_variable',), ('X', 'noise_var'), exact_match=True)
+    assert got is alg
+    with pytest.raises(ModelSpecificationError):
+        gp._get_algorithm_for_target_conditional_pair(gp._prediction_algorithms, ('random_variable',), ('X',), exact_match=True)
+    gp.gp_log_pdf.jitter = 1e-6                                                     # algorithm knobs are plain attributes
+    assert gp.gp_log_pdf.jitter == 1e-6
+
+
+def test_combination_kernels_prefix_parameters():
+    k = Matern52(4, name='matern52') + RBF(4)
+    assert set(k.parameters) == {'add_matern52_lengthscale', 'add_matern52_variance', 'add_rbf_lengthscale', 'add_rbf_variance'}
+    k2 = RBF(2) * RBF(2)
+    assert len(k2.parameters) == 4            # duplicate sub-kernel names are disambiguated
+    assert (RBF(2)).fused_spec() == ('rbf', False) and k.fused_spec() is None
+
+
+def test_svi_model_posterior_and_parameters_on_cpu():
+    m = Model()
+    m.N = Variable()
+    m.X = Normal.define_variable(mean=0, variance=1, shape=(m.N, 3))
+    m.Z = Variable(shape=(5, 3), initial_value=np.arange(15.).reshape(5, 3))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=RBF(3, ARD=True), noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1))
+    gp = m.Y.factor
+    post = gp._extra_graphs[0]
+    assert post.qU_mean.shape == (5, 1) and post.qU_cov_W.shape == (5, 5) and post.qU_cov_diag.shape == (5,)
+    q = create_Gaussian_meanfield(model=m, observed=[m.Y])
+    qX = q[m.X].factor
+    assert isinstance(qX, Normal) and q[m.X].uuid == m.X.uuid                 # posterior replicas keep the UUID
+    alg = StochasticVariationalInference(model=m, posterior=q, num_samples=4, observed=[m.Y])
+    params = InferenceParameters(dtype='float64', context=torch.device('cpu'))
+    params.update_constants({m.N.uuid: 7})
+    params.initialize_params(alg.graphs, alg.observed_variable_UUIDs, seed=0)
+    names = {v.uuid for v in (m.Z, m.noise_var, post.qU_mean, post.qU_cov_W, post.qU_cov_diag, qX.mean, qX.variance,
+                              gp.kernel.lengthscale, gp.kernel.variance)}
+    assert names == set(params._slices)                                      # exactly the trainable parameters, N/X/Y excluded
+    assert params.flat.numel() == 15 + 1 + 5 + 25 + 5 + 21 + 21 + 3 + 1 and params.flat.requires_grad
+    assert torch.allclose(params.raw(m.Z), torch.arange(15., dtype=torch.float64).reshape(5, 3))
+    # positive parameters are stored unconstrained: raw = log(expm1(value)) (var_trans.py:91)
+    assert torch.allclose(params.raw(m.noise_var), torch.log(torch.expm1(torch.tensor([0.01], dtype=torch.float64))))
+    params[post.qU_mean] = np.ones((5, 1))
+    assert torch.all(params.raw(post.qU_mean) == 1)
+    params[qX.variance] = np.full((7, 3), 0.5)
+    assert torch.allclose(params.raw(qX.variance), torch.log(torch.expm1(torch.tensor(0.5, dtype=torch.float64))))
+    views = params.tensors()
+    (views[m.Z.uuid].sum() * 2).backward()                                  # views are autograd-connected to the ONE flat leaf
+    o, n, _ = params._slices[m.Z.uuid]
+    assert torch.all(params.flat.grad[o:o + n] == 2) and params.flat.grad.abs().sum() == 2 * 15
+
+
+def test_minibatch_rollover_indexing(monkeypatch):
+    """minibatch_loop.py:65-69: shuffle=True, last_batch='rollover' -- the remainder opens the next epoch; every batch is full."""
+    from mxfusion_amd.inference import minibatch_loop as ml
+
+    class FakeTrainer(object):
+        def __init__(self, *a, **k):
+            self.steps = []
+
+        def step(self, batch_size=1):
+            self.steps.append(batch_size)
+    monkeypatch.setattr(ml, '_Adam', FakeTrainer)
+    seen = []
+
+    def executor(xb):
+        seen.append(xb.clone())
+        loss = (xb.sum() * 0).requires_grad_(True)
+        return loss, loss
+    data = [torch.arange(10.)]
+    loop = ml.MinibatchInferenceLoop(batch_size=4, rv_scaling=None)
+    loop.run(executor, data, param_dict=None, ctx=None, max_iter=2)
+    assert all(b.numel() == 4 for b in seen) and len(seen) == 5          # 10 + 10 samples -> 2 + 3 full batches, 0 left
+    assert sorted(torch.cat(seen).tolist()) == sorted(list(range(10)) * 2)
