@@ -12,6 +12,8 @@ struct mxf_ctx {
     std::string err;
     void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)
     size_t ws_bytes = 0;
+    hipStream_t side = nullptr;   // internal side stream: independent chains of the (M x M) core run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
 };
@@ -54,6 +56,14 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
     }
     h->ws_bytes = want;
     return h->ws;
+}
+
+static inline bool mxf_side_init(mxf_ctx* h) {
+    if (h->side) return true;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
 }
 
 static inline void* mxf_gram_ws(mxf_ctx* h, size_t bytes) {

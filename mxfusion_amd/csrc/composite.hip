@@ -362,50 +362,56 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
     int rc;
-    // ---- core, float64, once -------------------------------------------------------------------------
+    // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
+    if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
+    hipStream_t sd_ = h->side;
     rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu (+jitter) :69-72
     if (rc) return rc;
+    MXF_HIP(h, hipEventRecord(h->ev_fork, st));
+    MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
+    // side chain
+    rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);              // Kuf_all = k(Z, X_all) :73
+    if (rc) return rc;
+    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, M, (const D*)sd, Su);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, sd_);       // Su = W W^T + diag(s) :76
+    if (rc) return rc;
+    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, sd_));
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, sd_);                                // Ls = chol(Su) :84
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, sd_);
+    if (rc) return rc;
+    if (want_grad) {
+        rc = mxf_trtri_internal(h, MXF_F64, 1, M, tmp, M, MM, Lsinv, M, MM, sd_);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, sd_);
+        if (rc) return rc;
+    }
+    MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
+    // main chain
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
-    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, M, (const D*)sd, Su);
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, st);        // Su = W W^T + diag(s) :76
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
+    if (rc) return rc;
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));                                                // join
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
     MXF_HIP(h, hipMemcpyAsync(H0, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
-    if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
-    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
-    if (rc) return rc;
-    // Ls = chol(Su) (needed for logdet Su; its inverse for d/dSu)           :84
-    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, st);
-    if (rc) return rc;
-    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, st);
-    if (rc) return rc;
-    if (want_grad) {
-        rc = mxf_trtri_internal(h, MXF_F64, 1, M, tmp, M, MM, Lsinv, M, MM, st);
-        if (rc) return rc;
-        rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, st);
-        if (rc) return rc;
-    }
     // A_ext = [H0 ; w^T] in the streaming dtype
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
     hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);
 
     // ---- streaming part -----------------------------------------------------------------------------------
-    // Kuf_all = k(Z, X_all): M x SB                                          :73
-    rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, st);
-    if (rc) return rc;
     // [T; U] = [H0; w^T] Kuf_all
     rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
@@ -455,30 +461,35 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, Psi2, M, M, MM);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
-    // ---- core reverse mode (float64) ---------------------------------------------------------------------
+    // ---- core reverse mode (float64): the Su chain runs on the side stream next to the Kuu chain ----------------------
+    MXF_HIP(h, hipEventRecord(h->ev_fork, st));
+    MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
+    // side: dSu = -Ki G Ki + bP/2 (Sui - Ki); dW = 2 dSu W; dSdiag = diag(dSu)
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);            // T3 = Ki G
+    if (rc) return rc;
+    hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, 1.0, (const D*)Sui, -1.0, (const D*)Ki, dSu);   // Sui - Ki
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, tmp, M, 0, Ki, M, 0, 0.5 * bw * P, dSu, M, 0, 1, 0, sd_);
+    if (rc) return rc;
+    if (dW) {
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, Lsinv, M, 0, 1, 0, sd_);     // dW = 2 dSu W (Lsinv buffer is free)
+        if (rc) return rc;
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (T)1, (const D*)Lsinv, dW, 0);
+    }
+    if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, sd_, M, (const D*)dSu, M, dSdiag);
+    MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
+    // main: dKuu = -Ki A_Ki Ki - bP/2 Ki; dmu = Ki Gw - b w
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, st);           // T1 = G Ki Su
     if (rc) return rc;
     hipLaunchKernelGGL(aki_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)G, (const D*)T1, (const D*)Gw, (const D*)mud, (const D*)Su, bw, AKi);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, AKi, M, 0, 0.0, T2, M, 0, 1, 0, st);           // T2 = Ki A_Ki
     if (rc) return rc;
     MXF_HIP(h, hipMemcpyAsync(dKuu, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);   // dKuu = -Ki A Ki - b P/2 Ki
-    if (rc) return rc;
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, T2, M, 0, 1, 0, st);             // T3 = Ki G  (reuse T2)
-    if (rc) return rc;
-    hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, 1.0, (const D*)Sui, -1.0, (const D*)Ki, dSu);   // Sui - Ki
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, 0.5 * bw * P, dSu, M, 0, 1, 0, st);  // dSu = -Ki G Ki + bP/2 (Sui - Ki)
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);           // dmu = Ki Gw - b w
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);
     if (rc) return rc;
     if (dmu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (T)1, (const D*)dmud, dmu, 0);
-    if (dW) {
-        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, T1, M, 0, 1, 0, st);        // dW = 2 dSu W
-        if (rc) return rc;
-        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (T)1, (const D*)T1, dW, 0);
-    }
-    if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, st, M, (const D*)dSu, M, dSdiag);
     // Kuu-side reverse mode in float64, then added to the streaming-side gradients
     MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
     MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
@@ -492,6 +503,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
     }
     if (dnoise) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
     MXF_LAUNCH_CHECK(h);
     return 0;
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                 if (p < P && cvalid) {
                     e[p] = a.Y[sm * a.sY + nb * P + p] - a.U[(int64_t)p * a.lddk + col];
                     e2 += (double)e[p] * (double)e[p];
-                    if (a.dY) {
+                    if (a.dY && blockIdx.y == 0) {      // one row band owns the per-column outputs
                         const T g = -c1 * e[p];
                         if (a.dY_shared) atomic_add(a.dY + nb * P + p, g); else a.dY[col * P + p] = g;
                     }
