@@ -13,7 +13,7 @@ struct mxf_ctx {
     void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)
     size_t ws_bytes = 0;
     hipStream_t side = nullptr;   // internal side stream: independent chains of the (M x M) core run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
 };
@@ -62,7 +62,8 @@ static inline bool mxf_side_init(mxf_ctx* h) {
     if (h->side) return true;
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return false;
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }
 

@@ -343,7 +343,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T));
-    if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
+    if (want_grad) { acc((size_t)M * SB, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
     Carver cv(ws);
@@ -354,6 +354,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
     T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB);
+    T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr;
+    if (want_grad) { Kfu = cv.take<T>((size_t)M * SB); Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
@@ -387,6 +389,17 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
+    if (want_grad) {
+        // Psi2 = Kuf Kuf^T depends on neither the T-GEMM nor the reverse pass: it runs on the side stream, concurrently with them.
+        // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM, which streams both operands
+        // sequentially; the NT form on Kuf reads 256 K-strided (8 MB apart) streams per workgroup (measured 33 ms vs 29 ms).
+        rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, sd_);   // lower blocks only, split-K
+        if (rc) return rc;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
+    }
     // main chain
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
     if (rc) return rc;
@@ -424,13 +437,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
     if (S > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X (loop over samples on the host otherwise)");
     D* dnz = nullptr; D* dvdir = nullptr;
-    T* Psi2 = nullptr; T* R = nullptr;
     if (!want_grad) {
         hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
                            (const T*)wT, noise, a1, 0, (T*)nullptr, (T*)nullptr, 0, scal);
     } else {
         dnz = sc + 4; dvdir = sc + 5;
-        Psi2 = cv.take<T>(MM); R = cv.take<T>(MP);
         if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
         if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
         if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
@@ -449,16 +460,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
 
     D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
     D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
-    // Psi2 = Kuf Kuf^T (split-K MFMA)
-    // Psi2 = Kuf Kuf^T from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines): a TN GEMM streams both operands
-    // sequentially, whereas the NT form reads 256 K-strided (8 MB apart) streams per workgroup (measured 33 ms vs 21 ms).
-    // Kfu reuses the T buffer (T has been consumed by the fused reverse pass above).
-    T* Kfu = Text;
-    rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, st);
-    if (rc) return rc;
-    rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, st);   // lower blocks only
-    if (rc) return rc;
-    hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, Psi2, M, M, MM);
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Psi2 from the side stream
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
     hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
     // ---- core reverse mode (float64): the Su chain runs on the side stream next to the Kuu chain ----------------------

@@ -21,6 +21,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return 0;
