@@ -120,17 +120,21 @@ def gram_roofline(N, Q, dtype, reps=10):
     nbytes = (N * N + 2 * N * Q) * out.element_size()
     del out
     torch.cuda.empty_cache()
+    # HBM bytes per launch from the PMC passes (WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, separate rocprofv3 --pmc runs of exactly this
+    # launch; profiles/r01_gram_pmc.txt).  Only collected for the headline shape / dtype.
+    traffic = 17201975722 if (N == 65536 and Q == 8 and dtype == 'float32') else None
     return {"bound": "hbm", "kernel": "gram_kernel<%s,8,RBF> N=%d Q=%d" % (dtype, N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
-            "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": None, "ms_per_launch": ms, "algorithmic_bytes": nbytes}
+            "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes": nbytes,
+            "write_only_ceiling_GBps": 6080.0}
 
 
 def mfma_roofline(M, SB, dtype, reps=3):
-    """The dominant MFMA kernel of the step: T = [H0; w^T] Kuf_all  ((M+1) x M x SB GEMM)."""
+    """The dominant MFMA kernel of the step: T = H0 Kuf_all  (M x M x SB GEMM)."""
     from mxfusion_amd import ops
     td = torch.float32 if dtype == 'float32' else torch.float64
-    A = torch.randn(1, M + 1, M, device='cuda', dtype=td)
+    A = torch.randn(1, M, M, device='cuda', dtype=td)
     B = torch.randn(1, M, SB, device='cuda', dtype=td)
-    out = torch.empty(1, M + 1, SB, device='cuda', dtype=td)
+    out = torch.empty(1, M, SB, device='cuda', dtype=td)
     ops.gemm(A, B, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -140,11 +144,11 @@ def mfma_roofline(M, SB, dtype, reps=3):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * (M + 1) * M * SB
+    fl = 2.0 * M * M * SB
     peak = 157.3 if dtype == 'float32' else 78.6
     del A, B, out
     torch.cuda.empty_cache()
-    return {"bound": "mfma", "kernel": "gemm_kernel<%s,NN> %dx%dx%d" % (dtype, M + 1, SB, M), "achieved": fl / ms / 1e9, "peak": peak,
+    return {"bound": "mfma", "kernel": "gemm_kernel<%s,NN> %dx%dx%d" % (dtype, M, SB, M), "achieved": fl / ms / 1e9, "peak": peak,
             "unit": "TFLOP/s", "frac": fl / ms / 1e9 / peak, "traffic": None, "ms_per_launch": ms, "algorithmic_flops": fl}
 
 
