@@ -178,6 +178,16 @@ int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t
                     void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
                     void* dls, void* dvar, void* stream);
 
+/* SparseGPRegressionLogPdf.compute (modules/gp_modules/sparsegp_regression.py:42-108), Titsias bound, ONE sample
+ * (callers loop over samples), stationary kernel, sufficient-statistics form with C = Kuu + Psi2/noise.
+ *   X (B,Q)  Y (B,P) [minus mean]  Z (M,Q)  noise_var (1)  lengthscale (Q|1)  variance (1)
+ * outputs: logL (1); the posterior side products of :99-106: wv (M,P), L (M,M), LA (M,M) (any may be NULL);
+ * if want_grad: gscale * d logL / d(.) WRITTEN into dX (B,Q) dY (B,P) dZ (M,Q) dnoise (1) dls (Q|1) dvar (1).       */
+int mxf_sgp_logpdf(mxf_handle h, int kind, int dtype, int64_t B, int64_t M, int Q, int P, const void* X, const void* Y,
+                   const void* Z, const void* noise_var, const void* lengthscale, int ard, const void* variance,
+                   double jitter, double gscale, void* logL, void* wv, void* L, void* LA, int* info, int want_grad,
+                   void* dX, void* dY, void* dZ, void* dnoise, void* dls, void* dvar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,6 +510,175 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     return 0;
 }
 
+// ================================================================================================ sparse (Titsias) GP
+// SparseGPRegressionLogPdf.compute (sparsegp_regression.py:42-108), one sample, in sufficient statistics:
+//   C = Kuu + Psi2/s2 (= L A L^T of the reference, so LA = L^-1 chol(C)), a = C^-1 psi1,
+//   logL = -P/2 (log|C| - log|Kuu|) - 1/2 (ups/s2 + BP log 2pi + BP log s2) + tr(psi1^T a)/(2 s2^2) - P B var/(2 s2) + P tr(Ki Psi2)/(2 s2)
+// reverse mode (verified against autograd of the oracle to 1e-14):
+//   GC = -P/2 C^-1 - a a^T/(2 s2^2);  dPsi2 = GC/s2 + P/(2 s2) Ki;  dKuu = GC + P/2 Ki - P/(2 s2) Ki Psi2 Ki;  dpsi1 = a/s2^2
+__global__ void sgp_add_psi2_kernel(int64_t n, double* __restrict__ C, const double* __restrict__ Psi2, const double* __restrict__ noise) {
+    const double beta = 1.0 / noise[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) C[i] += beta * Psi2[i];
+}
+template <typename T>
+__global__ void sgp_grads_kernel(int64_t M, int P, const double* __restrict__ Ci, const double* __restrict__ Ki, const double* __restrict__ KPK,
+                                 const double* __restrict__ a, const double* __restrict__ noise, double gscale, T* __restrict__ G2,
+                                 double* __restrict__ GKuu, T* __restrict__ Gpsi1) {
+    const double s2 = noise[0], is2 = 1.0 / s2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * M; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / M, j = idx % M;
+        double aa = 0;
+        for (int p = 0; p < P; ++p) aa += a[i * P + p] * a[j * P + p];
+        const double GC = -0.5 * P * Ci[idx] - 0.5 * is2 * is2 * aa;
+        G2[idx] = (T)(gscale * 2.0 * (GC * is2 + 0.5 * P * is2 * Ki[idx]));
+        GKuu[idx] = gscale * (GC + 0.5 * P * Ki[idx] - 0.5 * P * is2 * KPK[idx]);
+        if (idx < M * P) Gpsi1[idx] = (T)(gscale * a[idx] * is2 * is2);
+    }
+}
+// sc: [0] sumlogdiag L  [1] sumlogdiag Lc  [2] <psi1,a>  [3] <Ki,Psi2>  [4] <Ci,Psi2>  [5] a^T Psi2 a  [6] ups
+template <typename T>
+__global__ void sgp_finalize_kernel(int64_t B, int64_t M, int P, const double* __restrict__ sc, const double* __restrict__ noise,
+                                    const double* __restrict__ var, double gscale, T* __restrict__ logL, double* __restrict__ dnoise,
+                                    double* __restrict__ dvar_direct, const double* __restrict__ a, T* __restrict__ wv) {
+    const double s2 = noise[0], is2 = 1.0 / s2, vk = var[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double l = -(double)P * (sc[1] - sc[0]) - 0.5 * (sc[6] * is2 + (double)B * P * (LOG2PI + log(s2))) + 0.5 * sc[2] * is2 * is2
+                         - 0.5 * P * (double)B * vk * is2 + 0.5 * P * sc[3] * is2;
+        logL[0] = (T)l;
+        const double gcpsi = -0.5 * P * sc[4] - 0.5 * is2 * is2 * sc[5];       // <GC, Psi2>
+        if (dnoise) dnoise[0] = gscale * (-gcpsi * is2 * is2 + 0.5 * sc[6] * is2 * is2 - 0.5 * (double)B * P * is2 - sc[2] * is2 * is2 * is2
+                                          + 0.5 * P * (double)B * vk * is2 * is2 - 0.5 * P * sc[3] * is2 * is2);
+        if (dvar_direct) dvar_direct[0] = gscale * (-0.5 * P * (double)B * is2);
+    }
+    if (wv) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * P; i += (int64_t)gridDim.x * blockDim.x) wv[i] = (T)(a[i] * is2);
+}
+// dY = dY (= Kuf^T Gpsi1) - gscale * Y / s2
+template <typename T>
+__global__ void sgp_dy_kernel(int64_t n, const T* __restrict__ Y, const T* __restrict__ noise, double gscale, T* __restrict__ dY) {
+    const T c = (T)gscale / noise[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dY[i] -= c * Y[i];
+}
+
+template <typename T>
+int sgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int64_t B, int64_t M, int Q, int P, const T* X, const T* Y, const T* Z, const T* noise,
+                     const T* ls, int ard, const T* var, double jitter, double gscale, T* logL, T* wv, T* Lout, T* LAout, int* info,
+                     int want_grad, T* dX, T* dY, T* dZ, T* dnoise, T* dls, T* dvar, hipStream_t st) {
+    typedef double D;
+    const int64_t MM = M * M, MP = M * P;
+    const int lsn = ard ? Q : 1;
+    size_t need = 0;
+    auto acc = [&](size_t n, size_t es) { need += mxf_align(n * es); };
+    acc(M * Q, 8); acc(lsn, 8); acc(1, 8); acc(1, 8);
+    for (int i = 0; i < 10; ++i) acc(MM, 8);
+    acc(MP, 8); acc(MP, 8); acc(MP, 8); acc(16, 8); acc(4, sizeof(int));
+    acc((size_t)M * B, sizeof(T)); acc((size_t)M * B, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T));
+    acc(M * Q, 8); acc(lsn, 8); acc(4, 8);
+    void* ws = mxf_ws(h, need);
+    if (!ws) MXF_FAIL(h, -4, "mxf_sgp_logpdf: cannot allocate %zu bytes of scratch", need);
+    Carver cv(ws);
+    D* Zd = cv.take<D>(M * Q); D* lsd = cv.take<D>(lsn); D* vard = cv.take<D>(1); D* noised = cv.take<D>(1);
+    D* Lm = cv.take<D>(MM); D* Linv = cv.take<D>(MM); D* Ki = cv.take<D>(MM); D* Cm = cv.take<D>(MM); D* Lcinv = cv.take<D>(MM);
+    D* Ci = cv.take<D>(MM); D* Psi2d = cv.take<D>(MM); D* KPK = cv.take<D>(MM); D* tmp = cv.take<D>(MM); D* GKuu = cv.take<D>(MM);
+    D* psi1d = cv.take<D>(MP); D* ad = cv.take<D>(MP); D* PA = cv.take<D>(MP); D* sc = cv.take<D>(16); int* info2 = cv.take<int>(4);
+    T* Kuf = cv.take<T>((size_t)M * B); T* Kfu = cv.take<T>((size_t)M * B); T* Psi2 = cv.take<T>(MM); T* psi1 = cv.take<T>(MP);
+    T* G2 = cv.take<T>(MM); T* Gpsi1 = cv.take<T>(MP);
+    D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
+#define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
+    CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); CONV(1, noise, noised);
+    MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
+    int rc;
+    rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu :69-72
+    if (rc) return rc;
+    MXF_HIP(h, hipMemcpyAsync(Cm, Lm, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                  // L :77
+    if (rc) return rc;
+    rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
+    if (rc) return rc;
+    // streaming statistics: Psi2 = Kuf Kuf^T (TN on the transposed Gram), psi1 = Kuf Y, ups = |Y|^2
+    rc = mxf_gram(h, kind, dtype, 1, M, B, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, B, 0, st);                 // Kuf :74
+    if (rc) return rc;
+    rc = mxf_gram(h, kind, dtype, 1, B, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, B, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, Psi2, M, M, MM);
+    rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, B, 1.0, Kuf, B, 0, Y, P, 0, 0.0, psi1, P, 0, 1, 0, st);
+    if (rc) return rc;
+    CONV(MM, (const T*)Psi2, Psi2d); CONV(MP, (const T*)psi1, psi1d);
+    hipLaunchKernelGGL((sumsq_kernel<T>), dim3(1), dim3(256), 0, st, B * P, Y, (int64_t)0, sc + 6);
+    // C = Kuu + Psi2/s2, Lc = chol(C), Ci, a = Ci psi1
+    hipLaunchKernelGGL(sgp_add_psi2_kernel, dim3(gridn(MM)), dim3(256), 0, st, MM, Cm, (const D*)Psi2d, (const D*)noised);
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Cm, M, MM, info2, st);
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Cm, M, MM, sc + 1, st);
+    if (rc) return rc;
+    rc = mxf_trtri_internal(h, MXF_F64, 1, M, Cm, M, MM, Lcinv, M, MM, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lcinv, M, 0, Lcinv, M, 0, 0.0, Ci, M, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ci, M, 0, psi1d, P, 0, 0.0, ad, P, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Psi2d, M, 0, ad, P, 0, 0.0, PA, P, 0, 1, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)psi1d, (const D*)ad, 1.0, sc + 2);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Psi2d, 1.0, sc + 3);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ci, (const D*)Psi2d, 1.0, sc + 4);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)ad, (const D*)PA, 1.0, sc + 5);
+    hipLaunchKernelGGL((sgp_finalize_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, B, M, P, (const D*)sc, (const D*)noised, (const D*)vard, gscale,
+                       logL, want_grad ? sc + 8 : (D*)nullptr, want_grad ? sc + 9 : (D*)nullptr, (const D*)ad, wv);
+    // posterior side products (:99-106): L, LA = L^-1 chol(C)
+    if (Lout) hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)Lm, M, Lout, M);
+    if (LAout) {
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Linv, M, 0, Cm, M, 0, 0.0, tmp, M, 0, 1, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)tmp, M, LAout, M);
+    }
+    MXF_LAUNCH_CHECK(h);
+    if (!want_grad) return 0;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Psi2d, M, 0, 0.0, tmp, M, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Ki, M, 0, 0.0, KPK, M, 0, 1, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sgp_grads_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)Ci, (const D*)Ki, (const D*)KPK, (const D*)ad,
+                       (const D*)noised, gscale, G2, GKuu, Gpsi1);
+    // dKuf = 2 dPsi2 Kuf + dpsi1 Y^T  (into the Kfu buffer), then the Gram reverse mode
+    T* dKuf = Kfu;
+    rc = mxf_gemm_internal(h, dtype, 0, 0, M, B, M, 1.0, G2, M, 0, Kuf, B, 0, 0.0, dKuf, B, 0, 1, 0, st);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 0, 1, M, B, P, 1.0, Gpsi1, P, 0, Y, P, 0, 1.0, dKuf, B, 0, 1, 0, st);
+    if (rc) return rc;
+    if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
+    if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
+    if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
+    if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * B * Q, st));
+    rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, B, Q, Z, 0, X, 0, ls, ard, 0, var, 0, dKuf, B, 0, dZ, dX, dls, dvar, st);
+    if (rc) return rc;
+    if (dY) {
+        rc = mxf_gemm_internal(h, dtype, 1, 0, B, P, M, 1.0, Kuf, B, 0, Gpsi1, P, 0, 0.0, dY, P, 0, 1, 0, st);     // Kuf^T dpsi1
+        if (rc) return rc;
+        hipLaunchKernelGGL((sgp_dy_kernel<T>), dim3(gridn(B * P)), dim3(256), 0, st, B * P, Y, noise, gscale, dY);
+    }
+    MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
+    MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
+    MXF_HIP(h, hipMemsetAsync(dvc, 0, sizeof(D) * 4, st));
+    rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, GKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
+    if (rc) return rc;
+    if (dZ) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(M * Q)), dim3(256), 0, st, M * Q, (T)1, (const D*)dZc, dZ, 1);
+    if (dls) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(lsn)), dim3(64), 0, st, (int64_t)lsn, (T)1, (const D*)dlsc, dls, 1);
+    if (dvar) {
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
+        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 9), dvar, 1);
+    }
+    if (dnoise) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 8), dnoise, 0);
+#undef CONV
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int mxf_gp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t N, int Q, int P,
@@ -564,4 +733,25 @@ extern "C" int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t
                                          want_grad, (double*)dX, (double*)dY, (double*)dZ, (double*)dnoise, (double*)dmu, (double*)dW,
                                          (double*)dSdiag, (double*)dls, (double*)dvar, st);
     MXF_FAIL(h, -2, "mxf_svgp_logpdf: bad dtype %d", dtype);
+}
+
+extern "C" int mxf_sgp_logpdf(mxf_handle h, int kind, int dtype, int64_t B, int64_t M, int Q, int P, const void* X, const void* Y,
+                              const void* Z, const void* noise_var, const void* lengthscale, int ard, const void* variance,
+                              double jitter, double gscale, void* logL, void* wv, void* L, void* LA, int* info, int want_grad,
+                              void* dX, void* dY, void* dZ, void* dnoise, void* dls, void* dvar, void* stream) {
+    if (!h) return -1;
+    if (B <= 0 || M <= 0 || Q <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_sgp_logpdf: bad shape");
+    if (!X || !Y || !Z || !noise_var || !lengthscale || !variance || !logL) MXF_FAIL(h, -2, "mxf_sgp_logpdf: null argument");
+    if (kind > MXF_K_MATERN52) MXF_FAIL(h, -2, "mxf_sgp_logpdf: stationary kernels only");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MXF_F32)
+        return sgp_logpdf_typed<float>(h, kind, dtype, B, M, Q, P, (const float*)X, (const float*)Y, (const float*)Z, (const float*)noise_var,
+                                       (const float*)lengthscale, ard, (const float*)variance, jitter, gscale, (float*)logL, (float*)wv, (float*)L,
+                                       (float*)LA, info, want_grad, (float*)dX, (float*)dY, (float*)dZ, (float*)dnoise, (float*)dls, (float*)dvar, st);
+    if (dtype == MXF_F64)
+        return sgp_logpdf_typed<double>(h, kind, dtype, B, M, Q, P, (const double*)X, (const double*)Y, (const double*)Z, (const double*)noise_var,
+                                        (const double*)lengthscale, ard, (const double*)variance, jitter, gscale, (double*)logL, (double*)wv,
+                                        (double*)L, (double*)LA, info, want_grad, (double*)dX, (double*)dY, (double*)dZ, (double*)dnoise,
+                                        (double*)dls, (double*)dvar, st);
+    MXF_FAIL(h, -2, "mxf_sgp_logpdf: bad dtype %d", dtype);
 }

@@ -55,3 +55,24 @@ class SVGPLogPdfFn(torch.autograd.Function):
         for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:]):
             out.append((grad.reshape(shp) * c) if need else None)
         return (None, None, None, None) + tuple(out)
+
+
+class SGPLogPdfFn(torch.autograd.Function):
+    """mxf_sgp_logpdf for ONE sample (arrays carry a unit sample axis); returns logL (1,), wv, L, LA."""
+
+    @staticmethod
+    def forward(ctx, kind, ard, jitter, X, Y, Z, noise, ls, var):
+        want = any(ctx.needs_input_grad[3:])
+        r = ops.sgp_logpdf(kind, X[0], Y[0], Z[0], noise.reshape(-1), ls.reshape(-1), var.reshape(-1), ard, jitter=jitter, gscale=1.0,
+                           want_grad=want)
+        if want:
+            ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dls'], r['dvar'])
+            ctx.shapes = tuple(t.shape for t in (X, Y, Z, noise, ls, var))
+        ctx.mark_non_differentiable(r['wv'], r['L'], r['LA'], r['info'])
+        return r['logL'], r['wv'], r['L'], r['LA'], r['info']
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        c = g.sum()
+        out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[3:])]
+        return (None, None, None) + tuple(out)

@@ -1,0 +1,160 @@
+"""SparseGPRegression (Titsias) module and its algorithms (mxfusion/modules/gp_modules/sparsegp_regression.py:32-430).
+
+  SparseGPRegressionLogPdf.compute                 -> mxf_sgp_logpdf (streaming Psi2 / psi1 statistics, C = Kuu + Psi2/s2, closed-form reverse mode)
+  SparseGPRegressionMeanVariancePrediction.compute -> mxf_gram + mxf_trsm + mxf_gemm + mxf_coldot
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...components.variables.variable import Variable
+from ...inference.inference_alg import SamplingAlgorithm
+from ...inference.variational import VariationalInference
+from ..module import Module, ModuleGraph
+from ._fused import SGPLogPdfFn
+
+
+class SparseGPRegressionLogPdf(VariationalInference):
+    """sparsegp_regression.py:32-108."""
+
+    def __init__(self, model, posterior, observed, jitter=0.):
+        super(SparseGPRegressionLogPdf, self).__init__(model=model, posterior=posterior, observed=observed)
+        self.log_pdf_scaling = 1          # set but never used by the reference either
+        self.jitter = jitter
+
+    def compute(self, F, variables):
+        X = variables[self.model.X]
+        Y = variables[self.model.Y]
+        Z = variables[self.model.inducing_inputs]
+        noise_var = variables[self.model.noise_var]
+        kern = self.model.kernel
+        kern_params = kern.fetch_parameters(variables)
+        spec = kern.fused_spec()
+        if spec is None:
+            raise NotImplementedError('SparseGPRegressionLogPdf on MI355X supports a single stationary kernel')
+        kind, ard = spec
+        ls = kern_params[kern.name + '_lengthscale']
+        var = kern_params[kern.name + '_variance']
+        if self.model.F.factor.has_mean:
+            Y = Y - variables[self.model.mean]
+        args = (X, Y, Z, noise_var, ls, var)
+        S = max(t.shape[0] for t in args)
+        pick = lambda t, s: t[s:s + 1] if t.shape[0] > 1 else t
+        outs = [SGPLogPdfFn.apply(kind, ard, float(self.jitter), *[pick(t, s) for t in args]) for s in range(S)]
+        logL = torch.cat([o[0] for o in outs])
+        with torch.no_grad():      # :99-106 persist sample 0 only
+            self.set_parameter(variables, self.graphs[1].wv, outs[0][1])
+            self.set_parameter(variables, self.graphs[1].L, outs[0][2])
+            self.set_parameter(variables, self.graphs[1].LA, outs[0][3])
+        return logL
+
+
+class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
+    """sparsegp_regression.py:111-174."""
+
+    def __init__(self, model, posterior, observed, target_variables=None, noise_free=True, diagonal_variance=True):
+        super(SparseGPRegressionMeanVariancePrediction, self).__init__(model=model, observed=observed, extra_graphs=[posterior],
+                                                                       target_variables=target_variables)
+        self.noise_free = noise_free
+        self.diagonal_variance = diagonal_variance
+
+    def compute(self, F, variables):
+        with torch.no_grad():
+            X = variables[self.model.X]
+            N = X.shape[-2]
+            Z = variables[self.model.inducing_inputs]
+            noise_var = variables[self.model.noise_var]
+            L = variables[self.graphs[1].L]
+            LA = variables[self.graphs[1].LA]
+            wv = variables[self.graphs[1].wv]
+            kern = self.model.kernel
+            kern_params = kern.fetch_parameters(variables)
+            Kxt = kern.K(F, Z, X, **kern_params)
+            mu = ops.gemm(Kxt, wv, transA=True)
+            if self.model.F.factor.has_mean:
+                mu = mu + variables[self.model.mean]
+            LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())
+            LAinvLinvKxt = ops.trsm_(LA, LinvKxt.clone())
+            if self.diagonal_variance:
+                var = kern.Kdiag(F, X, **kern_params) - ops.coldot(LinvKxt, LinvKxt) + ops.coldot(LAinvLinvKxt, LAinvLinvKxt)
+                if not self.noise_free:
+                    var = var + noise_var
+            else:
+                Ktt = kern.K(F, X, **kern_params).contiguous().clone()
+                var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt)
+                var = ops.gemm(LAinvLinvKxt, LAinvLinvKxt, transA=True, alpha=1.0, beta=1.0, out=var)
+                if not self.noise_free:
+                    var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+        outcomes = {self.model.Y.uuid: (mu, var)}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
+class SparseGPRegression(Module):
+    """sparsegp_regression.py:258-430."""
+
+    def __init__(self, X, kernel, noise_var, inducing_inputs=None, num_inducing=10, mean=None, rand_gen=None, dtype=None, ctx=None):
+        if not isinstance(X, Variable):
+            X = Variable(value=X)
+        if not isinstance(noise_var, Variable):
+            noise_var = Variable(value=noise_var)
+        if inducing_inputs is None:
+            inducing_inputs = Variable(shape=(num_inducing, kernel.input_dim), initial_value=np.random.randn(num_inducing, kernel.input_dim))
+        inputs = [('X', X), ('inducing_inputs', inducing_inputs), ('noise_var', noise_var)]
+        if mean is not None:
+            inputs.append(('mean', mean))
+        self._has_mean = mean is not None
+        object.__setattr__(self, 'kernel', kernel)
+        super(SparseGPRegression, self).__init__(inputs=inputs, outputs=None, input_names=[k for k, _ in inputs],
+                                                 output_names=['random_variable'], rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+
+    def _generate_outputs(self, output_shapes=None):
+        shape = output_shapes['random_variable']
+        self.set_outputs([Variable(shape=tuple(self.X.shape[:-1]) + (1,) if shape is None else shape)])
+
+    def _build_module_graphs(self):
+        Y = self.random_variable
+        graph = ModuleGraph(name='sparsegp_regression')
+        graph.X = self.X
+        graph.inducing_inputs = self.inducing_inputs
+        M = self.inducing_inputs.shape[0]
+        graph.noise_var = self.noise_var
+        if self._has_mean:
+            graph.mean = self.mean
+        graph.F = SimpleNamespace(factor=SimpleNamespace(has_mean=self._has_mean, dtype=self.dtype, kernel=self.kernel))
+        graph.Y = Y
+        graph.kernel = self.kernel
+        for n, v in self.kernel.parameters.items():
+            setattr(graph, n, v)
+        post = ModuleGraph(name='sparsegp_posterior')       # what prediction needs (:353-357)
+        post.L = Variable(shape=(M, M))
+        post.LA = Variable(shape=(M, M))
+        post.wv = Variable(shape=(M, Y.shape[-1]))
+        for v in (post.L, post.LA, post.wv):
+            v.is_posterior_cache = True
+        return graph, [post]
+
+    def _attach_default_inference_algorithms(self):
+        observed = [v for _, v in self.inputs] + [v for _, v in self.outputs]
+        self.attach_log_pdf_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                       algorithm=SparseGPRegressionLogPdf(self._module_graph, self._extra_graphs[0], observed),
+                                       alg_name='sgp_log_pdf')
+        observed = [v for _, v in self.inputs]
+        self.attach_prediction_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                          algorithm=SparseGPRegressionMeanVariancePrediction(self._module_graph, self._extra_graphs[0], observed),
+                                          alg_name='sgp_predict')
+
+    @staticmethod
+    def define_variable(X, kernel, noise_var, shape=None, inducing_inputs=None, num_inducing=10, mean=None, rand_gen=None,
+                        dtype=None, ctx=None):
+        gp = SparseGPRegression(X=X, kernel=kernel, noise_var=noise_var, inducing_inputs=inducing_inputs, num_inducing=num_inducing,
+                                mean=mean, rand_gen=rand_gen, dtype=dtype, ctx=ctx)
+        gp._generate_outputs({'random_variable': shape})
+        return gp.random_variable
+
+    @property
+    def random_variable(self):
+        return self._outputs[0][1]

@@ -235,3 +235,22 @@ def coldot(A, B):
     out = torch.empty((S, N), dtype=A.dtype, device=A.device)
     _lib.call('mxf_coldot', _h(A), _dt(A), S, M, N, _p(A), A.stride(-2), _ss(A), _p(B), B.stride(-2), _ss(B), _p(out), _stream())
     return out
+
+
+def sgp_logpdf(kind, X, Y, Z, noise_var, lengthscale, variance, ard, jitter=0.0, gscale=1.0, want_grad=False):
+    """SparseGPRegressionLogPdf.compute (sparsegp_regression.py:42-108) for ONE sample: X (B,Q), Y (B,P), Z (M,Q), noise_var (1,),
+    lengthscale (Q|1,), variance (1,).  Returns dict(logL (1,), wv (M,P), L (M,M), LA (M,M), info, gradients...)."""
+    X, Y, Z, noise_var, lengthscale, variance = [_c(t) for t in (X, Y, Z, noise_var, lengthscale, variance)]
+    B, Q, P, M = X.shape[-2], X.shape[-1], Y.shape[-1], Z.shape[-2]
+    dev, dt = X.device, X.dtype
+    E = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
+    out = {'logL': E(1), 'wv': E(M, P), 'L': E(M, M), 'LA': E(M, M), 'info': torch.zeros(1, dtype=torch.int32, device=dev)}
+    g = {}
+    if want_grad:
+        g = {'dX': E(B, Q), 'dY': E(B, P), 'dZ': E(M, Q), 'dnoise': E(1), 'dls': E(lengthscale.numel()), 'dvar': E(1)}
+    _lib.call('mxf_sgp_logpdf', _h(X), KIND[kind], _dt(X), B, M, Q, P, _p(X), _p(Y), _p(Z), _p(noise_var), _p(lengthscale),
+              int(bool(ard)), _p(variance), float(jitter), float(gscale), _p(out['logL']), _p(out['wv']), _p(out['L']), _p(out['LA']),
+              _p(out['info']), int(want_grad), _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dZ')), _p(g.get('dnoise')), _p(g.get('dls')),
+              _p(g.get('dvar')), _stream())
+    out.update(g)
+    return out

@@ -1,0 +1,83 @@
+"""GPU parity of the sparse (Titsias) GP path (row a13): C-ABI composite and the SparseGPRegression module vs the oracle /
+golden fixture built from testing/modules/sparsegpregression_test.py:38-47,58 (reference asserts the value vs GPy at :99)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _t(a, dtype=torch.float64):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+def test_sgp_composite_golden(golden_dir):
+    from mxfusion_amd import ops
+    g = np.load(os.path.join(golden_dir, 'kat_sgp.npz'))
+    r = ops.sgp_logpdf('rbf', _t(g['X']), _t(g['Y']), _t(g['Z']), _t(g['noise']), _t(g['ls']), _t(g['var']), True, jitter=1e-8, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    assert abs(float(r['logL'][0]) - (-20.731336414403)) < 1e-8
+    for k in ('wv', 'L', 'LA'):
+        assert np.allclose(r[k].cpu().numpy(), g[k], atol=1e-8), k
+    for n, k in (('dX', 'd_X'), ('dY', 'd_Y'), ('dZ', 'd_Z'), ('dnoise', 'd_noise'), ('dls', 'd_ls'), ('dvar', 'd_var')):
+        assert np.allclose(r[n].cpu().numpy().reshape(g[k].shape), g[k], rtol=1e-8, atol=1e-8 * max(1, np.abs(g[k]).max())), n
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 2e-5)])
+@pytest.mark.parametrize('kind', ['rbf', 'matern32'])
+def test_sgp_composite_vs_oracle(dtype, tol, kind):
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(3)
+    B, M, Q, P = 700, 90, 5, 2
+    X = rng.uniform(-2, 2, (B, Q))
+    Y = np.sin(X @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    ls = rng.rand(Q) * 0.5 + (1.0 if dtype == torch.float64 else 0.3)
+    var, noise = np.array([1.3]), np.array([0.05])
+    k = {'rbf': O.RBF, 'matern32': O.Matern32}[kind](Q, ARD=True)
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=X, Y=Y, Z=Z, noise=noise, ls=ls, var=var).items()}
+    ref = O.sgp_log_pdf(k, lv['X'][None], lv['Y'][None], lv['Z'][None], lv['noise'][None],
+                        {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-6)[0]
+    grads = torch.autograd.grad(ref, [lv[n] for n in ('X', 'Y', 'Z', 'noise', 'ls', 'var')])
+    r = ops.sgp_logpdf(kind, _t(X, dtype), _t(Y, dtype), _t(Z, dtype), _t(noise, dtype), _t(ls, dtype), _t(var, dtype), True, jitter=1e-6,
+                       want_grad=True)
+    assert abs(float(r['logL'][0]) - float(ref)) <= tol * abs(float(ref))
+    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    for key, gr in zip(('dX', 'dY', 'dZ', 'dnoise', 'dls', 'dvar'), grads):
+        a, b = r[key].cpu().numpy().reshape(gr.shape), gr.numpy()
+        assert np.allclose(a, b, rtol=gtol, atol=gtol * max(1., np.abs(b).max())), key
+
+
+def test_sgp_module_like_reference_tests(golden_dir):
+    """testing/modules/sparsegpregression_test.py:80-99 (test_log_pdf) and :137-196 (test_prediction)."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SparseGPRegression
+    from mxfusion_amd.inference import Inference, MAP, TransferInference, ModulePredictionAlgorithm
+    g = np.load(os.path.join(golden_dir, 'kat_sgp.npz'))
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 3))
+    m.Z = Variable(shape=(3, 3), initial_value=_t(g['Z']))
+    m.noise_var = Variable(transformation=PositiveTransformation(), initial_value=_t(g['noise']))
+    kernel = RBF(input_dim=3, ARD=True, variance=_t(g['var']), lengthscale=_t(g['ls']), dtype='float64')
+    m.Y = SparseGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 2), dtype='float64')
+    m.Y.factor.sgp_log_pdf.jitter = 1e-8
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype='float64')
+    loss, _ = infr.run(X=_t(g['X']), Y=_t(g['Y']))
+    assert abs(float(-loss) - (-20.731336414403)) < 1e-8
+    gp = m.Y.factor
+    for nf in (True, False):
+        for dg in (True, False):
+            infr2 = TransferInference(ModulePredictionAlgorithm(m, observed=[m.X], target_variables=[m.Y]), infr_params=infr.params, dtype='float64')
+            gp.sgp_predict.noise_free = nf
+            gp.sgp_predict.diagonal_variance = dg
+            res = infr2.run(X=_t(g['Xt']))[0]
+            tag = ('nf' if nf else 'noisy') + ('_diag' if dg else '_full')
+            assert np.allclose(res[0].cpu().numpy(), g['mu_' + tag], atol=1e-8), tag
+            assert np.allclose(res[1].cpu().numpy(), g['var_' + tag], atol=1e-8), tag
