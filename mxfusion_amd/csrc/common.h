@@ -12,7 +12,8 @@ struct mxf_ctx {
     std::string err;
     void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)
     size_t ws_bytes = 0;
-    hipStream_t side = nullptr;   // internal side stream: independent chains of the (M x M) core run concurrently
+    hipStream_t side = nullptr;   // internal side streams: independent chains of the SVGP step run concurrently
+    hipStream_t side2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
@@ -61,6 +62,8 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
 static inline bool mxf_side_init(mxf_ctx* h) {
     if (h->side) return true;
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
+    // (a CU-masked side2 via hipExtStreamCreateWithCUMask was measured: 83 -> 114 ms per step; plain stream kept)
+    if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) { h->side2 = nullptr; return false; }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess) return false;

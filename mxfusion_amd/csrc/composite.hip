@@ -374,6 +374,21 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // side chain
     rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);              // Kuf_all = k(Z, X_all) :73
     if (rc) return rc;
+    if (want_grad) {
+        // Psi2 = Kuf Kuf^T depends on neither the core nor the T-GEMM nor the reverse pass: it gets its own stream and starts at once.
+        // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM (sequential operand streams;
+        // the NT form on Kuf reads 256 K-strided streams per workgroup).  Its waves saturate the register file, so 16 CUs are left
+        // without a Psi2 workgroup for the latency-bound core chains that run meanwhile.
+        hipStream_t s2_ = h->side2;
+        rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
+        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_join2, 0));
+        rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, 16);   // lower blocks only, split-K
+        if (rc) return rc;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
+        MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
+    }
     hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, M, (const D*)sd, Su);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, sd_);       // Su = W W^T + diag(s) :76
     if (rc) return rc;
@@ -389,17 +404,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
-    if (want_grad) {
-        // Psi2 = Kuf Kuf^T depends on neither the T-GEMM nor the reverse pass: it runs on the side stream, concurrently with them.
-        // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM, which streams both operands
-        // sequentially; the NT form on Kuf reads 256 K-strided (8 MB apart) streams per workgroup (measured 33 ms vs 29 ms).
-        rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
-        if (rc) return rc;
-        rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, sd_);   // lower blocks only, split-K
-        if (rc) return rc;
-        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
-        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
-    }
     // main chain
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
     if (rc) return rc;

@@ -14,6 +14,7 @@
 //   C/D f64 16x16: col = l&15, row = (l>>4) + 4*r, r in [0,4)
 #include "common.h"
 #include "internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -301,7 +302,7 @@ __global__ void scale_kernel(T* C, int64_t M, int64_t N, int64_t ldc, int64_t sC
 template <typename T>
 int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
                int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta, void* C, int64_t ldc, int64_t sC,
-               int batch, int lower_only, hipStream_t st) {
+               int batch, int lower_only, hipStream_t st, int reserve_cus) {
     GemmArgs<T> g;
     g.A = (const T*)A; g.B = (const T*)B; g.C = (T*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
@@ -313,13 +314,14 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     }
     const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     // split K when the output grid cannot fill 256 CUs and K is long
-    int64_t tiles = tm * tn * batch;
-    if (lower_only) tiles = (tiles + 1) / 2;
+    const int64_t tiles = (lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;   // EXACT count (an estimate of 32 for 36 tiles cost 35 %)
     // split K when the output grid cannot fill the chip.  Resident slots: 256 CUs x (2 workgroups f32 | 1 f64); pick the
     // split so that the grid is (just under) a whole number of rounds -- 576 workgroups on 512 slots would run a
     // half-empty second round (measured: Psi2 33 ms -> 19 ms with 504).
     int splitk = 1;
-    const int64_t slots = 256 * (sizeof(T) == 4 ? 2 : 1);
+    // reserve_cus: leave that many CUs without a workgroup of this (register-saturating) kernel, so that latency-bound
+    // kernels of a concurrent stream can still be scheduled (the split-K grid is sized to the remaining CUs)
+    const int64_t slots = (256 - reserve_cus) * (sizeof(T) == 4 ? 2 : 1);
     if (tiles < slots && K >= 256) {
         const int64_t maxsplit = K / 128 > 0 ? K / 128 : 1;     // small latency-bound GEMMs of the (M x M) core split too
         int64_t sk = slots / tiles;
@@ -327,6 +329,10 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         if (sk > maxsplit) sk = maxsplit;
         if (sk < 1) sk = 1;
         splitk = (int)sk;
+    }
+    {   // probe knob (A/B experiments only)
+        static const int sk_env = getenv("MXF_GEMM_SPLITK") ? atoi(getenv("MXF_GEMM_SPLITK")) : 0;
+        if (sk_env > 0 && K >= 4096) splitk = sk_env;
     }
     int64_t kchunk = (K + splitk - 1) / splitk;
     kchunk = (kchunk + BK - 1) / BK * BK;
@@ -356,10 +362,10 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
 
 int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
-                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st) {
+                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    if (dtype == MXF_F32) return gemm_typed<float>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st);
-    if (dtype == MXF_F64) return gemm_typed<double>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st);
+    if (dtype == MXF_F32) return gemm_typed<float>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus);
+    if (dtype == MXF_F64) return gemm_typed<double>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus);
     MXF_FAIL(h, -2, "mxf_gemm: bad dtype %d", dtype);
 }
 
@@ -370,6 +376,7 @@ extern "C" int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t
     if (!h) return -1;
     if (M < 0 || N < 0 || K < 0 || batch < 0) MXF_FAIL(h, -2, "mxf_gemm: negative dimension");
     if ((M > 0 && N > 0 && batch > 0) && (!A || !B || !C) && K > 0) MXF_FAIL(h, -2, "mxf_gemm: null operand");
+    static const int lower_env = getenv("MXF_GEMM_LOWER") ? atoi(getenv("MXF_GEMM_LOWER")) : 0;   // probe knob
     return mxf_gemm_internal(h, dtype, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc,
-                             strideC, batch, 0, (hipStream_t)stream);
+                             strideC, batch, (lower_env && M == N) ? 1 : 0, (hipStream_t)stream);
 }

@@ -130,7 +130,16 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
             }
             __syncthreads();
             const int rmax = (int)((rend - rt) < TRB ? (rend - rt) : TRB);
-            for (int r = 0; r < rmax; ++r) {
+            constexpr int UNR = 4;                 // rows of dK / T fetched ahead of their use (hides the HBM latency of the row loads)
+            for (int r0_ = 0; r0_ < rmax; r0_ += UNR) {
+              T pre[UNR];
+#pragma unroll
+              for (int u = 0; u < UNR; ++u)
+                  pre[u] = (cvalid && r0_ + u < rmax) ? dK[(rt + r0_ + u) * a.lddk + col] : (T)0;
+#pragma unroll
+              for (int u = 0; u < UNR; ++u) {
+                const int r = r0_ + u;
+                if (r >= rmax) break;
                 const int64_t row = rt + r;
                 T d[QT], r2 = 0;
 #pragma unroll
@@ -139,14 +148,14 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                 cov_and_slope<T, KIND>(r2, k, w);
                 T g;
                 if (FUSED) {
-                    const T t_in = cvalid ? dK[row * a.lddk + col] : (T)0;
+                    const T t_in = pre[u];
                     T we = 0;
 #pragma unroll
                     for (int p = 0; p < PMAX; ++p) if (p < P) we = fma(wsm[r * PMAX + p], e[p], we);
                     qn = fma(k * variance, t_in, qn);
                     g = c1 * ((T)P * t_in + we);
                 } else {
-                    g = cvalid ? dK[row * a.lddk + col] : (T)0;
+                    g = pre[u];
                 }
                 gvar = fma(g, k, gvar);
                 const T W2 = (T)2 * g * w * variance;   // 2 dL/d(r2)
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                         }
                     }
                 }
+              }
             }
         }
         // column side: stored once when this block owns the whole column; both roles flow into dX in the square case

@@ -33,7 +33,7 @@ class BatchInferenceLoop(GradLoop):
         for i in range(max_iter):
             loss = self.step(infr_executor, data, param_dict)
             if verbose:
-                print('\rIteration {} loss: {}\t\t\t\t'.format(i + 1, float(loss)), end='')
+                print('\rIteration {} loss: {}\t\t\t\t'.format(i + 1, float(loss.detach())), end='')
                 if ((i + 1) % iter_step == 0 and i > 0) or i == max_iter - 1:
                     print()
             trainer.step(batch_size=1)

@@ -32,9 +32,9 @@ class MinibatchInferenceLoop(GradLoop):
                 loss, loss_for_gradient = infr_executor(*batch)
                 loss_for_gradient.backward()
                 if verbose:
-                    print('\repoch {} Iteration {} loss: {}\t\t\t'.format(e + 1, i + 1, float(loss)), end='')
+                    print('\repoch {} Iteration {} loss: {}\t\t\t'.format(e + 1, i + 1, float(loss.detach())), end='')
                 trainer.step(batch_size=B)
-                L_e += float(loss)
+                L_e += float(loss.detach())
                 n_batches += 1
             carry = idx[n_full * B:]
             if verbose and n_batches:

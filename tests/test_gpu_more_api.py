@@ -1,0 +1,147 @@
+"""GPU parity of the remaining algorithm classes: prior / predictive sampling with injected noise (a9, a12), combination
+kernels through the generic Cholesky path (a6 + a7), the minibatch loop with rv_scaling (a20)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+DT = 'float64'
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64).cuda()
+
+
+def _gp_model(g, kernel=None, rand_gen=None):
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 3))
+    m.noise_var = Variable(transformation=PositiveTransformation(), initial_value=_t(g['noise']))
+    kernel = kernel or RBF(input_dim=3, ARD=True, variance=_t(g['var']), lengthscale=_t(g['ls']), dtype=DT)
+    m.Y = GPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, shape=(m.N, 2), dtype=DT, rand_gen=rand_gen)
+    return m
+
+
+def test_gp_prior_and_predictive_sampling_with_injected_noise(golden_dir):
+    """testing/modules/gpregression_test.py:131-168 (test_draw_samples) and :256-307 (sampling prediction)."""
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.inference import Inference, MAP, ForwardSamplingAlgorithm, TransferInference, ModulePredictionAlgorithm
+    from mxfusion_amd.modules.gp_modules.gp_regression import GPRegressionSamplingPrediction
+    g = np.load(os.path.join(golden_dir, 'kat_gp.npz'))
+    k = O.RBF(3, ARD=True)
+    kp = {'rbf_lengthscale': O.T(g['ls'])[None], 'rbf_variance': O.T(g['var'])[None]}
+    rng = np.random.RandomState(5)
+    eps = rng.randn(2, 10, 2)
+    m = _gp_model(g, rand_gen=MockRandomGenerator(_t(eps)))
+    infr = Inference(ForwardSamplingAlgorithm(m, [m.X], num_samples=2, target_variables=[m.Y]), dtype=DT)
+    samples = infr.run(X=_t(g['X']))[0]
+    ref = O.gp_sample_prior(k, O.T(g['X'])[None], O.T(g['noise'])[None], kp, O.T(eps))
+    assert np.allclose(samples.cpu().numpy(), ref.numpy(), atol=1e-10)
+    # predictive sampling: swap the prediction algorithm through the registry (gp_regression.ipynb cell 24)
+    m = _gp_model(g)
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(g['X']), Y=_t(g['Y']))
+    post = O.gp_log_pdf(k, O.T(g['X'])[None], O.T(g['Y'])[None], O.T(g['noise'])[None], kp, return_posterior=True)[1]
+    gp = m.Y.factor
+    for dg, jit in ((True, 0.), (False, 1e-8)):
+        eps2 = rng.randn(3, 20, 2)
+        alg = GPRegressionSamplingPrediction(gp._module_graph, gp._extra_graphs[0], [gp._module_graph.X], rand_gen=MockRandomGenerator(_t(eps2)),
+                                             diagonal_variance=dg, jitter=jit)
+        gp.attach_prediction_algorithms(targets=gp.output_names, conditionals=gp.input_names, algorithm=alg, alg_name='gp_predict')
+        infr2 = TransferInference(ModulePredictionAlgorithm(model=m, observed=[m.X], target_variables=[m.Y], num_samples=3),
+                                  infr_params=infr.params, dtype=DT)
+        ys = infr2.run(X=_t(g['Xt']))[0]
+        ref = O.gp_predict_sample(k, O.T(g['Xt'])[None], O.T(g['noise'])[None], post[0][None], post[1][None], post[2][None], kp, O.T(eps2),
+                                  diagonal_variance=dg, jitter=jit)
+        assert np.allclose(ys.cpu().numpy(), ref.numpy(), atol=1e-8), dg
+
+
+def test_combination_kernel_gp_logpdf_and_gradients():
+    """AddKernel(Matern52, RBF) (add_kernel.py:44-68, the deep-GP config's kernel) through the generic path: HIP Gram per sub-kernel
+    (autograd via mxf_gram_bwd) + mxf_potrf/trsm/trtri with the closed-form dK."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop
+    rng = np.random.RandomState(0)
+    N, Q = 60, 4
+    X, Y = rng.uniform(-2, 2, (N, Q)), rng.randn(N, 1)
+    ls1, ls2, v1, v2, noise = np.array([1.3]), np.array([0.7]), np.array([0.9]), np.array([0.4]), np.array([0.2])
+    kern = Matern52(Q, variance=_t(v1), lengthscale=_t(ls1), dtype=DT) + RBF(Q, variance=_t(v2), lengthscale=_t(ls2), dtype=DT)
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(noise))
+    m.Y = GPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, shape=(m.N, 1), dtype=DT)
+    grads = []
+
+    class Rec(BatchInferenceLoop):
+        def _exchange(self, param_dict):
+            grads.append(param_dict.flat.grad.clone())
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=Rec(), dtype=DT)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=0.01)
+    ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
+    raw = {n: O.inv_softplus(O.T(v)).clone().requires_grad_(True) for n, v in dict(ls1=ls1, ls2=ls2, v1=v1, v2=v2, noise=noise).items()}
+    sp = O.softplus
+    logL = O.gp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], sp(raw['noise'])[None],
+                        {'add_matern52_lengthscale': sp(raw['ls1'])[None], 'add_matern52_variance': sp(raw['v1'])[None],
+                         'add_rbf_lengthscale': sp(raw['ls2'])[None], 'add_rbf_variance': sp(raw['v2'])[None]})
+    (-logL.sum()).backward()
+    P = infr.params
+    sub = {k.name: k for k in kern.sub_kernels}
+    for var, name in ((m.noise_var, 'noise'), (sub['matern52'].lengthscale, 'ls1'), (sub['matern52'].variance, 'v1'),
+                      (sub['rbf'].lengthscale, 'ls2'), (sub['rbf'].variance, 'v2')):
+        o, n, _ = P._slices[var.uuid]
+        assert np.allclose(grads[0][o:o + n].cpu().numpy(), raw[name].grad.numpy(), rtol=1e-8, atol=1e-9), name
+
+
+def test_minibatch_loop_with_rv_scaling_runs_and_scales(golden_dir):
+    """inference/minibatch_loop.py + rv_scaling -> SVGPRegressionLogPdf.log_pdf_scaling (svgp_regression.py:108); first minibatch loss vs oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, MinibatchInferenceLoop
+    rng = np.random.RandomState(1)
+    N, Q, M, Bsz = 64, 2, 8, 16
+    X, Y, Z = rng.uniform(-2, 2, (N, Q)), rng.randn(N, 1), rng.uniform(-2, 2, (M, Q))
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=_t(Z))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.1)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=RBF(Q, ARD=True, dtype=DT), noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=DT)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    seen = []
+
+    class Loop(MinibatchInferenceLoop):
+        def run(self, infr_executor, data, **kw):
+            def wrapped(*a):
+                out = infr_executor(*a)
+                seen.append((a[0].detach().clone(), a[1].detach().clone(), float(out[0].detach())))
+                return out
+            return super(Loop, self).run(wrapped, data, **kw)
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=Loop(batch_size=Bsz, rv_scaling={m.Y: N / Bsz}), dtype=DT)
+    infr.initialize(X=(N, Q), Y=(N, 1))
+    post = gp._extra_graphs[0]
+    qm, qW, qd = rng.randn(M, 1) * 0.1, rng.randn(M, M) * 0.05, rng.rand(M) + 0.5
+    infr.params[post.qU_mean], infr.params[post.qU_cov_W], infr.params[post.qU_cov_diag] = _t(qm), _t(qW), _t(qd)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=1e-3)
+    assert len(seen) == N // Bsz and gp.svgp_log_pdf.log_pdf_scaling == N / Bsz
+    xb, yb, loss0 = seen[0]
+    k = O.RBF(Q, ARD=True)
+    ref = O.svgp_log_pdf(k, O.T(xb.cpu().numpy())[None], O.T(yb.cpu().numpy())[None], O.T(Z)[None], O.T([[0.1]]), O.T(qm)[None], O.T(qW)[None],
+                         O.T(qd)[None], {'rbf_lengthscale': O.T(np.ones((1, Q))), 'rbf_variance': O.T([[1.0]])}, jitter=1e-6,
+                         log_pdf_scaling=N / Bsz)
+    assert abs(loss0 - float(-ref[0])) < 1e-8 * abs(float(ref[0]))
