@@ -96,6 +96,103 @@ __global__ __launch_bounds__(128) void solve_rows_kernel(T* __restrict__ A, int6
     }
 }
 
+// ---- fused panel step: every workgroup re-factors the 64x64 diagonal block in LDS (rank-4 blocked: 16 barrier pairs instead of
+// 64) and then solves its own 128 rows against it; workgroup 0 owns the diagonal block itself.  One launch per 64-wide block column
+// instead of two (diag + solve), and no dependent launch gap between them.
+template <typename T>
+__global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int64_t lda, int64_t sA, int64_t k0, int nb, int64_t n,
+                                                           int* __restrict__ info) {
+    __shared__ T a[NB][NB + 1];
+    __shared__ T lc[4][NB];
+    __shared__ T t[128][NB + 1];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    T* Ab = A + (int64_t)b * sA;
+    T* D = Ab + k0 * lda + k0;
+    for (int e = tid; e < NB * NB; e += 128) {
+        const int i = e / NB, c = e % NB;
+        T v = (T)0;
+        if (i < nb && c < nb) { if (c <= i) v = D[(int64_t)i * lda + c]; }
+        else if (i == c) v = (T)1;          // identity padding of a ragged last block
+        a[i][c] = v;
+    }
+    __syncthreads();
+    for (int jb = 0; jb < NB; jb += 4) {
+        if (tid < NB && tid >= jb) {
+            // 4x4 Cholesky of the current diagonal sub-block, redundantly in every participating thread
+            T L00, L10, L11, L20, L21, L22, L30, L31, L32, L33;
+            int bad = -1;
+            T d = a[jb][jb];                                          if (!(d > (T)0)) { if (bad < 0) bad = 0; d = (T)1; }
+            L00 = sqrt(d); const T i0 = (T)1 / L00;
+            L10 = a[jb + 1][jb] * i0; L20 = a[jb + 2][jb] * i0; L30 = a[jb + 3][jb] * i0;
+            d = a[jb + 1][jb + 1] - L10 * L10;                        if (!(d > (T)0)) { if (bad < 0) bad = 1; d = (T)1; }
+            L11 = sqrt(d); const T i1 = (T)1 / L11;
+            L21 = (a[jb + 2][jb + 1] - L20 * L10) * i1; L31 = (a[jb + 3][jb + 1] - L30 * L10) * i1;
+            d = a[jb + 2][jb + 2] - L20 * L20 - L21 * L21;            if (!(d > (T)0)) { if (bad < 0) bad = 2; d = (T)1; }
+            L22 = sqrt(d); const T i2 = (T)1 / L22;
+            L32 = (a[jb + 3][jb + 2] - L30 * L20 - L31 * L21) * i2;
+            d = a[jb + 3][jb + 3] - L30 * L30 - L31 * L31 - L32 * L32; if (!(d > (T)0)) { if (bad < 0) bad = 3; d = (T)1; }
+            L33 = sqrt(d); const T i3 = (T)1 / L33;
+            if (bad >= 0 && tid == jb && blockIdx.x == 0 && jb + bad < nb && info && info[b] == 0) info[b] = (int)(k0 + jb + bad + 1);
+            const int r = tid - jb;                                   // position relative to the sub-block
+            T l0, l1, l2, l3;
+            if (r == 0) { l0 = L00; l1 = 0; l2 = 0; l3 = 0; }
+            else if (r == 1) { l0 = L10; l1 = L11; l2 = 0; l3 = 0; }
+            else if (r == 2) { l0 = L20; l1 = L21; l2 = L22; l3 = 0; }
+            else if (r == 3) { l0 = L30; l1 = L31; l2 = L32; l3 = L33; }
+            else {
+                l0 = a[tid][jb] * i0;
+                l1 = (a[tid][jb + 1] - l0 * L10) * i1;
+                l2 = (a[tid][jb + 2] - l0 * L20 - l1 * L21) * i2;
+                l3 = (a[tid][jb + 3] - l0 * L30 - l1 * L31 - l2 * L32) * i3;
+            }
+            lc[0][tid] = l0; lc[1][tid] = l1; lc[2][tid] = l2; lc[3][tid] = l3;
+        }
+        __syncthreads();
+        if (tid < NB && tid >= jb) { a[tid][jb] = lc[0][tid]; a[tid][jb + 1] = lc[1][tid]; a[tid][jb + 2] = lc[2][tid]; a[tid][jb + 3] = lc[3][tid]; }
+        {   // rank-4 trailing update of the lower triangle
+            const int c = jb + 4 + (tid & 63);
+            if (c < NB) {
+                const T c0 = lc[0][c], c1 = lc[1][c], c2 = lc[2][c], c3 = lc[3][c];
+                for (int i = c + (tid >> 6); i < NB; i += 2)
+                    a[i][c] -= lc[0][i] * c0 + lc[1][i] * c1 + lc[2][i] * c2 + lc[3][i] * c3;
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < nb * nb; e += 128) {
+            const int i = e / nb, c = e % nb;
+            D[(int64_t)i * lda + c] = (c <= i) ? a[i][c] : (T)0;     // MXNet potrf zeroes the strict upper part
+        }
+        return;
+    }
+    // rows below: X L11^T = A21, one row per lane
+    const int64_t r0 = k0 + nb, nrows = n - r0;
+    const int64_t rb = r0 + (int64_t)(blockIdx.x - 1) * 128;
+    for (int e = tid; e < 128 * NB; e += 128) {
+        const int r = e / NB, c = e % NB;
+        t[r][c] = (rb + r < r0 + nrows && c < nb) ? Ab[(rb + r) * lda + k0 + c] : (T)0;
+    }
+    __syncthreads();
+    T x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        T sacc = t[tid][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sacc = fma(-x[k], a[j][k], sacc);
+        x[j] = sacc / a[j][j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) t[tid][j] = x[j];
+    __syncthreads();
+    for (int e = tid; e < 128 * NB; e += 128) {
+        const int r = e / NB, c = e % NB;
+        if (rb + r < r0 + nrows && c < nb) Ab[(rb + r) * lda + k0 + c] = t[r][c];
+    }
+}
+
 // ---- op(L_kk) X = B_k (X overwrites B_k): one right-hand-side column per lane ------------------------------
 // TRANS: solve L_kk^T X = B_k by index reversal (P L^T P is lower triangular)
 template <typename T, bool TRANS>
@@ -148,6 +245,38 @@ __global__ __launch_bounds__(256) void solve_cols_kernel(const T* __restrict__ L
     }
 }
 
+// ---- inverse of every 64x64 diagonal block of L in ONE launch (one workgroup per block, one column of the inverse per lane) ----
+template <typename T>
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L, int64_t ldl, int64_t sL, T* __restrict__ Li, int64_t ldi,
+                                                        int64_t sI, int64_t n) {
+    __shared__ T l[NB][NB + 1];
+    __shared__ T x[NB][NB + 1];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int64_t k0 = (int64_t)blockIdx.x * NB;
+    const int nb = (int)((k0 + NB < n) ? NB : n - k0);
+    const T* Lkk = L + (int64_t)b * sL + k0 * ldl + k0;
+    T* Ikk = Li + (int64_t)b * sI + k0 * ldi + k0;
+    for (int e = tid; e < NB * NB; e += 64) {
+        const int i = e / NB, m = e % NB;
+        T v = (T)0;
+        if (i < nb && m < nb) { if (m <= i) v = Lkk[(int64_t)i * ldl + m]; }
+        else if (i == m) v = (T)1;
+        l[i][m] = v;
+    }
+    __syncthreads();
+    const int c = tid;                       // column c of the inverse: x_i = (delta_ic - sum_{m=c}^{i-1} l_im x_m) / l_ii, i >= c
+    for (int i = 0; i < NB; ++i) {
+        T sacc = (i == c) ? (T)1 : (T)0;
+        if (i > c) for (int m = c; m < i; ++m) sacc = fma(-l[i][m], x[m][c], sacc);
+        x[i][c] = (i >= c) ? sacc / l[i][i] : (T)0;
+    }
+    __syncthreads();
+    for (int e = tid; e < nb * nb; e += 64) {
+        const int i = e / nb, m = e % nb;
+        Ikk[(int64_t)i * ldi + m] = x[i][m];
+    }
+}
+
 template <typename T>
 __global__ void zero_upper_kernel(T* A, int64_t n, int64_t lda, int64_t sA) {
     T* a = A + (int64_t)blockIdx.z * sA;
@@ -184,11 +313,8 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                                            A + j0 * lda + c0, lda, sA, 1.0, A + j0 * lda + j0, lda, sA, S, 0, st);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(S), dim3(256), 0, st, A, lda, sA, j0, nb, info);
             const int64_t below = n - (j0 + nb);
-            if (below > 0)
-                hipLaunchKernelGGL((solve_rows_kernel<T>), dim3((unsigned)((below + 127) / 128), S), dim3(128), 0, st, A, lda, sA, j0,
-                                   nb, j0 + nb, below);
+            hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(1 + (below + 127) / 128), S), dim3(128), 0, st, A, lda, sA, j0, nb, n, info);
         }
         if (pe < n) {   // trailing update, lower blocks only: A22 -= L21 L21^T with K = panel width
             int rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe, n - pe, pe - c0, -1.0, A + pe * lda + c0, lda, sA,
@@ -257,15 +383,69 @@ int mxf_trsm_internal(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, in
     MXF_FAIL(h, -2, "mxf_trsm: bad dtype %d", dtype);
 }
 
+namespace {
+
+template <typename T>
+__global__ void zero_block_kernel(T* __restrict__ P, int64_t rows, int64_t cols, int64_t ld, int64_t stride) {
+    T* p = P + (int64_t)blockIdx.y * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = (T)0;
+}
+
+// Log-depth blocked inverse of a lower-triangular matrix.  Level 0: all 64x64 diagonal blocks (one launch).  Level l merges pairs of
+// bs-blocks:  inv([L11 0; L21 L22]) = [I11 0; -I22 L21 I11, I22]  with two batched MFMA GEMMs; the temporary (L21 I11)^T lives in the
+// (unused, finally zeroed) upper-triangular mirror block of the output, so no extra workspace is needed.
+template <typename T>
+int trtri_typed(mxf_ctx* h, int dtype, int S, int64_t n, const T* L, int64_t ldl, int64_t sL, T* Li, int64_t ldi, int64_t sI, hipStream_t st) {
+    if (n > 65535) MXF_FAIL(h, -3, "mxf_trtri: n too large");
+    const int64_t nblk = (n + NB - 1) / NB;
+    hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)nblk, S), dim3(64), 0, st, L, ldl, sL, Li, ldi, sI, n);
+    for (int64_t bs = NB; bs < n; bs *= 2) {
+        const int64_t npairs_full = n / (2 * bs);                 // pairs whose second block is complete
+        const int64_t rem0 = npairs_full * 2 * bs;                  // start of a possible ragged last pair
+        for (int s = 0; s < S; ++s) {
+            const T* Ls = L + (int64_t)s * sL;
+            T* Is = Li + (int64_t)s * sI;
+            if (npairs_full > 0) {
+                const int64_t stL = 2 * bs * (ldl + 1), stI = 2 * bs * (ldi + 1);
+                // tmpT (bs x bs, in the upper mirror block) = I11^T L21^T
+                int rc = mxf_gemm_internal(h, dtype, 1, 1, bs, bs, bs, 1.0, Is, ldi, stI, Ls + bs * ldl, ldl, stL, 0.0, Is + bs, ldi, stI,
+                                           (int)npairs_full, 0, st);
+                if (rc) return rc;
+                // X21 = -I22 tmpT^T
+                rc = mxf_gemm_internal(h, dtype, 0, 1, bs, bs, bs, -1.0, Is + bs * (ldi + 1), ldi, stI, Is + bs, ldi, stI, 0.0, Is + bs * ldi, ldi,
+                                       stI, (int)npairs_full, 0, st);
+                if (rc) return rc;
+                // the scratch blocks become part of the next level's I11 operand: they must be zero again
+                hipLaunchKernelGGL((zero_block_kernel<T>), dim3((unsigned)((bs * bs + 255) / 256 > 1024 ? 1024 : (bs * bs + 255) / 256), (unsigned)npairs_full),
+                                   dim3(256), 0, st, Is + bs, bs, bs, ldi, stI);
+            }
+            const int64_t b2 = n - rem0 - bs;                       // rows of the ragged second block of the last pair (if any)
+            if (rem0 < n && b2 > 0) {
+                const T* Lp = Ls + rem0 * (ldl + 1);
+                T* Ip = Is + rem0 * (ldi + 1);
+                int rc = mxf_gemm_internal(h, dtype, 1, 1, bs, b2, bs, 1.0, Ip, ldi, 0, Lp + bs * ldl, ldl, 0, 0.0, Ip + bs, ldi, 0, 1, 0, st);
+                if (rc) return rc;
+                rc = mxf_gemm_internal(h, dtype, 0, 1, b2, bs, b2, -1.0, Ip + bs * (ldi + 1), ldi, 0, Ip + bs, ldi, 0, 0.0, Ip + bs * ldi, ldi, 0, 1, 0, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL((zero_block_kernel<T>), dim3((unsigned)((bs * b2 + 255) / 256 > 1024 ? 1024 : (bs * b2 + 255) / 256), 1), dim3(256), 0, st,
+                                   Ip + bs, bs, b2, ldi, (int64_t)0);
+            }
+        }
+    }
+    if (n > 1) hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, Li, n, ldi, sI);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+}  // namespace
+
 int mxf_trtri_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t sL, void* Linv, int64_t ldi,
                        int64_t sI, hipStream_t st) {
     if (n <= 0 || S <= 0) return 0;
-    if (n > 65535) MXF_FAIL(h, -3, "mxf_trtri: n too large");
-    dim3 g((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)S);
-    if (dtype == MXF_F32) hipLaunchKernelGGL((set_identity_kernel<float>), g, dim3(256), 0, st, (float*)Linv, n, ldi, sI);
-    else if (dtype == MXF_F64) hipLaunchKernelGGL((set_identity_kernel<double>), g, dim3(256), 0, st, (double*)Linv, n, ldi, sI);
-    else MXF_FAIL(h, -2, "mxf_trtri: bad dtype %d", dtype);
-    return mxf_trsm_internal(h, dtype, 0, S, n, n, L, ldl, sL, Linv, ldi, sI, 1, st);
+    if (dtype == MXF_F32) return trtri_typed<float>(h, dtype, S, n, (const float*)L, ldl, sL, (float*)Linv, ldi, sI, st);
+    if (dtype == MXF_F64) return trtri_typed<double>(h, dtype, S, n, (const double*)L, ldl, sL, (double*)Linv, ldi, sI, st);
+    MXF_FAIL(h, -2, "mxf_trtri: bad dtype %d", dtype);
 }
 
 int mxf_sumlogdiag_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t sL, void* out, hipStream_t st) {

@@ -344,7 +344,7 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     g.nwg = g.ntiles * batch * splitk;
     if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm: grid too large");
-    if (g.atomic) {
+    if (g.atomic && beta != 1.0) {     // beta == 1 (the potrf / trsm updates): C is accumulated into as is, nothing to pre-scale
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
         if (M > 65535) MXF_FAIL(h, -3, "mxf_gemm: split-K path needs M<=65535");
         hipLaunchKernelGGL((scale_kernel<T>), gs, dim3(256), 0, st, (T*)C, M, N, ldc, sC, (T)beta, lower_only);
