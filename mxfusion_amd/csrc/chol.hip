@@ -15,6 +15,14 @@
 namespace {
 
 constexpr int NB = 64;     // inner block
+
+// 1/sqrt(d) to full precision: hardware v_rsq estimate + Newton steps (cheaper than a correctly-rounded sqrt AND a division)
+__device__ __forceinline__ float inv_sqrt(float d) { float r = rsqrtf(d); r = r * (1.5f - 0.5f * d * r * r); return r; }
+__device__ __forceinline__ double inv_sqrt(double d) {
+    double r = rsqrt(d);
+    r = r * (1.5 - 0.5 * d * r * r);
+    return r;
+}
 constexpr int NBO = 512;   // outer panel
 
 // ---- 64x64 diagonal block Cholesky in LDS, one workgroup per batch item --------------------------------
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
                                                            int* __restrict__ info) {
     __shared__ T a[NB][NB + 1];
     __shared__ T lc[4][NB];
+    __shared__ T invd[NB];
     __shared__ T t[128][NB + 1];
     const int tid = threadIdx.x, b = blockIdx.y;
     T* Ab = A + (int64_t)b * sA;
@@ -122,16 +131,17 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
             T L00, L10, L11, L20, L21, L22, L30, L31, L32, L33;
             int bad = -1;
             T d = a[jb][jb];                                          if (!(d > (T)0)) { if (bad < 0) bad = 0; d = (T)1; }
-            L00 = sqrt(d); const T i0 = (T)1 / L00;
+            const T i0 = inv_sqrt(d); L00 = d * i0;
             L10 = a[jb + 1][jb] * i0; L20 = a[jb + 2][jb] * i0; L30 = a[jb + 3][jb] * i0;
             d = a[jb + 1][jb + 1] - L10 * L10;                        if (!(d > (T)0)) { if (bad < 0) bad = 1; d = (T)1; }
-            L11 = sqrt(d); const T i1 = (T)1 / L11;
+            const T i1 = inv_sqrt(d); L11 = d * i1;
             L21 = (a[jb + 2][jb + 1] - L20 * L10) * i1; L31 = (a[jb + 3][jb + 1] - L30 * L10) * i1;
             d = a[jb + 2][jb + 2] - L20 * L20 - L21 * L21;            if (!(d > (T)0)) { if (bad < 0) bad = 2; d = (T)1; }
-            L22 = sqrt(d); const T i2 = (T)1 / L22;
+            const T i2 = inv_sqrt(d); L22 = d * i2;
             L32 = (a[jb + 3][jb + 2] - L30 * L20 - L31 * L21) * i2;
             d = a[jb + 3][jb + 3] - L30 * L30 - L31 * L31 - L32 * L32; if (!(d > (T)0)) { if (bad < 0) bad = 3; d = (T)1; }
-            L33 = sqrt(d); const T i3 = (T)1 / L33;
+            const T i3 = inv_sqrt(d); L33 = d * i3;
+            if (tid == jb) { invd[jb] = i0; invd[jb + 1] = i1; invd[jb + 2] = i2; invd[jb + 3] = i3; }
             if (bad >= 0 && tid == jb && blockIdx.x == 0 && jb + bad < nb && info && info[b] == 0) info[b] = (int)(k0 + jb + bad + 1);
             const int r = tid - jb;                                   // position relative to the sub-block
             T l0, l1, l2, l3;
@@ -177,10 +187,11 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     T x[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        T sacc = t[tid][j];
+        T s0 = t[tid][j], s1 = (T)0;              // two accumulators: halves the dependent-FMA chain
 #pragma unroll
-        for (int k = 0; k < j; ++k) sacc = fma(-x[k], a[j][k], sacc);
-        x[j] = sacc / a[j][j];
+        for (int k = 0; k + 1 < j; k += 2) { s0 = fma(-x[k], a[j][k], s0); s1 = fma(-x[k + 1], a[j][k + 1], s1); }
+        if (j & 1) s0 = fma(-x[j - 1], a[j][j - 1], s0);
+        x[j] = (s0 + s1) * invd[j];
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();

@@ -24,7 +24,13 @@ namespace {
 #ifndef MXF_GEMM_WPS
 #define MXF_GEMM_WPS 2
 #endif
+#ifndef MXF_GEMM_WAVES
+#define MXF_GEMM_WAVES 8
+#endif
 constexpr int BM = 128, BN = 128, BK = MXF_GEMM_BK;
+constexpr int NWAVE = MXF_GEMM_WAVES;          // 4: 2x2 waves of 64x64;  8: 2x4 waves of 64x32 (half the accumulators -> 4 waves/SIMD)
+constexpr int NT = 64 * NWAVE;
+constexpr int WN = (NWAVE == 8) ? 32 : 64;     // wave tile width
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -43,7 +49,7 @@ struct GemmArgs {
     int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
 };
 
-constexpr int EPT = BK * 128 / 256;   // elements of one operand tile per thread
+constexpr int EPT = BK * 128 / NT;    // elements of one operand tile per thread
 
 // ---- generic (guarded, any alignment) tile loaders: [BK x 128] tile, EPT scalars per thread ------------------
 // KCONT: the matrix is stored with k contiguous (A not transposed / B transposed)
@@ -55,7 +61,7 @@ __device__ __forceinline__ void load_tile(T (&reg)[EPT], const T* __restrict__ P
         const int64_t kk = k0 + k;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int64_t i = mn0 + (tid / BK) + (256 / BK) * j;
+            const int64_t i = mn0 + (tid / BK) + (NT / BK) * j;
             reg[j] = (i < MN && kk < kend) ? P[i * ld + kk] : (T)0;
         }
     } else {
@@ -63,7 +69,7 @@ __device__ __forceinline__ void load_tile(T (&reg)[EPT], const T* __restrict__ P
         const int64_t ii = mn0 + i;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int64_t kk = k0 + (tid >> 7) + 2 * j;
+            const int64_t kk = k0 + (tid >> 7) + (NT / 128) * j;
             reg[j] = (ii < MN && kk < kend) ? P[kk * ld + ii] : (T)0;
         }
     }
@@ -75,11 +81,11 @@ __device__ __forceinline__ void store_tile(const T (&reg)[EPT], T* __restrict__ 
     if (KCONT) {
         const int k = tid & (BK - 1);
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) S[k * LD + (tid / BK) + (256 / BK) * j] = reg[j];
+        for (int j = 0; j < EPT; ++j) S[k * LD + (tid / BK) + (NT / BK) * j] = reg[j];
     } else {
         const int i = tid & 127;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) S[((tid >> 7) + 2 * j) * LD + i] = reg[j];
+        for (int j = 0; j < EPT; ++j) S[((tid >> 7) + (NT / 128) * j) * LD + i] = reg[j];
     }
 }
 
@@ -93,14 +99,14 @@ __device__ __forceinline__ void load_tile_vec(T (&reg)[EPT], const T* __restrict
         constexpr int VPR = BK / VEC;                 // vectors per row (k direction)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = tid + 256 * j, i = v / VPR, kc = v % VPR;
+            const int v = tid + NT * j, i = v / VPR, kc = v % VPR;
             *reinterpret_cast<V*>(&reg[j * VEC]) = *reinterpret_cast<const V*>(P + (mn0 + i) * ld + k0 + kc * VEC);
         }
     } else {
         constexpr int VPR = 128 / VEC;                // vectors per k-row (mn direction)
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = tid + 256 * j, kr = v / VPR, c = v % VPR;
+            const int v = tid + NT * j, kr = v / VPR, c = v % VPR;
             *reinterpret_cast<V*>(&reg[j * VEC]) = *reinterpret_cast<const V*>(P + (k0 + kr) * ld + mn0 + c * VEC);
         }
     }
@@ -116,7 +122,7 @@ __device__ __forceinline__ void store_tile_vec(const T (&reg)[EPT], T* __restric
         constexpr int VPR = BK / VEC;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = tid + 256 * j, i = v / VPR, kc = v % VPR;
+            const int v = tid + NT * j, i = v / VPR, kc = v % VPR;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) S[(kc * VEC + e) * LD + i] = reg[j * VEC + e];
         }
@@ -124,7 +130,7 @@ __device__ __forceinline__ void store_tile_vec(const T (&reg)[EPT], T* __restric
         constexpr int VPR = 128 / VEC;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = tid + 256 * j, kr = v / VPR, c = v % VPR;
+            const int v = tid + NT * j, kr = v / VPR, c = v % VPR;
             *reinterpret_cast<V*>(S + kr * LD + c * VEC) = *reinterpret_cast<const V*>(&reg[j * VEC]);
         }
     }
@@ -132,34 +138,38 @@ __device__ __forceinline__ void store_tile_vec(const T (&reg)[EPT], T* __restric
 
 template <typename T> struct Acc;
 template <> struct Acc<float> {
-    f32x16 c[2][2];
+    static constexpr int NB_ = WN / 32;      // 32-wide MFMA tiles along n per wave
+    f32x16 c[2][NB_];
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB_; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
     }
-    // one BK=16 slab from LDS
+    // one BK slab from LDS
     __device__ __forceinline__ void mma(const float* __restrict__ As, const float* __restrict__ Bs, int wm, int wn, int lane) {
         constexpr int LD = Tile<float>::LD;
         const int li = lane & 31, lk = lane >> 5;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
-            float a0 = As[(ks + lk) * LD + wm + li], a1 = As[(ks + lk) * LD + wm + 32 + li];
-            float b0 = Bs[(ks + lk) * LD + wn + li], b1 = Bs[(ks + lk) * LD + wn + 32 + li];
-            c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c[0][0], 0, 0, 0);
-            c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c[0][1], 0, 0, 0);
-            c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c[1][0], 0, 0, 0);
-            c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c[1][1], 0, 0, 0);
+            float a[2], b[NB_];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = As[(ks + lk) * LD + wm + 32 * t + li];
+#pragma unroll
+            for (int t = 0; t < NB_; ++t) b[t] = Bs[(ks + lk) * LD + wn + 32 * t + li];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < NB_; ++y) c[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], c[x][y], 0, 0, 0);
         }
     }
     template <typename F> __device__ __forceinline__ void for_each(int wm, int wn, int lane, F f) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB_; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -169,12 +179,13 @@ template <> struct Acc<float> {
     }
 };
 template <> struct Acc<double> {
-    f64x4 c[4][4];
+    static constexpr int NB_ = WN / 16;      // 16-wide MFMA tiles along n per wave
+    f64x4 c[4][NB_];
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB_; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[a][b][r] = 0.0;
     }
@@ -183,23 +194,22 @@ template <> struct Acc<double> {
         const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
-            double a[4], b[4];
+            double a[4], b[NB_];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = As[(ks + lk) * LD + wm + 16 * t + li];
-                b[t] = Bs[(ks + lk) * LD + wn + 16 * t + li];
-            }
+            for (int t = 0; t < 4; ++t) a[t] = As[(ks + lk) * LD + wm + 16 * t + li];
+#pragma unroll
+            for (int t = 0; t < NB_; ++t) b[t] = Bs[(ks + lk) * LD + wn + 16 * t + li];
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], c[x][y], 0, 0, 0);
+                for (int y = 0; y < NB_; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], c[x][y], 0, 0, 0);
         }
     }
     template <typename F> __device__ __forceinline__ void for_each(int wm, int wn, int lane, F f) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB_; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = wm + a * 16 + (lane >> 4) + 4 * r;
@@ -210,12 +220,13 @@ template <> struct Acc<double> {
 };
 
 template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? MXF_GEMM_WPS : 1)) void gemm_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? MXF_GEMM_WPS : 1))) void gemm_kernel(GemmArgs<T> g) {
     constexpr int LD = Tile<T>::LD;
     __shared__ __attribute__((aligned(16))) T smem[2][2][BK * LD];   // [buffer][A|B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (NWAVE == 8) ? (wave >> 2) * 64 : (wave >> 1) * 64;
+    const int wn = (NWAVE == 8) ? (wave & 3) * 32 : (wave & 1) * 64;
     // XCD-aware 1-D work mapping.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness): give
     // each XCD a CONTIGUOUS range of work ids so that tiles sharing an operand panel hit the same private L2, and
     // enumerate only the tiles that exist (lower_only: compact triangular decode) so every XCD gets the same load.
@@ -350,10 +361,10 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         hipLaunchKernelGGL((scale_kernel<T>), gs, dim3(256), 0, st, (T*)C, M, N, ldc, sC, (T)beta, lower_only);
     }
     dim3 grid((unsigned)g.nwg, 1, 1);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), 0, st, g);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(NT), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(NT), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(NT), 0, st, g);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
