@@ -178,6 +178,18 @@ int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t
                     void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
                     void* dls, void* dvar, void* stream);
 
+/* The same bound with heteroscedastic and/or per-output noise (svgp_regression.py:61-67: noise_var of shape (N, D'), D' in {1, D};
+ * testing/modules/svgpregression_test.py:142-167).  noise_var is (noise_rows, noise_cols) with noise_rows in {1, B} and noise_cols in {1, P},
+ * shared by all samples; dnoise has the same shape.  Generic (materialised dKuf) path: same results, not the streaming fused pass.    */
+int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                        const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                        const void* Z, const void* noise_var, int64_t noise_rows, int noise_cols,
+                        const void* qU_mean, const void* qU_cov_W, const void* qU_cov_diag, const void* lengthscale, int ard,
+                        const void* variance, double jitter, double scaling, double gscale,
+                        void* logL, int* info, int want_grad,
+                        void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
+                        void* dls, void* dvar, void* stream);
+
 /* SparseGPRegressionLogPdf.compute (modules/gp_modules/sparsegp_regression.py:42-108), Titsias bound, ONE sample
  * (callers loop over samples), stationary kernel, sufficient-statistics form with C = Kuu + Psi2/noise.
  *   X (B,Q)  Y (B,P) [minus mean]  Z (M,Q)  noise_var (1)  lengthscale (Q|1)  variance (1)

@@ -321,12 +321,79 @@ __global__ void svgp_finalize_kernel(int S, int64_t B, int64_t M, int P, const d
     if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * P * beta * (double)B);
 }
 
+// ---- heteroscedastic / per-output noise (svgp_regression.py:61-67): noise is (nrows, ncols), nrows in {1,B}, ncols in {1,P} ------
+// one thread per column n: beta_d = 1/noise[n|0][d|0], bs = sum_d beta_d, e = y - u, q = k^T H0 k;
+//   l_s += -1/2 sum_d (beta_d e_d^2 + log 2pi + log noise_d) - 1/2 bs (var - q)
+// reverse: dY = -a1 beta.e ; Eb = a1 beta.e (for Gw = Kuf Eb) ; T[:,n] <- a1 (bs T[:,n] + w (beta.e)) = dKuf ; Ksc = 1/2 a1 bs Kuf[:,n]
+template <typename T>
+__global__ __launch_bounds__(256) void svgp_het_mid_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf, T* __restrict__ Text,
+                                                           const T* __restrict__ Y, int64_t sY, const T* __restrict__ w, const T* __restrict__ noise,
+                                                           int64_t nrows, int ncols, const double* __restrict__ var, double a1, int want_grad,
+                                                           T* __restrict__ Eb, T* __restrict__ Ksc, T* __restrict__ dY, int dY_shared,
+                                                           T* __restrict__ dnoise, double* __restrict__ scal /* [S][2]: l_s, sum bs */) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= SB) return;
+    const int64_t s = n / B, nb = n % B;
+    const int64_t nr = (nrows > 1) ? nb : 0;
+    constexpr int PMAX = 8;
+    double be[PMAX], beta[PMAX], e2b = 0, lg = 0, bs = 0;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        be[p] = 0; beta[p] = 0;
+        if (p < P) {
+            const double nz = (double)noise[nr * ncols + (ncols > 1 ? p : 0)];
+            beta[p] = 1.0 / nz;
+            const double e = (double)Y[s * sY + nb * P + p] - (double)Text[(M + p) * SB + n];
+            be[p] = beta[p] * e;
+            e2b += be[p] * e; lg += LOG2PI + log(nz); bs += beta[p];
+        }
+    }
+    double q = 0;
+    for (int64_t m = 0; m < M; ++m) {
+        const double k = (double)Kuf[m * SB + n], t = (double)Text[m * SB + n];
+        q = fma(k, t, q);
+        if (want_grad) {
+            double we = 0;
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) if (p < P) we = fma((double)w[m * P + p], be[p], we);
+            Text[m * SB + n] = (T)(a1 * (bs * t + we));
+            Ksc[m * SB + n] = (T)(0.5 * a1 * bs * k);
+        }
+    }
+    const double vk = var[0];
+    atomic_add(scal + 2 * s, -0.5 * (e2b + lg) - 0.5 * bs * (vk - q));
+    atomic_add(scal + 2 * s + 1, bs);
+    if (!want_grad) return;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        if (p < P) {
+            Eb[n * P + p] = (T)(a1 * be[p]);
+            if (dY) { const T g = (T)(-a1 * be[p]); if (dY_shared) atomic_add(dY + nb * P + p, g); else dY[n * P + p] = g; }
+            if (dnoise) {
+                const double g = a1 * (0.5 * be[p] * be[p] - 0.5 * beta[p] + 0.5 * (vk - q) * beta[p] * beta[p]);
+                atomic_add(dnoise + nr * ncols + (ncols > 1 ? p : 0), (T)g);
+            }
+        }
+}
+template <typename T>
+__global__ void svgp_het_finalize_kernel(int S, int64_t M, int P, const double* __restrict__ scal, const double* __restrict__ sldL,
+                                         const double* __restrict__ sldLs, const double* __restrict__ trKiSu, const double* __restrict__ muw,
+                                         double scaling, double a1, T* __restrict__ logL, double* __restrict__ dvar_direct) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double negKL = 0.5 * P * ((double)M + 2.0 * sldLs[0] - 2.0 * sldL[0] - trKiSu[0]) - 0.5 * muw[0];
+    double sb = 0;
+    for (int s = 0; s < S; ++s) { logL[s] = (T)(scaling * scal[2 * s] + negKL); sb += scal[2 * s + 1]; }
+    if (dvar_direct) dvar_direct[0] = -0.5 * a1 * sb;
+}
+
 template <typename T>
 int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P, const T* X, int64_t sX, const T* Y,
-                      int64_t sY, const T* Z, const T* noise, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
+                      int64_t sY, const T* Z, const T* noise, int64_t nrows, int ncols, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
                       double jitter, double scaling, double gscale, T* logL, int* info, int want_grad, T* dX, T* dY, T* dZ, T* dnoise,
                       T* dmu, T* dW, T* dSdiag, T* dls, T* dvar, hipStream_t st) {
     if (P > 8) MXF_FAIL(h, -3, "mxf_svgp_logpdf: P > 8 outputs not supported");
+    if ((nrows != 1 && nrows != B) || (ncols != 1 && ncols != P)) MXF_FAIL(h, -2, "mxf_svgp_logpdf: noise_var must be (1|B, 1|P)");
+    const bool het = nrows > 1 || ncols > 1;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
     const int SS = (sX == 0 && sY == 0) ? 1 : S;   // samples that need their own columns
     // when X is shared but Y is sampled we still lay S copies of the columns (rare); X columns repeat
@@ -343,7 +410,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T));
-    if (want_grad) { acc((size_t)M * SB, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
+    if (want_grad) { acc((size_t)M * SB, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
     Carver cv(ws);
@@ -354,16 +421,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
     T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB);
-    T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr;
-    if (want_grad) { Kfu = cv.take<T>((size_t)M * SB); Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); }
+    T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
+    if (want_grad) { Kfu = cv.take<T>((size_t)M * SB); Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
-    CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
+    CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); if (!het) CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
 #undef CONV
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
     int rc;
+    static const int psi2_late = getenv("MXF_SVGP_PSI2_LATE") ? atoi(getenv("MXF_SVGP_PSI2_LATE")) : 0;
+    static const int psi2_reserve = getenv("MXF_SVGP_PSI2_RESERVE") ? atoi(getenv("MXF_SVGP_PSI2_RESERVE")) : 0;
     // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
     if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
     hipStream_t sd_ = h->side;
@@ -374,7 +443,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // side chain
     rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);              // Kuf_all = k(Z, X_all) :73
     if (rc) return rc;
-    if (want_grad) {
+    if (want_grad && !het) {
         // Psi2 = Kuf Kuf^T depends on neither the core nor the T-GEMM nor the reverse pass: it gets its own stream and starts at once.
         // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM (sequential operand streams;
         // the NT form on Kuf reads 256 K-strided streams per workgroup).  Its waves saturate the register file, so 16 CUs are left
@@ -384,10 +453,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
         MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_join2, 0));
-        rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, 16);   // lower blocks only, split-K
-        if (rc) return rc;
-        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
-        MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
+        if (!psi2_late) {
+            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, 16);   // lower blocks only, split-K
+            if (rc) return rc;
+            hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
+            MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
+        }
     }
     hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, M, (const D*)sd, Su);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, sd_);       // Su = W W^T + diag(s) :76
@@ -441,7 +512,31 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
     if (S > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X (loop over samples on the host otherwise)");
     D* dnz = nullptr; D* dvdir = nullptr;
-    if (!want_grad) {
+    if (het) {
+        if (want_grad) {
+            dvdir = sc + 5;
+            if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
+            if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
+            if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
+            if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
+            if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
+            if (dnoise) MXF_HIP(h, hipMemsetAsync(dnoise, 0, sizeof(T) * (size_t)nrows * ncols, st));
+        }
+        T* Ksc = Kfu;   // the transposed-Gram slot is unused on this path
+        hipLaunchKernelGGL((svgp_het_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
+                           (const T*)wT, noise, nrows, ncols, (const D*)vard, a1, want_grad, Eb, Ksc, dY, dY_shared, dnoise, scal);
+        hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
+                           (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
+        MXF_LAUNCH_CHECK(h);
+        if (!want_grad) return 0;
+        // G' = 1/2 a1 Kuf diag(bs) Kuf^T (-> Psi2 slot), Gw = Kuf (a1 beta.e) (-> R slot), Kuf-side reverse mode from dKuf = Text
+        rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Ksc, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, SB, 1.0, Kuf, SB, 0, Eb, P, 0, 0.0, R, P, 0, 1, 0, st);
+        if (rc) return rc;
+        rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, Text, SB, 0, dZ, dX, dls, dvar, st);
+        if (rc) return rc;
+    } else if (!want_grad) {
         hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
                            (const T*)wT, noise, a1, 0, (T*)nullptr, (T*)nullptr, 0, scal);
     } else {
@@ -453,20 +548,37 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
         MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
+        if (psi2_late) {
+            // Psi2 (MFMA-bound) next to the fused reverse pass (VALU-bound) instead of next to the T GEMM (MFMA-bound)
+            hipStream_t s2_ = h->side2;
+            MXF_HIP(h, hipEventRecord(h->ev_aux, st));
+            MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux, 0));
+            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, psi2_reserve);
+            if (rc) return rc;
+            hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
+            MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
+        }
         rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
                                          dY, dY_shared, R, scal, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
-                       (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
-    MXF_LAUNCH_CHECK(h);
-    if (!want_grad) return 0;
+    if (!het) {
+        hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
+                           (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
+        MXF_LAUNCH_CHECK(h);
+        if (!want_grad) return 0;
+    }
 
     D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
     D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
-    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Psi2 from the side stream
-    hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
-    hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
+    if (het) {
+        hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const T*)Psi2, MM, G, MM);
+        hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const T*)R, MP, Gw, MP);
+    } else {
+        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Psi2 from the side stream
+        hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
+        hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
+    }
     // ---- core reverse mode (float64): the Su chain runs on the side stream next to the Kuu chain ----------------------
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));
     MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
@@ -508,7 +620,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
         hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
     }
-    if (dnoise) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
     MXF_LAUNCH_CHECK(h);
     return 0;
@@ -710,6 +822,33 @@ extern "C" int mxf_gp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t N
     MXF_FAIL(h, -2, "mxf_gp_logpdf: bad dtype %d", dtype);
 }
 
+static int svgp_dispatch(mxf_handle h, const char* fn, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                         const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y, const void* Z, const void* noise_var,
+                         int64_t noise_rows, int noise_cols, const void* qU_mean, const void* qU_cov_W, const void* qU_cov_diag,
+                         const void* lengthscale, int ard, const void* variance, double jitter, double scaling, double gscale,
+                         void* logL, int* info, int want_grad, void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW,
+                         void* dSdiag, void* dls, void* dvar, void* stream) {
+    if (!h) return -1;
+    if (S <= 0 || B <= 0 || M <= 0 || Q <= 0 || P <= 0) MXF_FAIL(h, -2, "%s: bad shape", fn);
+    if (!X || !Y || !Z || !noise_var || !qU_mean || !qU_cov_W || !qU_cov_diag || !lengthscale || !variance || !logL)
+        MXF_FAIL(h, -2, "%s: null argument", fn);
+    if (kind > MXF_K_MATERN52) MXF_FAIL(h, -2, "%s: stationary kernels only", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MXF_F32)
+        return svgp_logpdf_typed<float>(h, kind, dtype, S, B, M, Q, P, (const float*)X, strideS_X, (const float*)Y, strideS_Y, (const float*)Z,
+                                        (const float*)noise_var, noise_rows, noise_cols, (const float*)qU_mean, (const float*)qU_cov_W,
+                                        (const float*)qU_cov_diag, (const float*)lengthscale, ard, (const float*)variance, jitter, scaling, gscale,
+                                        (float*)logL, info, want_grad, (float*)dX, (float*)dY, (float*)dZ, (float*)dnoise, (float*)dmu, (float*)dW,
+                                        (float*)dSdiag, (float*)dls, (float*)dvar, st);
+    if (dtype == MXF_F64)
+        return svgp_logpdf_typed<double>(h, kind, dtype, S, B, M, Q, P, (const double*)X, strideS_X, (const double*)Y, strideS_Y, (const double*)Z,
+                                         (const double*)noise_var, noise_rows, noise_cols, (const double*)qU_mean, (const double*)qU_cov_W,
+                                         (const double*)qU_cov_diag, (const double*)lengthscale, ard, (const double*)variance, jitter, scaling,
+                                         gscale, (double*)logL, info, want_grad, (double*)dX, (double*)dY, (double*)dZ, (double*)dnoise,
+                                         (double*)dmu, (double*)dW, (double*)dSdiag, (double*)dls, (double*)dvar, st);
+    MXF_FAIL(h, -2, "%s: bad dtype %d", fn, dtype);
+}
+
 extern "C" int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
                                const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
                                const void* Z, const void* noise_var, const void* qU_mean, const void* qU_cov_W,
@@ -718,25 +857,22 @@ extern "C" int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t
                                void* logL, int* info, int want_grad,
                                void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
                                void* dls, void* dvar, void* stream) {
-    if (!h) return -1;
-    if (S <= 0 || B <= 0 || M <= 0 || Q <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf: bad shape");
-    if (!X || !Y || !Z || !noise_var || !qU_mean || !qU_cov_W || !qU_cov_diag || !lengthscale || !variance || !logL)
-        MXF_FAIL(h, -2, "mxf_svgp_logpdf: null argument");
-    if (kind > MXF_K_MATERN52) MXF_FAIL(h, -2, "mxf_svgp_logpdf: stationary kernels only");
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == MXF_F32)
-        return svgp_logpdf_typed<float>(h, kind, dtype, S, B, M, Q, P, (const float*)X, strideS_X, (const float*)Y, strideS_Y, (const float*)Z,
-                                        (const float*)noise_var, (const float*)qU_mean, (const float*)qU_cov_W, (const float*)qU_cov_diag,
-                                        (const float*)lengthscale, ard, (const float*)variance, jitter, scaling, gscale, (float*)logL, info,
-                                        want_grad, (float*)dX, (float*)dY, (float*)dZ, (float*)dnoise, (float*)dmu, (float*)dW, (float*)dSdiag,
-                                        (float*)dls, (float*)dvar, st);
-    if (dtype == MXF_F64)
-        return svgp_logpdf_typed<double>(h, kind, dtype, S, B, M, Q, P, (const double*)X, strideS_X, (const double*)Y, strideS_Y, (const double*)Z,
-                                         (const double*)noise_var, (const double*)qU_mean, (const double*)qU_cov_W, (const double*)qU_cov_diag,
-                                         (const double*)lengthscale, ard, (const double*)variance, jitter, scaling, gscale, (double*)logL, info,
-                                         want_grad, (double*)dX, (double*)dY, (double*)dZ, (double*)dnoise, (double*)dmu, (double*)dW,
-                                         (double*)dSdiag, (double*)dls, (double*)dvar, st);
-    MXF_FAIL(h, -2, "mxf_svgp_logpdf: bad dtype %d", dtype);
+    return svgp_dispatch(h, "mxf_svgp_logpdf", kind, dtype, S, B, M, Q, P, X, strideS_X, Y, strideS_Y, Z, noise_var, 1, 1, qU_mean, qU_cov_W,
+                         qU_cov_diag, lengthscale, ard, variance, jitter, scaling, gscale, logL, info, want_grad, dX, dY, dZ, dnoise, dmu, dW,
+                         dSdiag, dls, dvar, stream);
+}
+
+extern "C" int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                                   const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y,
+                                   const void* Z, const void* noise_var, int64_t noise_rows, int noise_cols,
+                                   const void* qU_mean, const void* qU_cov_W, const void* qU_cov_diag, const void* lengthscale, int ard,
+                                   const void* variance, double jitter, double scaling, double gscale,
+                                   void* logL, int* info, int want_grad,
+                                   void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
+                                   void* dls, void* dvar, void* stream) {
+    return svgp_dispatch(h, "mxf_svgp_logpdf_het", kind, dtype, S, B, M, Q, P, X, strideS_X, Y, strideS_Y, Z, noise_var, noise_rows, noise_cols,
+                         qU_mean, qU_cov_W, qU_cov_diag, lengthscale, ard, variance, jitter, scaling, gscale, logL, info, want_grad, dX, dY, dZ,
+                         dnoise, dmu, dW, dSdiag, dls, dvar, stream);
 }
 
 extern "C" int mxf_sgp_logpdf(mxf_handle h, int kind, int dtype, int64_t B, int64_t M, int Q, int P, const void* X, const void* Y,

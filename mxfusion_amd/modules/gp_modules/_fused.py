@@ -40,7 +40,7 @@ class SVGPLogPdfFn(torch.autograd.Function):
     def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
         want = any(ctx.needs_input_grad[4:])
         S = max(X.shape[0], Y.shape[0])
-        r = ops.svgp_logpdf(kind, X, Y, Z[0], noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1), ard,
+        r = ops.svgp_logpdf(kind, X, Y, Z[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1), ard,
                             jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
         if want:
             ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'], r['dls'], r['dvar'])

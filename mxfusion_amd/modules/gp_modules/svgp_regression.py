@@ -45,8 +45,6 @@ class SVGPRegressionLogPdf(VariationalInference):
         if spec is None:
             raise NotImplementedError('SVGPRegressionLogPdf on MI355X supports a single stationary kernel '
                                       '(RBF / Matern12/32/52); combination kernels are a next-row item (SURVEY 8f)')
-        if noise_var.dim() > 2 and noise_var.shape[-2] > 1:
-            raise NotImplementedError('heteroscedastic noise (svgp_regression.py:61-67) is not implemented in the fused path')
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']

@@ -205,8 +205,8 @@ def gp_logpdf(kind, X, Y, noise_var, lengthscale, variance, ard, jitter=0.0, wan
 
 def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance, ard, jitter=0.0,
                 scaling=1.0, gscale=1.0, want_grad=False):
-    """SVGPRegressionLogPdf.compute (svgp_regression.py:43-109), homoscedastic.  X (S|1,B,Q), Y (S|1,B,P) [minus mean],
-    Z (M,Q), noise_var (1,), qU_mean (M,P), qU_cov_W (M,M), qU_cov_diag (M,) [positive], lengthscale (Q|1,), variance (1,).
+    """SVGPRegressionLogPdf.compute (svgp_regression.py:43-109).  X (S|1,B,Q), Y (S|1,B,P) [minus mean],
+    Z (M,Q), noise_var (1,) | (P,) | (B,1) | (B,P), qU_mean (M,P), qU_cov_W (M,M), qU_cov_diag (M,) [positive], lengthscale (Q|1,), variance (1,).
     Returns dict(logL (S,), info, and -- if want_grad -- the gradients of gscale*sum_s logL[s])."""
     X, Y, Z = _c(X), _c(Y), _c(Z)
     noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance = [_c(t) for t in (noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance)]
@@ -214,16 +214,27 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
     B, Q, P, M = X.shape[-2], X.shape[-1], Y.shape[-1], Z.shape[-2]
     dev, dt = X.device, X.dtype
     out = {'logL': torch.empty(S, dtype=dt, device=dev), 'info': torch.zeros(1, dtype=torch.int32, device=dev)}
+    # noise_var: (1,) homoscedastic -> streaming fused path; (P,), (B,1) or (B,P) -> mxf_svgp_logpdf_het (svgp_regression.py:61-67)
+    if noise_var.dim() == 1:
+        noise_var = noise_var.reshape(1, -1)
+    nrows, ncols = noise_var.shape
+    if nrows not in (1, B) or ncols not in (1, P):
+        raise ValueError('svgp_logpdf: noise_var must be (1|B, 1|P), got %s' % (tuple(noise_var.shape),))
+    het = nrows * ncols > 1
     g = {}
     if want_grad:
         E = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
-        g = {'dX': E(*X.shape), 'dY': E(*Y.shape), 'dZ': E(M, Q), 'dnoise': E(1), 'dmu': E(M, P), 'dW': E(M, M), 'dSdiag': E(M),
+        g = {'dX': E(*X.shape), 'dY': E(*Y.shape), 'dZ': E(M, Q), 'dnoise': E(nrows, ncols), 'dmu': E(M, P), 'dW': E(M, M), 'dSdiag': E(M),
              'dls': E(lengthscale.numel()), 'dvar': E(1)}
-    _lib.call('mxf_svgp_logpdf', _h(X), KIND[kind], _dt(X), S, B, M, Q, P, _p(X), _ss(X), _p(Y), _ss(Y), _p(Z), _p(noise_var),
-              _p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), _p(lengthscale), int(bool(ard)), _p(variance), float(jitter),
-              float(scaling), float(gscale), _p(out['logL']), _p(out['info']), int(want_grad),
-              _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dZ')), _p(g.get('dnoise')), _p(g.get('dmu')), _p(g.get('dW')),
-              _p(g.get('dSdiag')), _p(g.get('dls')), _p(g.get('dvar')), _stream())
+    tail = (_p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), _p(lengthscale), int(bool(ard)), _p(variance), float(jitter),
+            float(scaling), float(gscale), _p(out['logL']), _p(out['info']), int(want_grad),
+            _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dZ')), _p(g.get('dnoise')), _p(g.get('dmu')), _p(g.get('dW')),
+            _p(g.get('dSdiag')), _p(g.get('dls')), _p(g.get('dvar')), _stream())
+    head = (_h(X), KIND[kind], _dt(X), S, B, M, Q, P, _p(X), _ss(X), _p(Y), _ss(Y), _p(Z), _p(noise_var))
+    if het:
+        _lib.call('mxf_svgp_logpdf_het', *head, nrows, ncols, *tail)
+    else:
+        _lib.call('mxf_svgp_logpdf', *head, *tail)
     out.update(g)
     return out
 

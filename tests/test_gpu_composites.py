@@ -113,3 +113,35 @@ def test_svgp_logpdf_vs_oracle(kind, dtype, tol, B, M, Q, P, S):
     gtol = tol * 50 if dtype == torch.float64 else 5e-3
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('nshape', ['BP', 'B1', '1P'])
+@pytest.mark.parametrize('B,M,Q,P,S', [(10, 3, 3, 2, 1), (700, 70, 5, 3, 2)])
+def test_svgp_logpdf_heteroscedastic_vs_oracle(dtype, tol, nshape, B, M, Q, P, S):
+    """noise_var of shape (N, D) / (N, 1) / (D,): svgp_regression.py:61-67, exercised by the reference in
+    testing/modules/svgpregression_test.py:142-167 (test_log_pdf_w_samples_of_noise_var)."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(B + M + len(nshape))
+    X = rng.uniform(-2, 2, (S, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm, qW, qd = rng.randn(M, P) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    ls = rng.rand(Q) * 0.5 + (1.0 if dtype == torch.float64 else 0.25)
+    var = np.array([1.3])
+    noise = rng.rand(*{'BP': (B, P), 'B1': (B, 1), '1P': (1, P)}[nshape]) * 0.2 + 0.03
+    k = O.RBF(Q, ARD=True)
+    names = ('X', 'Y', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    vals = dict(X=X, Y=Y, Z=Z, noise=noise, qm=qm, qW=qW, qd=qd, ls=ls, var=var)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    o_noise = lv['noise'][None] if nshape != '1P' else lv['noise']          # (1,N,D') heteroscedastic; (1,D) per-output
+    logL = O.svgp_log_pdf(k, lv['X'], lv['Y'][None], lv['Z'][None], o_noise, lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-6, log_pdf_scaling=1.5)
+    grads = torch.autograd.grad(logL.mean(), [lv[n] for n in names])
+    r = ops.svgp_logpdf('rbf', _dev(X, dtype), _dev(Y[None], dtype), _dev(Z, dtype), _dev(noise, dtype), _dev(qm, dtype), _dev(qW, dtype),
+                        _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=1.5, gscale=1.0 / S, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')
+    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)

@@ -145,3 +145,42 @@ def test_minibatch_loop_with_rv_scaling_runs_and_scales(golden_dir):
                          O.T(qd)[None], {'rbf_lengthscale': O.T(np.ones((1, Q))), 'rbf_variance': O.T([[1.0]])}, jitter=1e-6,
                          log_pdf_scaling=N / Bsz)
     assert abs(loss0 - float(-ref[0])) < 1e-8 * abs(float(ref[0]))
+
+
+def test_svgp_heteroscedastic_noise_through_the_api(golden_dir):
+    """testing/modules/svgpregression_test.py:142-167 (test_log_pdf_w_samples_of_noise_var): noise_var Variable of shape (N, D), D = 2,
+    one MAP iteration.  The reference only smoke-tests it; here the loss of that iteration is also checked against the oracle."""
+    from oracle import gp_oracle as O
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import Inference, MAP
+    g = np.load(os.path.join(golden_dir, 'kat_svgp.npz'))
+    rng = np.random.RandomState(7)
+    D = 2
+    X, Z = g['X'], g['Z']
+    Y = rng.rand(10, D)
+    qm = rng.rand(3, D)
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 3))
+    m.Z = Variable(shape=(3, 3), initial_value=_t(Z))
+    m.noise_var = Variable(transformation=PositiveTransformation(), shape=(m.N, D))
+    kernel = RBF(input_dim=3, ARD=True, variance=_t(g['var']), lengthscale=_t(g['ls']), dtype=DT)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, D), dtype=DT)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-8
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.initialize(X=X.shape, Y=Y.shape)
+    infr.params[gp._extra_graphs[0].qU_mean] = _t(qm)
+    infr.params[gp._extra_graphs[0].qU_cov_W] = _t(g['qW'])
+    infr.params[gp._extra_graphs[0].qU_cov_diag] = _t(g['qd'])
+    noise0 = infr.params[m.noise_var].detach().cpu().double()          # the randomly initialised (N, D) noise, constrained space
+    assert noise0.shape[-2:] == (10, D)
+    loss, _ = infr.run(X=_t(X), Y=_t(Y), max_iter=1)
+    k = O.RBF(3, ARD=True)
+    ref = O.svgp_log_pdf(k, O.T(X)[None], O.T(Y)[None], O.T(Z)[None], noise0.reshape(1, 10, D), O.T(qm)[None], O.T(g['qW'])[None],
+                         O.T(g['qd'])[None], {k.name + '_lengthscale': O.T(g['ls'])[None], k.name + '_variance': O.T(g['var'])[None]},
+                         jitter=1e-8)
+    assert abs(float(-loss) - float(ref[0])) < 1e-8 * max(1.0, abs(float(ref[0])))
