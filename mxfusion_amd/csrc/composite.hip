@@ -321,6 +321,13 @@ __global__ void svgp_finalize_kernel(int S, int64_t B, int64_t M, int P, const d
     if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * P * beta * (double)B);
 }
 
+// materialised-Gram mode (any kernel with an autograd-capable K on the host: Add / Multiply / Linear ... ): the caller passes
+// Kuu (M x M, without jitter), Kuf (M x B), Kdiag (B) and receives d/dKuu, d/dKuf, d/dKdiag instead of kernel-parameter gradients
+template <typename T>
+struct SvgpMat { const T* Kuu = nullptr; const T* Kuf = nullptr; const T* Kdiag = nullptr; T* dKuu = nullptr; T* dKuf = nullptr; T* dKdiag = nullptr; };
+__global__ void add_diag_kernel(int64_t n, double* __restrict__ A, double v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) A[i * n + i] += v;
+}
 // ---- heteroscedastic / per-output noise (svgp_regression.py:61-67): noise is (nrows, ncols), nrows in {1,B}, ncols in {1,P} ------
 // one thread per column n: beta_d = 1/noise[n|0][d|0], bs = sum_d beta_d, e = y - u, q = k^T H0 k;
 //   l_s += -1/2 sum_d (beta_d e_d^2 + log 2pi + log noise_d) - 1/2 bs (var - q)
@@ -328,9 +335,11 @@ __global__ void svgp_finalize_kernel(int S, int64_t B, int64_t M, int P, const d
 template <typename T>
 __global__ __launch_bounds__(256) void svgp_het_mid_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf, T* __restrict__ Text,
                                                            const T* __restrict__ Y, int64_t sY, const T* __restrict__ w, const T* __restrict__ noise,
-                                                           int64_t nrows, int ncols, const double* __restrict__ var, double a1, int want_grad,
-                                                           T* __restrict__ Eb, T* __restrict__ Ksc, T* __restrict__ dY, int dY_shared,
-                                                           T* __restrict__ dnoise, double* __restrict__ scal /* [S][2]: l_s, sum bs */) {
+                                                           int64_t nrows, int ncols, const double* __restrict__ var,
+                                                           const T* __restrict__ kdiag /* per column, or NULL -> var[0] */, double a1,
+                                                           int want_grad, T* __restrict__ Eb, T* __restrict__ Ksc, T* __restrict__ dY,
+                                                           int dY_shared, T* __restrict__ dnoise, T* __restrict__ dkdiag,
+                                                           double* __restrict__ scal /* [S][2]: l_s, sum bs */) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= SB) return;
     const int64_t s = n / B, nb = n % B;
@@ -360,7 +369,8 @@ __global__ __launch_bounds__(256) void svgp_het_mid_kernel(int64_t SB, int64_t B
             Ksc[m * SB + n] = (T)(0.5 * a1 * bs * k);
         }
     }
-    const double vk = var[0];
+    const double vk = kdiag ? (double)kdiag[n] : var[0];
+    if (want_grad && dkdiag) dkdiag[n] = (T)(-0.5 * a1 * bs);
     atomic_add(scal + 2 * s, -0.5 * (e2b + lg) - 0.5 * bs * (vk - q));
     atomic_add(scal + 2 * s + 1, bs);
     if (!want_grad) return;
@@ -390,10 +400,12 @@ template <typename T>
 int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P, const T* X, int64_t sX, const T* Y,
                       int64_t sY, const T* Z, const T* noise, int64_t nrows, int ncols, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
                       double jitter, double scaling, double gscale, T* logL, int* info, int want_grad, T* dX, T* dY, T* dZ, T* dnoise,
-                      T* dmu, T* dW, T* dSdiag, T* dls, T* dvar, hipStream_t st) {
+                      T* dmu, T* dW, T* dSdiag, T* dls, T* dvar, hipStream_t st, SvgpMat<T> mat = SvgpMat<T>()) {
     if (P > 8) MXF_FAIL(h, -3, "mxf_svgp_logpdf: P > 8 outputs not supported");
     if ((nrows != 1 && nrows != B) || (ncols != 1 && ncols != P)) MXF_FAIL(h, -2, "mxf_svgp_logpdf: noise_var must be (1|B, 1|P)");
-    const bool het = nrows > 1 || ncols > 1;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
+    const bool use_mat = mat.Kuu != nullptr;
+    if (use_mat && S != 1) MXF_FAIL(h, -3, "mxf_svgp_logpdf_mat: one sample per call");
+    const bool het = nrows > 1 || ncols > 1 || use_mat;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
     const int SS = (sX == 0 && sY == 0) ? 1 : S;   // samples that need their own columns
     // when X is shared but Y is sampled we still lay S copies of the columns (rare); X columns repeat
@@ -426,7 +438,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
-    CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); if (!het) CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
+    if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); } if (!het) CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
 #undef CONV
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
@@ -436,13 +448,23 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
     if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
     hipStream_t sd_ = h->side;
-    rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu (+jitter) :69-72
+    if (use_mat) {
+        hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, mat.Kuu, MM, Lm, MM);
+        if (jitter != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(gridn(M)), dim3(256), 0, st, M, Lm, jitter);
+        rc = 0;
+    } else {
+        rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu (+jitter) :69-72
+    }
     if (rc) return rc;
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));
     MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
     // side chain
-    rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);              // Kuf_all = k(Z, X_all) :73
-    if (rc) return rc;
+    if (use_mat) {
+        MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
+    } else {
+        rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
+        if (rc) return rc;
+    }
     if (want_grad && !het) {
         // Psi2 = Kuf Kuf^T depends on neither the core nor the T-GEMM nor the reverse pass: it gets its own stream and starts at once.
         // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM (sequential operand streams;
@@ -516,15 +538,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (want_grad) {
             dvdir = sc + 5;
             if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
-            if (dZ) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
-            if (dls) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
-            if (dvar) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
-            if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
+            if (dZ && !use_mat) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
+            if (dls && !use_mat) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
+            if (dvar && !use_mat) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
+            if (dX && !use_mat) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
             if (dnoise) MXF_HIP(h, hipMemsetAsync(dnoise, 0, sizeof(T) * (size_t)nrows * ncols, st));
         }
         T* Ksc = Kfu;   // the transposed-Gram slot is unused on this path
         hipLaunchKernelGGL((svgp_het_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
-                           (const T*)wT, noise, nrows, ncols, (const D*)vard, a1, want_grad, Eb, Ksc, dY, dY_shared, dnoise, scal);
+                           (const T*)wT, noise, nrows, ncols, (const D*)vard, mat.Kdiag, a1, want_grad, Eb, Ksc, dY, dY_shared, dnoise,
+                           mat.dKdiag, scal);
         hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
                            (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
         MXF_LAUNCH_CHECK(h);
@@ -534,8 +557,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, SB, 1.0, Kuf, SB, 0, Eb, P, 0, 0.0, R, P, 0, 1, 0, st);
         if (rc) return rc;
-        rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, Text, SB, 0, dZ, dX, dls, dvar, st);
-        if (rc) return rc;
+        if (use_mat) {
+            if (mat.dKuf) MXF_HIP(h, hipMemcpyAsync(mat.dKuf, Text, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, st));
+        } else {
+            rc = mxf_gram_bwd_internal(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, Text, SB, 0, dZ, dX, dls, dvar, st);
+            if (rc) return rc;
+        }
     } else if (!want_grad) {
         hipLaunchKernelGGL((svgp_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
                            (const T*)wT, noise, a1, 0, (T*)nullptr, (T*)nullptr, 0, scal);
@@ -609,16 +636,20 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     if (dmu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (T)1, (const D*)dmud, dmu, 0);
     // Kuu-side reverse mode in float64, then added to the streaming-side gradients
-    MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
-    MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
-    MXF_HIP(h, hipMemsetAsync(dvc, 0, sizeof(D) * 4, st));
-    rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
-    if (rc) return rc;
-    if (dZ) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(M * Q)), dim3(256), 0, st, M * Q, (T)1, (const D*)dZc, dZ, 1);
-    if (dls) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(lsn)), dim3(64), 0, st, (int64_t)lsn, (T)1, (const D*)dlsc, dls, 1);
-    if (dvar) {
-        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
-        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
+    if (use_mat) {
+        if (mat.dKuu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (T)1, (const D*)dKuu, mat.dKuu, 0);
+    } else {
+        MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
+        MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
+        MXF_HIP(h, hipMemsetAsync(dvc, 0, sizeof(D) * 4, st));
+        rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
+        if (rc) return rc;
+        if (dZ) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(M * Q)), dim3(256), 0, st, M * Q, (T)1, (const D*)dZc, dZ, 1);
+        if (dls) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(lsn)), dim3(64), 0, st, (int64_t)lsn, (T)1, (const D*)dlsc, dls, 1);
+        if (dvar) {
+            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
+            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
+        }
     }
     if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
@@ -873,6 +904,35 @@ extern "C" int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int
     return svgp_dispatch(h, "mxf_svgp_logpdf_het", kind, dtype, S, B, M, Q, P, X, strideS_X, Y, strideS_Y, Z, noise_var, noise_rows, noise_cols,
                          qU_mean, qU_cov_W, qU_cov_diag, lengthscale, ard, variance, jitter, scaling, gscale, logL, info, want_grad, dX, dY, dZ,
                          dnoise, dmu, dW, dSdiag, dls, dvar, stream);
+}
+
+extern "C" int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int64_t B, int64_t M, int P, const void* Kuu, const void* Kuf, const void* Kdiag,
+                                   const void* Y, const void* noise_var, int64_t noise_rows, int noise_cols, const void* qU_mean,
+                                   const void* qU_cov_W, const void* qU_cov_diag, double jitter, double scaling, double gscale, void* logL,
+                                   int* info, int want_grad, void* dKuu, void* dKuf, void* dKdiag, void* dY, void* dnoise, void* dmu,
+                                   void* dW, void* dSdiag, void* stream) {
+    if (!h) return -1;
+    if (B <= 0 || M <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: bad shape");
+    if (!Kuu || !Kuf || !Kdiag || !Y || !noise_var || !qU_mean || !qU_cov_W || !qU_cov_diag || !logL) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MXF_F32) {
+        SvgpMat<float> m; m.Kuu = (const float*)Kuu; m.Kuf = (const float*)Kuf; m.Kdiag = (const float*)Kdiag;
+        m.dKuu = (float*)dKuu; m.dKuf = (float*)dKuf; m.dKdiag = (float*)dKdiag;
+        return svgp_logpdf_typed<float>(h, MXF_K_RBF, dtype, 1, B, M, 1, P, (const float*)Kuf /*unused X*/, 0, (const float*)Y, 0, nullptr,
+                                        (const float*)noise_var, noise_rows, noise_cols, (const float*)qU_mean, (const float*)qU_cov_W,
+                                        (const float*)qU_cov_diag, nullptr, 0, nullptr, jitter, scaling, gscale, (float*)logL, info, want_grad,
+                                        nullptr, (float*)dY, nullptr, (float*)dnoise, (float*)dmu, (float*)dW, (float*)dSdiag, nullptr, nullptr, st, m);
+    }
+    if (dtype == MXF_F64) {
+        SvgpMat<double> m; m.Kuu = (const double*)Kuu; m.Kuf = (const double*)Kuf; m.Kdiag = (const double*)Kdiag;
+        m.dKuu = (double*)dKuu; m.dKuf = (double*)dKuf; m.dKdiag = (double*)dKdiag;
+        return svgp_logpdf_typed<double>(h, MXF_K_RBF, dtype, 1, B, M, 1, P, (const double*)Kuf, 0, (const double*)Y, 0, nullptr,
+                                         (const double*)noise_var, noise_rows, noise_cols, (const double*)qU_mean, (const double*)qU_cov_W,
+                                         (const double*)qU_cov_diag, nullptr, 0, nullptr, jitter, scaling, gscale, (double*)logL, info, want_grad,
+                                         nullptr, (double*)dY, nullptr, (double*)dnoise, (double*)dmu, (double*)dW, (double*)dSdiag, nullptr, nullptr,
+                                         st, m);
+    }
+    MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: bad dtype %d", dtype);
 }
 
 extern "C" int mxf_sgp_logpdf(mxf_handle h, int kind, int dtype, int64_t B, int64_t M, int Q, int P, const void* X, const void* Y,

@@ -57,6 +57,28 @@ class SVGPLogPdfFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(out)
 
 
+class SVGPMatLogPdfFn(torch.autograd.Function):
+    """mxf_svgp_logpdf_mat for ONE sample (arrays carry a unit sample axis): the bound from materialised Kuu / Kuf / Kdiag; their
+    gradients flow on into the kernels' own reverse mode (combination kernels)."""
+
+    @staticmethod
+    def forward(ctx, jitter, scaling, Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag):
+        want = any(ctx.needs_input_grad[2:])
+        r = ops.svgp_logpdf_mat(Kuu[0], Kuf[0], Kdiag[0], Y[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0],
+                                jitter=jitter, scaling=scaling, gscale=1.0, want_grad=want)
+        if want:
+            ctx.grads = (r['dKuu'], r['dKuf'], r['dKdiag'], r['dY'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'])
+            ctx.shapes = tuple(t.shape for t in (Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag))
+        ctx.mark_non_differentiable(r['info'])
+        return r['logL'], r['info']
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        c = g.sum()
+        out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:])]
+        return (None, None) + tuple(out)
+
+
 class SGPLogPdfFn(torch.autograd.Function):
     """mxf_sgp_logpdf for ONE sample (arrays carry a unit sample axis); returns logL (1,), wv, L, LA."""
 

@@ -15,7 +15,7 @@ from ...components.variables.var_trans import PositiveTransformation
 from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
-from ._fused import SVGPLogPdfFn
+from ._fused import SVGPLogPdfFn, SVGPMatLogPdfFn
 
 
 def _S(t):
@@ -43,8 +43,7 @@ class SVGPRegressionLogPdf(VariationalInference):
         kern_params = kern.fetch_parameters(variables)
         spec = kern.fused_spec()
         if spec is None:
-            raise NotImplementedError('SVGPRegressionLogPdf on MI355X supports a single stationary kernel '
-                                      '(RBF / Matern12/32/52); combination kernels are a next-row item (SURVEY 8f)')
+            return self._compute_materialised(F, variables, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params, has_mean)
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
@@ -65,6 +64,22 @@ class SVGPRegressionLogPdf(VariationalInference):
             info = torch.stack([o[1] for o in outs]).sum(0)
         self._last_info = info
         return logL
+
+
+    def _compute_materialised(self, F, variables, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params, has_mean):
+        """Combination kernels (add_kernel.py:44-68, multiply_kernel.py:44-67): Kuu / Kuf / Kdiag come from kern.K (each sub-kernel one
+        mxf_gram pass with its own reverse mode) and the bound from mxf_svgp_logpdf_mat, one call per sample."""
+        if has_mean:
+            Y = Y - variables[self.model.mean]
+        Kuu = kern.K(F, Z, **kern_params)
+        Kuf = kern.K(F, Z, X, **kern_params)
+        Kdiag = kern.Kdiag(F, X, **kern_params)
+        ops_in = (Kuu, Kuf, Kdiag, Y, noise_var, mu, S_W, S_diag)
+        S = max(_S(t) for t in ops_in)
+        pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
+        outs = [SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *[pick(t, s) for t in ops_in]) for s in range(S)]
+        self._last_info = torch.stack([o[1] for o in outs]).sum(0)
+        return torch.cat([o[0] for o in outs])
 
 
 class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):

@@ -145,3 +145,50 @@ def test_svgp_logpdf_heteroscedastic_vs_oracle(dtype, tol, nshape, B, M, Q, P, S
     gtol = tol * 50 if dtype == torch.float64 else 5e-3
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
+
+
+class _MatKernel(object):
+    """oracle-side stand-in kernel whose K / Kdiag return fixed leaf tensors, so that autograd yields d/dKuu, d/dKuf, d/dKdiag."""
+    name = 'mat'
+
+    def __init__(self, Kuu, Kuf, Kdiag):
+        self.Kuu, self.Kuf, self.Kdiag_ = Kuu, Kuf, Kdiag
+
+    def K(self, X, X2=None, **kw):
+        return self.Kuu[None] if X2 is None else self.Kuf[None]
+
+    def Kdiag(self, X, **kw):
+        return self.Kdiag_[None]
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('nshape', ['11', 'BP'])
+def test_svgp_logpdf_mat_vs_oracle(dtype, tol, nshape):
+    """mxf_svgp_logpdf_mat: the bound and its reverse mode w.r.t. materialised Kuu / Kuf / Kdiag (any PSD Kuu, any Kuf)."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(5)
+    B, M, P = 400, 40, 2
+    A = rng.randn(M, M)
+    Kuu = A @ A.T / M + np.eye(M) * (0.5 if dtype == torch.float64 else 2.0)
+    Kuf = rng.randn(M, B) * 0.3
+    Kdiag = rng.rand(B) + 1.0
+    Y = rng.randn(B, P)
+    qm, qW, qd = rng.randn(M, P) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    noise = rng.rand(*{'11': (1,), 'BP': (B, P)}[nshape]) * 0.2 + 0.05
+    names = ('Kuu', 'Kuf', 'Kdiag', 'Y', 'noise', 'qm', 'qW', 'qd')
+    vals = dict(Kuu=Kuu, Kuf=Kuf, Kdiag=Kdiag, Y=Y, noise=noise, qm=qm, qW=qW, qd=qd)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    k = _MatKernel(lv['Kuu'], lv['Kuf'], lv['Kdiag'])
+    logL = O.svgp_log_pdf(k, torch.zeros(1, B, 1, dtype=torch.float64), lv['Y'][None], torch.zeros(1, M, 1, dtype=torch.float64),
+                          lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None], {'mat_unused': torch.zeros(1, 1, dtype=torch.float64)},
+                          jitter=1e-6, log_pdf_scaling=3.0)
+    grads = torch.autograd.grad(logL.sum(), [lv[n] for n in names])
+    r = ops.svgp_logpdf_mat(*[_dev(vals[n], dtype) for n in names], jitter=1e-6, scaling=3.0, gscale=1.0, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')
+    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    for n, key in zip(names, ('dKuu', 'dKuf', 'dKdiag', 'dY', 'dnoise', 'dmu', 'dW', 'dSdiag')):
+        got, ref = r[key], grads[names.index(n)]
+        if key == 'dKuu':      # autograd of the oracle gives the gradient w.r.t. an unconstrained (non-symmetric) Kuu: compare symmetrised
+            got, ref = 0.5 * (got + got.T), 0.5 * (ref + ref.T)
+        _close(got.reshape(ref.shape), ref, gtol, key)

@@ -184,3 +184,93 @@ def test_svgp_heteroscedastic_noise_through_the_api(golden_dir):
                          O.T(g['qd'])[None], {k.name + '_lengthscale': O.T(g['ls'])[None], k.name + '_variance': O.T(g['var'])[None]},
                          jitter=1e-8)
     assert abs(float(-loss) - float(ref[0])) < 1e-8 * max(1.0, abs(float(ref[0])))
+
+
+@pytest.mark.parametrize('latent', [False, True])
+def test_svgp_with_add_kernel_through_the_api(latent):
+    """The deep-GP configuration's layer: SVGPRegression with AddKernel(Matern52, RBF) (add_kernel.py:44-68), plain and
+    with latent (sampled) inputs as in svgpregression_test.py:357-385; first-step loss and flat gradient vs the oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, StochasticVariationalInference, BatchInferenceLoop, create_Gaussian_meanfield
+    rng = np.random.RandomState(3)
+    N, Q, M, S = 50, 3, 7, 3
+    X, Y, Z = rng.uniform(-2, 2, (N, Q)), rng.randn(N, 1), rng.uniform(-2, 2, (M, Q))
+    ls1, ls2, v1, v2, noise = np.array([1.3]), np.array([0.7]), np.array([0.9]), np.array([0.4]), np.array([0.2])
+    qm, qW, qd = rng.randn(M, 1) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    eps = rng.randn(S, N, Q)
+    kern = Matern52(Q, variance=_t(v1), lengthscale=_t(ls1), dtype=DT) + RBF(Q, variance=_t(v2), lengthscale=_t(ls2), dtype=DT)
+    m = Model()
+    m.N = Variable()
+    m.X = Normal.define_variable(mean=0, variance=1, shape=(m.N, Q)) if latent else Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=_t(Z))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(noise))
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=DT)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    grads, losses = [], []
+
+    class Rec(BatchInferenceLoop):
+        def _exchange(self, param_dict):
+            grads.append(param_dict.flat.grad.clone())
+
+        def run(self, infr_executor, data, **kw):
+            def wrapped(*a):
+                out = infr_executor(*a)
+                losses.append(float(out[0]))
+                return out
+            return super(Rec, self).run(wrapped, data, **kw)
+    if latent:
+        q = create_Gaussian_meanfield(model=m, observed=[m.Y], dtype=DT)
+        qX = q[m.X].factor
+        qX._rand_gen = MockRandomGenerator(_t(eps.reshape(-1)))
+        alg = StochasticVariationalInference(model=m, posterior=q, num_samples=S, observed=[m.Y])
+        data = dict(Y=_t(Y))
+    else:
+        alg = MAP(model=m, observed=[m.X, m.Y])
+        data = dict(X=_t(X), Y=_t(Y))
+    infr = GradBasedInference(alg, grad_loop=Rec(), dtype=DT)
+    infr.initialize(**{k: v.shape for k, v in data.items()})
+    infr.params[gp._extra_graphs[0].qU_mean] = _t(qm)
+    infr.params[gp._extra_graphs[0].qU_cov_W] = _t(qW)
+    infr.params[gp._extra_graphs[0].qU_cov_diag] = _t(qd)
+    if latent:
+        infr.params[qX.mean] = _t(X)
+        infr.params[qX.variance] = _t(np.full((N, Q), 0.01))
+    infr.run(max_iter=1, learning_rate=1e-3, **data)
+    loss = losses[0]
+
+    ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
+    sp = O.softplus
+    raw = {n: O.inv_softplus(O.T(v)).clone().requires_grad_(True) for n, v in dict(ls1=ls1, ls2=ls2, v1=v1, v2=v2, noise=noise, qd=qd).items()}
+    lin = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(Z=Z, qm=qm, qW=qW).items()}
+    kp = {'add_matern52_lengthscale': sp(raw['ls1'])[None], 'add_matern52_variance': sp(raw['v1'])[None],
+          'add_rbf_lengthscale': sp(raw['ls2'])[None], 'add_rbf_variance': sp(raw['v2'])[None]}
+    if latent:
+        xm = O.T(X).clone().requires_grad_(True)
+        xv_raw = O.inv_softplus(O.T(np.full((N, Q), 0.01))).clone().requires_grad_(True)
+        xv = sp(xv_raw)
+        Xs = xm[None] + O.T(eps) * torch.sqrt(xv)[None]
+        logq = O.normal_log_pdf(xm[None], xv[None], Xs).reshape(S, -1).sum(-1)
+        logp = O.normal_log_pdf(torch.zeros(1, dtype=torch.float64), torch.ones(1, dtype=torch.float64), Xs).reshape(S, -1).sum(-1)
+    else:
+        Xs, logq, logp = O.T(X)[None], 0.0, 0.0
+    logL = O.svgp_log_pdf(ok, Xs, O.T(Y)[None], lin['Z'][None], sp(raw['noise'])[None], lin['qm'][None], lin['qW'][None], sp(raw['qd'])[None],
+                          kp, jitter=1e-6)
+    obj = -((logL + logp - logq).mean() if latent else logL.sum())
+    obj.backward()
+    assert abs(float(loss) - float(obj)) < 1e-8 * max(1.0, abs(float(obj)))
+    P = infr.params
+    sub = {k.name: k for k in kern.sub_kernels}
+    checks = [(m.noise_var, raw['noise']), (sub['matern52'].lengthscale, raw['ls1']), (sub['matern52'].variance, raw['v1']),
+              (sub['rbf'].lengthscale, raw['ls2']), (sub['rbf'].variance, raw['v2']), (m.Z, lin['Z']),
+              (gp._extra_graphs[0].qU_mean, lin['qm']), (gp._extra_graphs[0].qU_cov_W, lin['qW']), (gp._extra_graphs[0].qU_cov_diag, raw['qd'])]
+    if latent:
+        checks += [(qX.mean, xm), (qX.variance, xv_raw)]
+    for var, ref in checks:
+        o, n, _ = P._slices[var.uuid]
+        assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
