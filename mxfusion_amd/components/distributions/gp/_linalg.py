@@ -1,0 +1,92 @@
+"""autograd bridges over the dense linear algebra of the C ABI (mxf_potrf / mxf_trsm / mxf_trtri / mxf_gemm) with closed-form
+reverse modes: no reverse-mode Cholesky is needed anywhere on the path."""
+import math
+
+import torch
+
+from .... import ops
+
+
+class CholLogPdfFn(torch.autograd.Function):
+    """logL[s] = -c * sumlogdiag(chol(K[s])) - 1/2 (|L^-1 Y|^2 + N P log 2pi), c = P unless `logdet_mult` is given
+    (gp.py:113-122, gp_regression.py:61-70).  Reverse mode: dK = 1/2 (alpha alpha^T - c K^-1), dY = -alpha, alpha = K^-1 Y.
+    Also returns the factor L, L^-1 Y and the potrf info word."""
+
+    @staticmethod
+    def forward(ctx, K, Y, logdet_mult=None):
+        SK, N, P = K.shape[0], K.shape[-1], Y.shape[-1]
+        S = max(SK, Y.shape[0])                                   # either operand may be shared over the sample axis
+        c = float(P if logdet_mult is None else logdet_mult)
+        L, info = ops.potrf_(K.contiguous().clone())
+        LinvY = ops.trsm_(L, Y.expand(S, N, P).contiguous().clone())
+        logL = -c * ops.sumlogdiag(L) - 0.5 * ((LinvY ** 2).reshape(S, -1).sum(-1) + N * P * math.log(2 * math.pi))
+        if any(ctx.needs_input_grad[:2]):
+            Linv = ops.trtri(L)
+            alpha = ops.gemm(Linv, LinvY, transA=True)
+            dK = ops.gemm(alpha, alpha, transB=True, alpha=0.5)
+            Kinv = ops.gemm(Linv, Linv, transA=True)
+            dK = dK - (0.5 * c) * Kinv
+            ctx.save_for_backward(dK, alpha)
+            ctx.yshape, ctx.kshape = Y.shape, K.shape
+        ctx.mark_non_differentiable(L, LinvY, info)
+        return logL, L, LinvY, info
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        dK, alpha = ctx.saved_tensors
+        gK = dK * g.reshape(-1, 1, 1)
+        gY = -alpha * g.reshape(-1, 1, 1)
+        if ctx.kshape[0] == 1 and gK.shape[0] > 1:
+            gK = gK.sum(0, keepdim=True)
+        if ctx.yshape[0] == 1 and gY.shape[0] > 1:
+            gY = gY.sum(0, keepdim=True)
+        return gK, gY, None
+
+
+class SpdInverseFn(torch.autograd.Function):
+    """A = K^-1 for symmetric positive definite K (potrf + trtri + gemm); dK = -A G A."""
+
+    @staticmethod
+    def forward(ctx, K):
+        L, info = ops.potrf_(K.clone())
+        Linv = ops.trtri(L)
+        A = ops.gemm(Linv, Linv, transA=True)
+        ctx.save_for_backward(A)
+        ctx.mark_non_differentiable(info)
+        return A, info
+
+    @staticmethod
+    def backward(ctx, G, *_):
+        A, = ctx.saved_tensors
+        T = ops.gemm(A, G.contiguous())
+        return ops.gemm(T, A, alpha=-1.0)
+
+
+class MatmulFn(torch.autograd.Function):
+    """C = op(A) op(B) through mxf_gemm (batched over the sample axis), with its two reverse-mode GEMMs."""
+
+    @staticmethod
+    def forward(ctx, A, B, transA, transB):
+        ctx.tA, ctx.tB = transA, transB
+        ctx.save_for_backward(A, B)
+        return ops.gemm(A, B, transA=transA, transB=transB)
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        G = G.contiguous()
+        tA, tB = ctx.tA, ctx.tB
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            gA = ops.gemm(B, G, transA=tB, transB=True) if tA else ops.gemm(G, B, transB=not tB)
+            if A.shape[0] == 1 and gA.shape[0] > 1:
+                gA = gA.sum(0, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            gB = ops.gemm(G, A, transA=True, transB=tA) if tB else ops.gemm(A, G, transA=not tA)
+            if B.shape[0] == 1 and gB.shape[0] > 1:
+                gB = gB.sum(0, keepdim=True)
+        return gA, gB, None, None
+
+
+def matmul(A, B, transA=False, transB=False):
+    return MatmulFn.apply(A, B, transA, transB)

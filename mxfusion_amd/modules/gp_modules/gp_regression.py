@@ -17,41 +17,14 @@ from ...components.variables.runtime_variable import arrays_as_samples
 from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
+from ...components.distributions.gp._linalg import CholLogPdfFn
 from ._fused import GPLogPdfFn
 
 
 def _chol_logpdf_generic(F, K, Y):
     """log N(Y | 0, K) per sample from an explicit K (any kernel with an autograd-capable K()): value via
     mxf_potrf / mxf_trsm, reverse mode via dK = 1/2 (alpha alpha^T - P K^-1)."""
-    return _CholLogPdfFn.apply(K, Y)
-
-
-class _CholLogPdfFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, K, Y):
-        import math
-        S, N, P = K.shape[0], K.shape[-1], Y.shape[-1]
-        L, info = ops.potrf_(K.clone())
-        LinvY = ops.trsm_(L, Y.expand(S, N, P).clone())
-        logL = -P * ops.sumlogdiag(L) - 0.5 * ((LinvY ** 2).reshape(S, -1).sum(-1) + N * P * math.log(2 * math.pi))
-        if any(ctx.needs_input_grad):
-            Linv = ops.trtri(L)
-            alpha = ops.gemm(Linv, LinvY, transA=True)
-            dK = ops.gemm(alpha, alpha, transB=True, alpha=0.5)
-            ops.gemm(Linv, Linv, transA=True, alpha=-0.5 * P, beta=1.0, out=dK)
-            ctx.save_for_backward(dK, alpha)
-            ctx.yshape = Y.shape
-        ctx.mark_non_differentiable(L, LinvY, info)
-        return logL, L, LinvY, info
-
-    @staticmethod
-    def backward(ctx, g, *_):
-        dK, alpha = ctx.saved_tensors
-        gK = dK * g.reshape(-1, 1, 1)
-        gY = -alpha * g.reshape(-1, 1, 1)
-        if ctx.yshape[0] == 1 and gY.shape[0] > 1:
-            gY = gY.sum(0, keepdim=True)
-        return gK, gY
+    return CholLogPdfFn.apply(K, Y)
 
 
 class GPRegressionLogPdf(VariationalInference):

@@ -639,6 +639,40 @@ def gp_dist_draw(kern, X, kern_params, eps, mean=None):
     return y + mean if mean is not None else y
 
 
+def _cond_gp_moments(kern, X, X_cond, Y_cond, kern_params, mean_cond=None):
+    """cond_gp.py:164-177 (shared by log_pdf_impl and draw_samples_impl)."""
+    K = kern.K(X, **kern_params)
+    Kc = kern.K(X_cond, X, **kern_params)
+    Kcc = kern.K(X_cond, **kern_params)
+    Lcc = potrf(Kcc)
+    LccInvKc = trsm(Lcc, Kc)
+    cov = K - syrk(LccInvKc, transpose=True)
+    L = potrf(cov)
+    if mean_cond is not None:
+        Y_cond = Y_cond - mean_cond
+    LccInvY = trsm(Lcc, Y_cond)
+    rv_mean = gemm2(LccInvKc, LccInvY, True, False)
+    return L, rv_mean
+
+
+def cond_gp_dist_log_pdf(kern, X, X_cond, Y_cond, rv, kern_params, mean=None, mean_cond=None, log_pdf_scaling=1.):
+    """cond_gp.py:124-183 -- including the reference's sum over the output axis BEFORE squaring (:179)."""
+    D = rv.shape[-1]
+    L, rv_mean = _cond_gp_moments(kern, X, X_cond, Y_cond, kern_params, mean_cond)
+    if mean is not None:
+        rv = rv - mean
+    LinvY = trsm(L, rv - rv_mean).sum(-1)
+    logdet_l = sumlogdiag(torch.abs(L))
+    return (-logdet_l * D - (LinvY ** 2 + LOG2PI).sum(-1) / 2) * log_pdf_scaling
+
+
+def cond_gp_dist_draw(kern, X, X_cond, Y_cond, kern_params, eps, mean=None, mean_cond=None):
+    """cond_gp.py:185-223."""
+    L, rv_mean = _cond_gp_moments(kern, X, X_cond, Y_cond, kern_params, mean_cond)
+    rv = trmm(L.expand(eps.shape[0], -1, -1), eps) + rv_mean
+    return rv + mean if mean is not None else rv
+
+
 # ----------------------------------------------------------------------------
 # Objective assembly: inference/{map,variational}.py + models/factor_graph.py:192-238
 # ----------------------------------------------------------------------------

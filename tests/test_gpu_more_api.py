@@ -274,3 +274,87 @@ def test_svgp_with_add_kernel_through_the_api(latent):
     for var, ref in checks:
         o, n, _ = P._slices[var.uuid]
         assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
+
+
+def test_two_layer_deep_gp_svi_step_matches_oracle():
+    """SURVEY 8f rank 1 (BASELINE config 5 in miniature): two chained SVGPRegression modules, first layer AddKernel(Matern52, RBF),
+    hidden layer H with a mean-field q(H) (inference/meanfield.py:24-44), StochasticVariationalInference with injected noise.
+    Loss and flat gradient of the first step vs the oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, BatchInferenceLoop, create_Gaussian_meanfield
+    rng = np.random.RandomState(11)
+    N, Q, Dh, M, S = 40, 3, 2, 6, 4
+    X, Y = rng.uniform(-2, 2, (N, Q)), rng.randn(N, 1)
+    Z0, Z1 = rng.uniform(-2, 2, (M, Q)), rng.randn(M, Dh)
+    p = dict(ls1=np.array([1.3]), v1=np.array([0.9]), ls2=np.array([0.7]), v2=np.array([0.4]), ls3=np.array([1.1, 0.8]), v3=np.array([1.2]),
+             n0=np.array([0.1]), n1=np.array([0.2]))
+    qm0, qW0, qd0 = rng.randn(M, Dh) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    qm1, qW1, qd1 = rng.randn(M, 1) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    hm, hv = rng.randn(N, Dh), np.full((N, Dh), 0.05)
+    eps = rng.randn(S, N, Dh)
+    k0 = Matern52(Q, variance=_t(p['v1']), lengthscale=_t(p['ls1']), dtype=DT) + RBF(Q, variance=_t(p['v2']), lengthscale=_t(p['ls2']), dtype=DT)
+    k1 = RBF(Dh, ARD=True, variance=_t(p['v3']), lengthscale=_t(p['ls3']), name='rbf_top', dtype=DT)
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z0 = Variable(shape=(M, Q), initial_value=_t(Z0))
+    m.Z1 = Variable(shape=(M, Dh), initial_value=_t(Z1))
+    m.noise0 = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(p['n0']))
+    m.noise1 = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(p['n1']))
+    m.H = SVGPRegression.define_variable(X=m.X, kernel=k0, noise_var=m.noise0, inducing_inputs=m.Z0, shape=(m.N, Dh), dtype=DT)
+    m.Y = SVGPRegression.define_variable(X=m.H, kernel=k1, noise_var=m.noise1, inducing_inputs=m.Z1, shape=(m.N, 1), dtype=DT)
+    g0, g1 = m.H.factor, m.Y.factor
+    g0.svgp_log_pdf.jitter = g1.svgp_log_pdf.jitter = 1e-6
+    q = create_Gaussian_meanfield(model=m, observed=[m.X, m.Y], dtype=DT)
+    qH = q[m.H].factor
+    qH._rand_gen = MockRandomGenerator(_t(eps.reshape(-1)))
+    grads, losses = [], []
+
+    class Rec(BatchInferenceLoop):
+        def _exchange(self, param_dict):
+            grads.append(param_dict.flat.grad.clone())
+
+        def run(self, infr_executor, data, **kw):
+            def wrapped(*a):
+                out = infr_executor(*a)
+                losses.append(float(out[0].detach()))
+                return out
+            return super(Rec, self).run(wrapped, data, **kw)
+    infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S, observed=[m.X, m.Y]), grad_loop=Rec(), dtype=DT)
+    infr.initialize(X=X.shape, Y=Y.shape)
+    for gp, (a, b, c) in ((g0, (qm0, qW0, qd0)), (g1, (qm1, qW1, qd1))):
+        infr.params[gp._extra_graphs[0].qU_mean] = _t(a)
+        infr.params[gp._extra_graphs[0].qU_cov_W] = _t(b)
+        infr.params[gp._extra_graphs[0].qU_cov_diag] = _t(c)
+    infr.params[qH.mean] = _t(hm)
+    infr.params[qH.variance] = _t(hv)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=1e-3)
+
+    sp = O.softplus
+    raw = {n: O.inv_softplus(O.T(v)).clone().requires_grad_(True) for n, v in dict(p, qd0=qd0, qd1=qd1, hv=hv).items()}
+    lin = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(Z0=Z0, Z1=Z1, qm0=qm0, qW0=qW0, qm1=qm1, qW1=qW1, hm=hm).items()}
+    ok0, ok1 = O.AddKernel([O.Matern52(Q), O.RBF(Q)]), O.RBF(Dh, ARD=True, name='rbf_top')
+    Hs = lin['hm'][None] + O.T(eps) * torch.sqrt(sp(raw['hv']))[None]
+    l0 = O.svgp_log_pdf(ok0, O.T(X)[None], Hs, lin['Z0'][None], sp(raw['n0'])[None], lin['qm0'][None], lin['qW0'][None], sp(raw['qd0'])[None],
+                        {'add_matern52_lengthscale': sp(raw['ls1'])[None], 'add_matern52_variance': sp(raw['v1'])[None],
+                         'add_rbf_lengthscale': sp(raw['ls2'])[None], 'add_rbf_variance': sp(raw['v2'])[None]}, jitter=1e-6)
+    l1 = O.svgp_log_pdf(ok1, Hs, O.T(Y)[None], lin['Z1'][None], sp(raw['n1'])[None], lin['qm1'][None], lin['qW1'][None], sp(raw['qd1'])[None],
+                        {'rbf_top_lengthscale': sp(raw['ls3'])[None], 'rbf_top_variance': sp(raw['v3'])[None]}, jitter=1e-6)
+    logq = O.normal_log_pdf(lin['hm'][None], sp(raw['hv'])[None], Hs).reshape(S, -1).sum(-1)
+    obj = -(l0 + l1 - logq).mean()
+    obj.backward()
+    assert abs(losses[0] - float(obj)) < 1e-8 * max(1.0, abs(float(obj)))
+    P = infr.params
+    sub = {k.name: k for k in k0.sub_kernels}
+    checks = [(m.noise0, raw['n0']), (m.noise1, raw['n1']), (sub['matern52'].lengthscale, raw['ls1']), (sub['matern52'].variance, raw['v1']),
+              (sub['rbf'].lengthscale, raw['ls2']), (sub['rbf'].variance, raw['v2']), (k1.lengthscale, raw['ls3']), (k1.variance, raw['v3']),
+              (m.Z0, lin['Z0']), (m.Z1, lin['Z1']), (qH.mean, lin['hm']), (qH.variance, raw['hv']),
+              (g0._extra_graphs[0].qU_mean, lin['qm0']), (g0._extra_graphs[0].qU_cov_W, lin['qW0']), (g0._extra_graphs[0].qU_cov_diag, raw['qd0']),
+              (g1._extra_graphs[0].qU_mean, lin['qm1']), (g1._extra_graphs[0].qU_cov_W, lin['qW1']), (g1._extra_graphs[0].qU_cov_diag, raw['qd1'])]
+    for var, ref in checks:
+        o, n, _ = P._slices[var.uuid]
+        assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
