@@ -358,3 +358,41 @@ def test_two_layer_deep_gp_svi_step_matches_oracle():
     for var, ref in checks:
         o, n, _ = P._slices[var.uuid]
         assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
+
+
+@pytest.mark.parametrize('square', [True, False])
+@pytest.mark.parametrize('S', [1, 3])
+@pytest.mark.parametrize('ard', [True, False])
+def test_linear_bias_white_kernels_reverse_mode(square, S, ard):
+    """Linear / Bias / White (kernels/linear.py:59-103, static.py:56-164) and their combination with a stationary
+    kernel (sum and product): K and d<K, G>/d(inputs, parameters) vs the oracle's autograd."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Linear, Bias, White
+    rng = np.random.RandomState(17 + S)
+    N, N2, Q = 9, 7, 3
+    X, X2 = rng.randn(S, N, Q), rng.randn(1, N2, Q)
+    lv, bv, wv = rng.rand(1, Q if ard else 1) + 0.3, rng.rand(1, 1) + 0.2, rng.rand(1, 1) + 0.1
+    rl, rv = rng.rand(1, 1) + 0.5, rng.rand(1, 1) + 0.5
+    G = rng.randn(S, N, N if square else N2)
+    kern = (Linear(Q, ARD=ard, dtype=DT) + Bias(Q, dtype=DT) + White(Q, dtype=DT)) * RBF(Q, dtype=DT)
+    okern = O.MultiplyKernel([O.AddKernel([O.AddKernel([O.Linear(Q, ARD=ard), O.Bias(Q)]), O.White(Q)]), O.RBF(Q)])   # '+' nests, kernel.py:149-164
+    vals = dict(X=X, X2=X2, lv=lv, bv=bv, wv=wv, rl=rl, rv=rv)
+    dev = {n: _t(v).requires_grad_(True) for n, v in vals.items()}
+    ora = {n: O.T(v).clone().requires_grad_(True) for n, v in vals.items()}
+    names = {'mul_add_add_linear_variances': 'lv', 'mul_add_add_bias_variance': 'bv', 'mul_add_white_variance': 'wv', 'mul_rbf_lengthscale': 'rl',
+             'mul_rbf_variance': 'rv'}
+    assert sorted(kern.parameters) == sorted(names)
+    K = kern.K(None, dev['X'], None if square else dev['X2'], **{k: dev[v] for k, v in names.items()})
+    Ko = okern.K(ora['X'], None if square else ora['X2'], **{k: ora[v] for k, v in names.items()})
+    assert np.allclose(K.detach().cpu().numpy(), Ko.detach().numpy(), rtol=1e-11, atol=1e-12)
+    (K * _t(G)).sum().backward()
+    (Ko * O.T(G)).sum().backward()
+    for n in vals:
+        if n == 'X2' and square:
+            continue
+        if ora[n].grad is None:          # White with an explicit X2 is identically zero (static.py:147-150)
+            assert dev[n].grad is None or float(dev[n].grad.abs().max()) == 0.0, n
+            continue
+        assert np.allclose(dev[n].grad.cpu().numpy(), ora[n].grad.numpy(), rtol=1e-9, atol=1e-10), n
+    Kd = kern.Kdiag(None, dev['X'], **{k: dev[v].detach() for k, v in names.items()})
+    Kdo = okern.Kdiag(ora['X'].detach(), **{k: ora[v].detach() for k, v in names.items()})
+    assert np.allclose(Kd.detach().cpu().numpy(), Kdo.numpy(), rtol=1e-11)
