@@ -4,6 +4,9 @@ import warnings
 import numpy as np
 import torch
 
+from ..util import serialization as ser
+from ..common.exceptions import SerializationError
+
 from ..common import config
 from ..common.exceptions import InferenceError
 from ..components.variables.variable import Variable
@@ -93,6 +96,94 @@ class Inference(object):
         for u, v in self.params._vars.items():
             if u in self.params:
                 print(v.name, u, self.params[v])
+
+    # ---- checkpoint (inference.py:179-310): the reference's zip layout, parameters keyed by UUID -------------------
+    def _graph_listing(self):
+        """graphs.json: per graph, every variable in registration order (deterministic for a given model script) with its
+        uuid / name / type.  (The reference dumps a networkx node-link graph; the payload files are identical in layout, the
+        graph file here carries what reconciliation needs: order, names and types.)"""
+        out = []
+        for g in self._graphs:
+            comps = []
+            for u, v in g.variables.items():
+                comps.append({'uuid': u, 'name': v.name, 'type': type(v).__name__, 'version': ser.__GRAPH_JSON_VERSION__,
+                              'var_type': str(getattr(v, 'type', None)), 'has_factor': v.factor is not None and type(v.factor).__name__})
+            out.append({'name': g.name, 'type': type(g).__name__, 'variables': comps})
+        return out
+
+    def get_serializable(self):
+        return {'observed': self.observed_variable_UUIDs}
+
+    def save(self, zip_filename=ser.DEFAULT_ZIP):
+        """inference.py:255-310: version.json, graphs.json, mxnet_parameters.npz (one array per parameter UUID, the stored
+        = unconstrained value, as gluon keeps it), mxnet_constants.npz, variable_constants.json, configuration.json."""
+        params = self.params.export_raw()
+        arr_consts, var_consts = {}, {}
+        for u, c in self.params.constants.items():
+            if isinstance(c, (int, float, np.integer, np.floating)):
+                var_consts[u] = c.item() if hasattr(c, 'item') else c
+            else:
+                arr_consts[u] = c
+        ser.write_zip(zip_filename,
+                      {ser.FILENAMES['graphs']: self._graph_listing(), ser.FILENAMES['variable_constants']: var_consts,
+                       ser.FILENAMES['configuration']: self.get_serializable(),
+                       ser.FILENAMES['version_file']: {'serialization_version': ser.SERIALIZATION_VERSION}},
+                      {ser.FILENAMES['mxnet_params']: params, ser.FILENAMES['mxnet_constants']: arr_consts})
+
+    def load(self, zip_filename=ser.DEFAULT_ZIP):
+        """inference.py:179-228: reconcile the saved graphs with the current ones ({saved uuid: current uuid} in
+        self._uuid_map) and load the parameters / constants through that map.  Call after initialize()."""
+        import zipfile
+        ver = ser.load_json_from_zip(zip_filename, ser.FILENAMES['version_file'])
+        if ver.get('serialization_version') != ser.SERIALIZATION_VERSION:
+            raise SerializationError('Serialization version of saved inference and running code are not the same.')
+        with zipfile.ZipFile(zip_filename, 'r') as zf:
+            saved_params = ser.load_parameters(ser.FILENAMES['mxnet_params'], zf)
+            saved_consts = ser.load_parameters(ser.FILENAMES['mxnet_constants'], zf)
+        var_consts = ser.load_json_from_zip(zip_filename, ser.FILENAMES['variable_constants'])
+        saved_graphs = ser.load_json_from_zip(zip_filename, ser.FILENAMES['graphs'])
+        current = self._graph_listing()
+        if len(saved_graphs) != len(current):
+            raise SerializationError('saved inference has %d graphs, the current one %d' % (len(saved_graphs), len(current)))
+        uuid_map = {}
+        for sg, cg in zip(saved_graphs, current):
+            if len(sg['variables']) != len(cg['variables']):
+                raise SerializationError('graph %s: %d saved variables vs %d current' % (cg['name'], len(sg['variables']), len(cg['variables'])))
+            for sv, cv in zip(sg['variables'], cg['variables']):
+                if sv['type'] != cv['type'] or sv['has_factor'] != cv['has_factor'] or \
+                        (sv['name'] != cv['name'] and sv['name'] != sv['uuid'] and cv['name'] != cv['uuid']):
+                    raise SerializationError('graph %s: saved component %s (%s) does not match current %s (%s)'
+                                             % (cg['name'], sv['name'], sv['type'], cv['name'], cv['type']))
+                uuid_map[sv['uuid']] = cv['uuid']
+        self._uuid_map = uuid_map
+        if not self._initialized:
+            raise SerializationError('load() needs an initialised inference (call initialize(...) first, as the reference tests do)')
+        for su, arr in saved_params.items():
+            cu = uuid_map.get(su)
+            if cu is None:
+                raise SerializationError('saved parameter %s has no counterpart in the current graphs' % su)
+            raw = self.params._to_tensor(arr)
+            if cu in self.params._slices:
+                o, n, shape = self.params._slices[cu]
+                if raw.numel() != n:
+                    raise SerializationError('saved parameter %s has %d elements, the current one %d' % (su, raw.numel(), n))
+                with torch.no_grad():
+                    self.params._flat[o:o + n] = raw.reshape(-1)
+            else:
+                self.params._fixed[cu] = raw
+                if cu not in self.params._vars:
+                    for g in self._graphs:
+                        if cu in g.variables:
+                            self.params._vars[cu] = g.variables[cu]
+        consts = {}
+        for su, arr in saved_consts.items():
+            if su in uuid_map:
+                consts[uuid_map[su]] = self.params._to_tensor(arr)
+        for su, c in var_consts.items():
+            if su in uuid_map:
+                consts[uuid_map[su]] = c
+        self.params.update_constants(consts)
+        return self
 
 
 class TransferInference(Inference):
