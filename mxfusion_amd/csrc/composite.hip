@@ -443,8 +443,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
     int rc;
-    static const int psi2_late = getenv("MXF_SVGP_PSI2_LATE") ? atoi(getenv("MXF_SVGP_PSI2_LATE")) : 0;
-    static const int psi2_reserve = getenv("MXF_SVGP_PSI2_RESERVE") ? atoi(getenv("MXF_SVGP_PSI2_RESERVE")) : 0;
+    static const int64_t psi2_ka = getenv("MXF_SVGP_PSI2_KA") ? atoll(getenv("MXF_SVGP_PSI2_KA")) : -1;
+    static const int psi2_ra = getenv("MXF_SVGP_PSI2_RA") ? atoi(getenv("MXF_SVGP_PSI2_RA")) : 148;
+    static const int psi2_rb = getenv("MXF_SVGP_PSI2_RB") ? atoi(getenv("MXF_SVGP_PSI2_RB")) : 16;
     // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
     if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
     hipStream_t sd_ = h->side;
@@ -457,47 +458,43 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     if (rc) return rc;
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));
+    hipStream_t s2_ = h->side2;
     MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
-    // side chain
+    MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_fork, 0));
+    // Enqueue order = priority order (the host needs ~5 us per launch and a step has ~280 of them): first the few launches that carry
+    // the bulk of the device work (Grams, Psi2), then the latency-critical Kuu chain, then the Su chain.
+    // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
     if (use_mat) {
         MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
     } else {
         rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
         if (rc) return rc;
     }
+    MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf ready (the T GEMM waits for it)
     if (want_grad && !het) {
-        // Psi2 = Kuf Kuf^T depends on neither the core nor the T-GEMM nor the reverse pass: it gets its own stream and starts at once.
+        // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream.
         // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM (sequential operand streams;
-        // the NT form on Kuf reads 256 K-strided streams per workgroup).  Its waves saturate the register file, so 16 CUs are left
-        // without a Psi2 workgroup for the latency-bound core chains that run meanwhile.
-        hipStream_t s2_ = h->side2;
+        // the NT form on Kuf reads 256 K-strided streams per workgroup), lower blocks only, split-K.
         rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
         if (rc) return rc;
-        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
-        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_join2, 0));
-        if (!psi2_late) {
-            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, 16);   // lower blocks only, split-K
+        // two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
+        // ~216 CUs, so that the core chains' f64 workgroups (a whole CU's LDS / registers each) still find free CUs; phase B (the rest)
+        // fills the chip.  Same-box A/B at 4 samples per GPU: 13.65 -> 12.95 ms per step; neutral at 32 samples.
+        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : 128 * M;
+        const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
+        if (KA > 0) {
+            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, KA, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, sd_, psi2_ra);
             if (rc) return rc;
-            hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
-            MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
         }
+        if (KA < SB) {
+            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB - KA, 1.0, Kfu + KA * M, M, 0, Kfu + KA * M, M, 0, KA > 0 ? 1.0 : 0.0, Psi2, M, 0, 1, 1,
+                                   sd_, psi2_rb);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
     }
-    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, M, (const D*)sd, Su);
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, sd_);       // Su = W W^T + diag(s) :76
-    if (rc) return rc;
-    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, sd_));
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, sd_);                                // Ls = chol(Su) :84
-    if (rc) return rc;
-    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, sd_);
-    if (rc) return rc;
-    if (want_grad) {
-        rc = mxf_trtri_internal(h, MXF_F64, 1, M, tmp, M, MM, Lsinv, M, MM, sd_);
-        if (rc) return rc;
-        rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, sd_);
-        if (rc) return rc;
-    }
-    MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
-    // main chain
+    // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
@@ -509,6 +506,22 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
+    // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
+    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s2_, M, (const D*)sd, Su);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
+    if (rc) return rc;
+    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, s2_));
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_);                                // Ls = chol(Su) :84
+    if (rc) return rc;
+    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, s2_);
+    if (rc) return rc;
+    if (want_grad) {
+        rc = mxf_trtri_internal(h, MXF_F64, 1, M, tmp, M, MM, Lsinv, M, MM, s2_);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, s2_);
+        if (rc) return rc;
+    }
+    MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));                                                // join
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
@@ -523,6 +536,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
 
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
     {
@@ -575,16 +589,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
         MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
-        if (psi2_late) {
-            // Psi2 (MFMA-bound) next to the fused reverse pass (VALU-bound) instead of next to the T GEMM (MFMA-bound)
-            hipStream_t s2_ = h->side2;
-            MXF_HIP(h, hipEventRecord(h->ev_aux, st));
-            MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux, 0));
-            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, s2_, psi2_reserve);
-            if (rc) return rc;
-            hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, s2_, Psi2, M, M, MM);
-            MXF_HIP(h, hipEventRecord(h->ev_join2, s2_));
-        }
         rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
                                          dY, dY_shared, R, scal, st);
         if (rc) return rc;
