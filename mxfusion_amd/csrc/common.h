@@ -133,6 +133,40 @@ __device__ __forceinline__ double wave_sum63(double v) {
     return v;
 }
 
+// ---- row-level reduce-scatter of N per-lane values (N = 2, 4, 8, 16) -------------------------------------------------------------
+// Input: every lane holds a[0..N-1].  Output: lane l of each 16-lane row holds  sum over the row's 16 lanes of a[l & (N-1)]
+// (all lanes valid; lanes with (l & 15) < N form one complete set per row).  A halving butterfly: at each level a lane keeps one
+// half of its values and receives the partner's partial sums of that half, so the cost is (N-1) DPP adds + 2(N-1) selects
+// instead of 4N DPP adds for N separate row reductions.  Partners (row_mirror, row_half_mirror, quad reverse, quad xor-1) always hold
+// the same half, so every level is ONE symmetric DPP move.
+template <int CTRL> __device__ __forceinline__ float mxf_dpp_mov(float v) { return MXF_DPP_F(v, CTRL, 0xf); }
+template <int CTRL> __device__ __forceinline__ double mxf_dpp_mov(double v) { return MXF_DPP_D(v, CTRL, 0xf); }
+
+template <typename T, int HALF, int CTRL>
+__device__ __forceinline__ void mxf_rs_level(T* a, bool upper) {
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const T keep = upper ? a[i + HALF] : a[i];
+        const T send = upper ? a[i] : a[i + HALF];
+        a[i] = keep + mxf_dpp_mov<CTRL>(send);
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ T row_reduce_scatter(T* a /* N values, clobbered */, int lane) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16, "row_reduce_scatter: N must be a power of two <= 16");
+    if (N >= 16) mxf_rs_level<T, 8, 0x140>(a, (lane & 8) != 0);                 // row_mirror        i <-> 15-i
+    if (N >= 8) mxf_rs_level<T, (N >= 8 ? 4 : 1), 0x141>(a, (lane & 4) != 0);   // row_half_mirror   i <-> 7-i (within 8)
+    if (N >= 4) mxf_rs_level<T, (N >= 4 ? 2 : 1), 0x1B>(a, (lane & 2) != 0);    // quad_perm [3,2,1,0]
+    if (N >= 2) mxf_rs_level<T, 1, 0xB1>(a, (lane & 1) != 0);                   // quad_perm [1,0,3,2]
+    T v = a[0];
+    // lanes that hold the same index differ in the bits above log2(N): fold them with rotations (index-preserving)
+    if (N <= 1) v += mxf_dpp_mov<0xB1>(v);
+    if (N <= 2) v += mxf_dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]  (xor 2)
+    if (N <= 4) v += mxf_dpp_mov<0x124>(v);     // row_ror:4
+    if (N <= 8) v += mxf_dpp_mov<0x128>(v);     // row_ror:8
+    return v;
+}
+
 // block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {

@@ -160,25 +160,27 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                 gvar = fma(g, k, gvar);
                 const T W2 = (T)2 * g * w * variance;   // 2 dL/d(r2)
                 T* ra = racc + (row - r0) * QA;
+                T tq[QT];
 #pragma unroll
                 for (int q = 0; q < QT; ++q) {
                     const T t = W2 * d[q];              // dL/d(xs_q) in scaled coordinates
                     gz[q] -= t;
                     gl[q] = fma(-t, d[q], gl[q]);       // dL/dl_q * l_q
-                    if (a.dX) {
-                        const T rs = wave_sum63(t);
-                        if (lane == 63 && q < Q) lds_add(ra + q, rs);
-                    }
+                    tq[q] = t;
+                }
+                if (a.dX) {
+                    // row side: the QT sums over this wave's 64 columns as ONE reduce-scatter per 16-lane row (lane l ends with the
+                    // row's sum of t[l & (QT-1)]), then one LDS atomic from QT lanes of each row
+                    const T rs = row_reduce_scatter<T, QT>(tq, lane);
+                    if ((lane & 15) < QT && (lane & 15) < Q) lds_add(ra + (lane & 15), rs);
                 }
                 if (FUSED && a.R) {
                     const T kv = cvalid ? k * variance : (T)0;
+                    T ke[PMAX];
 #pragma unroll
-                    for (int p = 0; p < PMAX; ++p) {
-                        if (p < P) {
-                            const T rs = wave_sum63(kv * e[p]);
-                            if (lane == 63) lds_add(ra + QT + p, rs);
-                        }
-                    }
+                    for (int p = 0; p < PMAX; ++p) ke[p] = kv * e[p];
+                    const T rs = row_reduce_scatter<T, PMAX>(ke, lane);
+                    if ((lane & 15) < PMAX && (lane & 15) < P) lds_add(ra + QT + (lane & 15), rs);
                 }
               }
             }
