@@ -167,6 +167,17 @@ __device__ __forceinline__ T row_reduce_scatter(T* a /* N values, clobbered */, 
     return v;
 }
 
+// lane-wise sum over the wave's four 16-lane rows (every lane ends with x[l%16 of row0] + ... + x[l%16 of row3]): the gfx950
+// v_permlane16_swap / v_permlane32_swap instructions.  Inline asm: the clang builtin (ROCm 7.2) folds its two results into one
+// register and returns 2x (tests/probes/probe_permlane.hip).
+__device__ __forceinline__ float wave_rows_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = a + b; b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {

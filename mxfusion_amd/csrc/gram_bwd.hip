@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
     constexpr bool FUSED = PT > 0;
     constexpr int PMAX = FUSED ? PT : 1;
     constexpr int QA = QT + (FUSED ? PMAX : 0);
+    constexpr bool PACKED = sizeof(T) == 4 && QT >= 2;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* racc = reinterpret_cast<T*>(smem_raw);           // [RB][QA]
     T* xs = racc + a.RB * QA;                           // [TRB][QT]
@@ -142,8 +144,21 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                 if (r >= rmax) break;
                 const int64_t row = rt + r;
                 T d[QT], r2 = 0;
+                if constexpr (PACKED) {   // float: the q loops two at a time on v_pk_add / v_pk_fma / v_pk_mul_f32
+                    f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < QT; ++q) { d[q] = xs[r * QT + q] - z[q]; r2 = fma(d[q], d[q], r2); }
+                    for (int j = 0; j < QT / 2; ++j) {
+                        const f32x2 xx = {xs[r * QT + 2 * j], xs[r * QT + 2 * j + 1]};
+                        const f32x2 zz = {z[2 * j], z[2 * j + 1]};
+                        const f32x2 dd = xx - zz;
+                        acc2 = __builtin_elementwise_fma(dd, dd, acc2);
+                        d[2 * j] = dd.x; d[2 * j + 1] = dd.y;
+                    }
+                    r2 = acc2.x + acc2.y;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) { d[q] = xs[r * QT + q] - z[q]; r2 = fma(d[q], d[q], r2); }
+                }
                 T k, w;
                 cov_and_slope<T, KIND>(r2, k, w);
                 T g;
@@ -161,26 +176,55 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                 const T W2 = (T)2 * g * w * variance;   // 2 dL/d(r2)
                 T* ra = racc + (row - r0) * QA;
                 T tq[QT];
+                if constexpr (PACKED) {
+                    const f32x2 w2 = {W2, W2};
 #pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const T t = W2 * d[q];              // dL/d(xs_q) in scaled coordinates
-                    gz[q] -= t;
-                    gl[q] = fma(-t, d[q], gl[q]);       // dL/dl_q * l_q
-                    tq[q] = t;
+                    for (int j = 0; j < QT / 2; ++j) {
+                        const f32x2 dd = {d[2 * j], d[2 * j + 1]};
+                        const f32x2 t = w2 * dd;
+                        f32x2 g2 = {gz[2 * j], gz[2 * j + 1]};
+                        f32x2 l2 = {gl[2 * j], gl[2 * j + 1]};
+                        g2 = g2 - t;
+                        l2 = __builtin_elementwise_fma(-t, dd, l2);
+                        gz[2 * j] = g2.x; gz[2 * j + 1] = g2.y;
+                        gl[2 * j] = l2.x; gl[2 * j + 1] = l2.y;
+                        tq[2 * j] = t.x; tq[2 * j + 1] = t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const T t = W2 * d[q];              // dL/d(xs_q) in scaled coordinates
+                        gz[q] -= t;
+                        gl[q] = fma(-t, d[q], gl[q]);       // dL/dl_q * l_q
+                        tq[q] = t;
+                    }
                 }
-                if (a.dX) {
-                    // row side: the QT sums over this wave's 64 columns as ONE reduce-scatter per 16-lane row (lane l ends with the
-                    // row's sum of t[l & (QT-1)]), then one LDS atomic from QT lanes of each row
-                    const T rs = row_reduce_scatter<T, QT>(tq, lane);
-                    if ((lane & 15) < QT && (lane & 15) < Q) lds_add(ra + (lane & 15), rs);
-                }
+                // row side: the QT sums (and, fused, the P sums of R) over this wave's 64 columns: ONE reduce-scatter per 16-lane row
+                // (lane l ends with its row's sum of t[l & (QT-1)]), rows folded with the permlane swaps (float), then one LDS atomic
+                // instruction from QT (+P) lanes -- the LDS atomic unit, not the VALU, bounds this kernel once the sums are cheap.
+                constexpr bool MERGE = FUSED && sizeof(T) == 4 && (QT + PMAX <= 16);
+                T rs = 0, rsR = 0;
+                if (a.dX) rs = row_reduce_scatter<T, QT>(tq, lane);
                 if (FUSED && a.R) {
                     const T kv = cvalid ? k * variance : (T)0;
                     T ke[PMAX];
 #pragma unroll
                     for (int p = 0; p < PMAX; ++p) ke[p] = kv * e[p];
-                    const T rs = row_reduce_scatter<T, PMAX>(ke, lane);
-                    if ((lane & 15) < PMAX && (lane & 15) < P) lds_add(ra + QT + (lane & 15), rs);
+                    rsR = row_reduce_scatter<T, PMAX>(ke, lane);
+                }
+                const int l16 = lane & 15;
+                if constexpr (MERGE) {
+                    const bool isq = l16 < QT;
+                    float v = isq ? rs : rsR;
+                    v = wave_rows_sum(v);
+                    const bool act = isq ? (a.dX != nullptr && l16 < Q) : (a.R != nullptr && (l16 - QT) < P);
+                    if (lane < 16 && act) lds_add(ra + l16, v);
+                } else if constexpr (sizeof(T) == 4) {
+                    if (a.dX) { const float v = wave_rows_sum(rs); if (lane < QT && lane < Q) lds_add(ra + lane, v); }
+                    if (FUSED && a.R) { const float v = wave_rows_sum(rsR); if (lane < PMAX && lane < P) lds_add(ra + QT + lane, v); }
+                } else {
+                    if (a.dX && l16 < QT && l16 < Q) lds_add(ra + l16, rs);
+                    if (FUSED && a.R && l16 < PMAX && l16 < P) lds_add(ra + QT + l16, rsR);
                 }
               }
             }
