@@ -90,6 +90,13 @@ int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t M, int64_t
              const void* B, int64_t ldb, int64_t strideB,
              double beta, void* C, int64_t ldc, int64_t strideC, int batch, void* stream);
 
+/* The same product, C = alpha A B^T + beta C for k-contiguous float32 operands A (M x K), B (N x K), on the bf16 matrix pipe:
+ * every f32 operand is split exactly into three bf16 terms and the six leading bf16 products accumulate in f32 (f32-equivalent
+ * accuracy, 6/16 of the f32-MFMA cost; gemm_split.hip).  Replaces linalg.gemm2(A, B, False, True) / linalg.syrk call sites whose
+ * operands are float32 (svgp_regression.py:88-107).  lower_only: only blocks / entries on or below the diagonal are written.     */
+int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
+                   double beta, void* C, int64_t ldc, int lower_only, void* stream);
+
 /* in-place lower Cholesky, strictly-upper part zeroed -- linalg.potrf (gp_regression.py:61,
  * svgp_regression.py:83-84).  info: device int[S], 0 or (1-based) index of the first bad pivot.   */
 int mxf_potrf(mxf_handle h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t strideS_A,

@@ -422,7 +422,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T));
-    if (want_grad) { acc((size_t)M * SB, sizeof(T)); acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
+    // float32 streaming: the two big GEMMs run on the bf16 matrix pipe from three-term split planes of their operands (gemm_split.hip)
+    static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
+    const bool use_split = split_env && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128;
+    const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
+    if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); if (want_grad) acc(3 * pl_big, 2); }
+    if (want_grad || use_split) acc((size_t)M * SB, sizeof(T));
+    if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
     Carver cv(ws);
@@ -433,8 +439,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
     T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB);
+    unsigned short* plKfu = nullptr; unsigned short* plH0 = nullptr; unsigned short* plKuf = nullptr;
+    if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); if (want_grad) plKuf = cv.take<unsigned short>(3 * pl_big); }
     T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
-    if (want_grad) { Kfu = cv.take<T>((size_t)M * SB); Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
+    if (want_grad || use_split) Kfu = cv.take<T>((size_t)M * SB);
+    if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
@@ -470,26 +479,48 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
         if (rc) return rc;
     }
-    MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf ready (the T GEMM waits for it)
-    if (want_grad && !het) {
-        // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream.
-        // It is formed from the TRANSPOSED Gram Kfu (S*B x M, rows = contiguous 4 KB lines) as a TN GEMM (sequential operand streams;
-        // the NT form on Kuf reads 256 K-strided streams per workgroup), lower blocks only, split-K.
+    if (use_split) {
+        // T GEMM operand: the transposed Gram Kfu (k = inducing index contiguous), split into bf16 planes
         rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
         if (rc) return rc;
-        // two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
+        rc = mxf_split_planes_internal(h, SB, M, (const float*)Kfu, M, plKfu, sd_);
+        if (rc) return rc;
+    }
+    MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf (and the Kfu planes) ready: the T GEMM waits for it
+    if (want_grad && !het) {
+        // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream,
+        // lower blocks only, split-K.  float32: from the bf16 planes of Kuf (gemm_split.hip); float64 / fallback: from the TRANSPOSED
+        // Gram Kfu (S*B x M, rows = contiguous lines) as a TN GEMM (the NT form on Kuf reads 256 K-strided streams per workgroup).
+        // Two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
         // ~216 CUs, so that the core chains' f64 workgroups (a whole CU's LDS / registers each) still find free CUs; phase B (the rest)
         // fills the chip.  Same-box A/B at 4 samples per GPU: 13.65 -> 12.95 ms per step; neutral at 32 samples.
         const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : 128 * M;
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
-        if (KA > 0) {
-            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, KA, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, sd_, psi2_ra);
+        if (use_split) {
+            rc = mxf_split_planes_internal(h, M, SB, (const float*)Kuf, SB, plKuf, sd_);
             if (rc) return rc;
-        }
-        if (KA < SB) {
-            rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB - KA, 1.0, Kfu + KA * M, M, 0, Kfu + KA * M, M, 0, KA > 0 ? 1.0 : 0.0, Psi2, M, 0, 1, 1,
-                                   sd_, psi2_rb);
+            if (KA > 0) {
+                rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_, psi2_ra);
+                if (rc) return rc;
+            }
+            if (KA < SB) {
+                const unsigned short* pk = plKuf + (KA / 16) * M * 16;
+                rc = mxf_gemm_split_internal(h, M, M, SB - KA, 1.0, pk, (int64_t)pl_big, pk, (int64_t)pl_big, KA > 0 ? 1.0 : 0.0, (float*)Psi2, M, 1, sd_,
+                                             psi2_rb);
+                if (rc) return rc;
+            }
+        } else {
+            rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
             if (rc) return rc;
+            if (KA > 0) {
+                rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, KA, 1.0, Kfu, M, 0, Kfu, M, 0, 0.0, Psi2, M, 0, 1, 1, sd_, psi2_ra);
+                if (rc) return rc;
+            }
+            if (KA < SB) {
+                rc = mxf_gemm_internal(h, dtype, 1, 0, M, M, SB - KA, 1.0, Kfu + KA * M, M, 0, Kfu + KA * M, M, 0, KA > 0 ? 1.0 : 0.0, Psi2, M, 0, 1, 1,
+                                       sd_, psi2_rb);
+                if (rc) return rc;
+            }
         }
         hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
@@ -536,8 +567,15 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
 
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
+    if (use_split) {
+        rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st);
+        if (rc) return rc;
+    }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
-    rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
+    if (use_split)   // T = H0 Kuf = H0 Kfu^T on the bf16 pipe (f32-equivalent three-term splitting)
+        rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0);
+    else
+        rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
     {
         constexpr int VEC = Vec16<T>::n;

@@ -1,0 +1,286 @@
+// f32-accurate GEMM on the bf16 matrix pipe of gfx950:  C = alpha * A * B^T (+ beta * C),  A (M x K), B (N x K), f32 in / f32 out.
+//
+// The f32 MFMA (v_mfma_f32_32x32x2_f32) runs at the VECTOR rate, 1/16 of v_mfma_f32_32x32x16_bf16.  Every f32 operand is
+// therefore split EXACTLY into three bf16 terms  x = h + m + l  (8 + 8 + 8 significand bits, round-to-nearest at each step:
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)), and the product is formed from the six bf16 x bf16 products whose weight
+// is >= 2^-16 of the leading one,
+//        x y  ~=  m m' + h l' + l h' + h m' + m h' + h h'        (dropped: m l', l m', l l'  <= 2^-23 |x y|)
+// accumulated in f32 inside the MFMA, i.e. the same product accuracy and the same accumulator as the f32 MFMA, at 6/16 of its
+// cost (peak 2.5 PF / 6 = 417 TF vs 157 TF).  This is an f32 GEMM (Ozaki-style splitting), not a reduced-precision one: the
+// parity tests bound its error against float64 exactly as for the plain f32 kernel.
+//
+// Operand storage ("planes"): plane p of an (R x K) operand holds the p-th bf16 term in k16-blocked order
+//        element (r, k)  ->  ((k / 16) * R + r) * 16 + k % 16
+// so that the (128 rows x 16 k) slab a workgroup needs per MFMA step is ONE contiguous 4 KB run: the loader is a linear 16-byte
+// copy per thread and the LDS image equals the global one (with an XOR swizzle of the two 16-byte halves of a row, which makes
+// the ds_read_b128 fragment reads conflict free).  A-fragment of v_mfma_f32_32x32x16_bf16: lane l -> A[i = l & 31][k = 8 (l >> 5) .. +7]
+// = one 16-byte unit; B likewise (both operands are k-contiguous: "NT" form only -- the SVGP step has both Kuf and Kfu).
+#include "common.h"
+#include "internal.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBM = 128, SBN = 128, SNT = 256;   // one 16-wide k block per MFMA step
+
+// ------------------------------------------------------------------------------------------------ f32 -> three bf16 planes
+// X (R x K, row stride ld) -> planes; K is padded with zeros to a multiple of 16 (Kp).  One block: 64 rows x 64 k.
+__global__ __launch_bounds__(256) void split_planes_kernel(int64_t R, int64_t K, const float* __restrict__ X, int64_t ld,
+                                                           unsigned short* __restrict__ P, int64_t pstride) {
+    __shared__ float tile[64][68];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, k0 = (int64_t)blockIdx.x * 64;
+    // coalesced read: 16 threads x float4 per row
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (tid >> 4), c = (tid & 15) * 4;
+        const int64_t r = r0 + row, k = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            if (k + 3 < K && ((ld & 3) == 0) && (((uintptr_t)X & 15) == 0)) v = *reinterpret_cast<const float4*>(X + r * ld + k);
+            else {
+                if (k + 0 < K) v.x = X[r * ld + k + 0];
+                if (k + 1 < K) v.y = X[r * ld + k + 1];
+                if (k + 2 < K) v.z = X[r * ld + k + 2];
+                if (k + 3 < K) v.w = X[r * ld + k + 3];
+            }
+        }
+        tile[row][c + 0] = v.x; tile[row][c + 1] = v.y; tile[row][c + 2] = v.z; tile[row][c + 3] = v.w;
+    }
+    __syncthreads();
+    const int row = tid & 63, kbl = tid >> 6;            // one (row, 16-k block) unit per thread
+    const int64_t r = r0 + row, kb = k0 / 16 + kbl;
+    const int64_t Kp16 = (K + 15) / 16;
+    if (r >= R || kb >= Kp16) return;
+    unsigned short h[16], m[16], l[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float x = tile[row][kbl * 16 + j];
+        const __bf16 bh = (__bf16)x;
+        const float r1 = x - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const float r2 = r1 - (float)bm;
+        const __bf16 bl = (__bf16)r2;
+        h[j] = __builtin_bit_cast(unsigned short, bh); m[j] = __builtin_bit_cast(unsigned short, bm); l[j] = __builtin_bit_cast(unsigned short, bl);
+    }
+    const int64_t off = (kb * R + r) * 16;
+    auto put = [&](unsigned short* dst, const unsigned short (&v)[16]) {
+        u32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = (unsigned)v[2 * j] | ((unsigned)v[2 * j + 1] << 16); b[j] = (unsigned)v[8 + 2 * j] | ((unsigned)v[8 + 2 * j + 1] << 16); }
+        *reinterpret_cast<u32x4*>(dst) = a;
+        *reinterpret_cast<u32x4*>(dst + 8) = b;
+    };
+    put(P + off, h);
+    put(P + pstride + off, m);
+    put(P + 2 * pstride + off, l);
+}
+
+// ------------------------------------------------------------------------------------------------ the GEMM
+struct SplitArgs {
+    const unsigned short* A; const unsigned short* B; float* C;
+    int64_t M, N, K16;          // K16 = number of 16-wide k blocks
+    int64_t pA, pB, ldc;
+    float alpha, beta;
+    int splitk, lower_only, atomic, nprod;
+    int64_t kchunk;             // k blocks per split
+    int64_t tm, tn, ntiles, nwg;
+};
+
+__device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
+
+__global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
+    __shared__ u32x4 smem[2][2][3][256];   // [buffer][A|B][plane][unit]  (48 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    int64_t wid = blockIdx.x;
+    {   // XCD-aware mapping (see gemm.hip)
+        const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t split = wid / g.ntiles;
+    int64_t t = wid % g.ntiles;
+    int64_t tile_m, tile_n;
+    if (g.lower_only) {
+        int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        tile_m = row; tile_n = t - row * (row + 1) / 2;
+    } else {
+        tile_m = t % g.tm; tile_n = t / g.tm;
+    }
+    const int64_t m0 = tile_m * SBM, n0 = tile_n * SBN;
+    const int64_t kbeg = split * g.kchunk;
+    const int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
+
+    f32x16 c[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;
+
+    // loader: thread t <-> 16-byte unit t of the (128 x 16) slab (row = t >> 1, k half = t & 1)
+    const int lrow = tid >> 1, lkh = tid & 1;
+    const bool va = (m0 + lrow) < g.M, vb = (n0 + lrow) < g.N;
+    const unsigned short* pa = g.A + (m0 + lrow) * 16 + lkh * 8;
+    const unsigned short* pb = g.B + (n0 + lrow) * 16 + lkh * 8;
+    const int sunit = lds_unit(lrow, lkh);
+    u32x4 ra[3], rb[3];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define SLOAD(kb)                                                                                                                  \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                            \
+            ra[p] = va ? *reinterpret_cast<const u32x4*>(pa + p * g.pA + (kb) * g.M * 16) : zero4;                                 \
+            rb[p] = vb ? *reinterpret_cast<const u32x4*>(pb + p * g.pB + (kb) * g.N * 16) : zero4;                                 \
+        }                                                                                                                          \
+    } while (0)
+#define SSTORE(buf)                                                                                                                \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) { smem[buf][0][p][sunit] = ra[p]; smem[buf][1][p][sunit] = rb[p]; }          \
+    } while (0)
+    if (kbeg < kend) { SLOAD(kbeg); SSTORE(0); }
+    __syncthreads();
+    const int li = lane & 31, lk = lane >> 5;
+    int ua[2], ub[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { ua[x] = lds_unit(wm + 32 * x + li, lk); ub[x] = lds_unit(wn + 32 * x + li, lk); }
+    int cur = 0;
+    for (int64_t kb = kbeg; kb < kend; ++kb) {
+        const bool more = kb + 1 < kend;
+        if (more) SLOAD(kb + 1);
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[x][p] = __builtin_bit_cast(bf16x8, smem[cur][0][p][ua[x]]);
+                b[x][p] = __builtin_bit_cast(bf16x8, smem[cur][1][p][ub[x]]);
+            }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                f32x16 acc = c[x][y];
+                if (g.nprod >= 6) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc, 0, 0, 0);   // m m'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc, 0, 0, 0);   // h l'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc, 0, 0, 0);   // l h'
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc, 0, 0, 0);       // h m'
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc, 0, 0, 0);       // m h'
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc, 0, 0, 0);       // h h'
+                c[x][y] = acc;
+            }
+        if (more) SSTORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef SLOAD
+#undef SSTORE
+    const float alpha = g.alpha, beta = g.beta;
+    const bool atomic = g.atomic != 0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t col = n0 + wn + y * 32 + (lane & 31);
+                if (row < g.M && col < g.N && !(g.lower_only && col > row)) {
+                    float* p = g.C + row * g.ldc + col;
+                    const float v = alpha * c[x][y][r];
+                    if (atomic) atomic_add(p, v);
+                    else *p = (beta == 0.f) ? v : v + beta * (*p);
+                }
+            }
+}
+
+__global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col < N && !(lower_only && col > row)) {
+        float* p = C + row * ldc + col;
+        *p = (beta == 0.f) ? 0.f : beta * (*p);
+    }
+}
+
+}  // namespace
+
+size_t mxf_split_plane_elems(int64_t R, int64_t K) { return (size_t)((K + 15) / 16) * (size_t)R * 16; }
+
+int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st) {
+    if (R <= 0 || K <= 0) return 0;
+    const int64_t pstride = (int64_t)mxf_split_plane_elems(R, K);
+    dim3 grid((unsigned)((K + 63) / 64), (unsigned)((R + 63) / 64));
+    if (grid.y > 65535u) MXF_FAIL(h, -3, "split planes: too many rows for one launch (%lld)", (long long)R);
+    hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, st, R, K, X, ld, planes, pstride);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+// C (M x N) = alpha * A (M x K) * B (N x K)^T + beta * C from split planes; pA / pB = plane strides in elements.  A k sub-range
+// [k0, k0+K) of a (R x Ktot) operand is the pointer planes + (k0 / 16) * R * 16 with the FULL operand's plane stride.
+int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
+                            const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
+                            int reserve_cus) {
+    if (M <= 0 || N <= 0) return 0;
+    SplitArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
+    g.pA = pA; g.pB = pB; g.ldc = ldc;
+    g.alpha = (float)alpha; g.beta = (float)beta; g.lower_only = lower_only;
+    static const int nprod = getenv("MXF_SPLIT_NPROD") ? atoi(getenv("MXF_SPLIT_NPROD")) : 6;
+    g.nprod = nprod;
+    const int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
+    if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
+    const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    int splitk = 1;
+    const int64_t slots = (int64_t)(256 - reserve_cus) * 3;
+    if (tiles < slots && g.K16 >= 16) {
+        int64_t sk = slots / tiles;
+        if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
+        const int64_t maxsplit = g.K16 / 8 > 0 ? g.K16 / 8 : 1;
+        if (sk > maxsplit) sk = maxsplit;
+        if (sk < 1) sk = 1;
+        splitk = (int)sk;
+    }
+    int64_t kchunk = (g.K16 + splitk - 1) / splitk;
+    if (kchunk < 1) kchunk = 1;
+    splitk = (int)((g.K16 + kchunk - 1) / kchunk);
+    if (splitk < 1) splitk = 1;
+    g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
+    g.tm = tm; g.tn = tn; g.ntiles = tiles; g.nwg = tiles * splitk;
+    if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm_split: grid too large");
+    if (g.atomic && beta != 1.0) {
+        if (M > 65535) MXF_FAIL(h, -3, "mxf_gemm_split: split-K path needs M<=65535");
+        dim3 gs((unsigned)((N + 255) / 256), (unsigned)M);
+        hipLaunchKernelGGL(split_scale_kernel, gs, dim3(256), 0, st, C, M, N, ldc, (float)beta, lower_only);
+    }
+    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+// C ABI (f32 only): operands given as plain f32 matrices; they are split into the handle's scratch and multiplied.
+extern "C" int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, double beta, void* C, int64_t ldc, int lower_only, void* stream) {
+    if (!h) return -1;
+    if (M <= 0 || N <= 0 || K <= 0) MXF_FAIL(h, -2, "mxf_gemm_f32x3: bad shape");
+    if (!A || !B || !C) MXF_FAIL(h, -2, "mxf_gemm_f32x3: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ea = mxf_split_plane_elems(M, K), eb = mxf_split_plane_elems(N, K);
+    const size_t need = mxf_align(3 * ea * 2) + mxf_align(3 * eb * 2);
+    char* ws = (char*)mxf_ws(h, need);
+    if (!ws) MXF_FAIL(h, -4, "mxf_gemm_f32x3: cannot allocate %zu bytes of scratch", need);
+    unsigned short* pa = (unsigned short*)ws;
+    unsigned short* pb = (unsigned short*)(ws + mxf_align(3 * ea * 2));
+    int rc = mxf_split_planes_internal(h, M, K, (const float*)A, lda, pa, st);
+    if (rc) return rc;
+    rc = mxf_split_planes_internal(h, N, K, (const float*)B, ldb, pb, st);
+    if (rc) return rc;
+    return mxf_gemm_split_internal(h, M, N, K, alpha, pa, (int64_t)ea, pb, (int64_t)eb, beta, (float*)C, ldc, lower_only, st, 0);
+}

@@ -24,3 +24,10 @@ int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int6
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
                                 void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st);
+
+// f32-accurate GEMM on the bf16 matrix pipe (three-term bf16 splitting, gemm_split.hip)
+size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE plane of an (R x K) operand
+int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st);
+int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
+                            const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
+                            int reserve_cus = 0);

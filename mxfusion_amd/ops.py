@@ -81,6 +81,20 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
     return out
 
 
+def gemm_f32x3(A, B, alpha=1.0, beta=0.0, out=None, lower_only=False):
+    """C = alpha A B^T + beta C for float32 A (M,K), B (N,K) on the bf16 matrix pipe with three-term splitting (f32-equivalent)."""
+    A, B = _c(A), _c(B)
+    if A.dtype != torch.float32 or B.dtype != torch.float32 or A.dim() != 2 or B.dim() != 2:
+        raise ValueError('gemm_f32x3: 2-D float32 operands')
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if lower_only else torch.empty((M, N), dtype=A.dtype, device=A.device)
+    _lib.call('mxf_gemm_f32x3', _h(A), M, N, K, float(alpha), _p(A), A.stride(0), _p(B), B.stride(0), float(beta), _p(out), out.stride(0),
+              int(bool(lower_only)), _stream())
+    return out
+
+
 def gram_bwd(kind, X, X2, lengthscale, variance, ard, dK, need=('X', 'X2', 'ls', 'var')):
     """Reverse mode of gram(); returns (dX, dX2, dls, dvar) shaped like their primals (summed over S for
     broadcast operands)."""
