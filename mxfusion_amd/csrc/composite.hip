@@ -284,6 +284,43 @@ __global__ __launch_bounds__(256) void wt_kuf_kernel(int64_t M, int64_t SB, int 
             for (int v = 0; v < VEC; ++v) if (n0 + v < SB) U[(int64_t)p * SB + n0 + v] = acc[p][v];
 }
 
+// The same row block from the three-term bf16 planes of Kfu (operand (n, k = m), gemm_split.hip layout): U[p][n] = sum_m w[m][p] Kfu[n][m].
+// lane <-> column n (32 contiguous bytes per lane and plane per k block); HBM-read bound (6 bytes per element).
+template <int PT>
+__global__ __launch_bounds__(256) void wt_planes_kernel(int64_t M, int64_t SB, int P, const unsigned short* __restrict__ pl, int64_t pstride,
+                                                        const float* __restrict__ w, float* __restrict__ U) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= SB) return;
+    float acc[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[p] = 0.f;
+    const int64_t K16 = (M + 15) / 16;
+    for (int64_t kb = 0; kb < K16; ++kb) {
+        const unsigned short* base = pl + (kb * SB + n) * 16;
+        u4 v[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { v[q][0] = *reinterpret_cast<const u4*>(base + q * pstride); v[q][1] = *reinterpret_cast<const u4*>(base + q * pstride + 8); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float x = 0.f;
+#pragma unroll
+            for (int q = 2; q >= 0; --q) {
+                const unsigned word = v[q][j >> 3][(j & 7) >> 1];
+                const unsigned bits = (j & 1) ? (word & 0xffff0000u) : (word << 16);
+                x += __builtin_bit_cast(float, bits);
+            }
+            const int64_t m = kb * 16 + j;
+            if (m < M) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[p] = fma((p < P) ? w[m * P + p] : 0.f, x, acc[p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p) if (p < P) U[(int64_t)p * SB + n] = acc[p];
+}
+
 // A_Ki = (G - T1 - T1^T) + 1/2 (Gw mu^T + mu Gw^T) - b (P/2 Su + 1/2 mu mu^T)
 __global__ void aki_kernel(int64_t M, int P, const double* __restrict__ G, const double* __restrict__ T1, const double* __restrict__ Gw,
                            const double* __restrict__ mu, const double* __restrict__ Su, double b, double* __restrict__ A) {
@@ -421,13 +458,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     for (int i = 0; i < 9; ++i) acc(MM, 8);   // L, Linv, Ki, Su(Ls), Lsinv, Sui, KiSu, H0, tmp
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
-    acc((size_t)M * SB, sizeof(T)); acc((size_t)(M + P) * SB, sizeof(T));
+    acc((size_t)(M + P) * SB, sizeof(T));
     // float32 streaming: the two big GEMMs run on the bf16 matrix pipe from three-term split planes of their operands (gemm_split.hip)
     static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
-    const bool use_split = split_env && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128;
+    const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
     const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
-    if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); if (want_grad) acc(3 * pl_big, 2); }
-    if (want_grad || use_split) acc((size_t)M * SB, sizeof(T));
+    if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); }
+    else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
@@ -438,11 +475,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* Sui = cv.take<D>(MM); D* KiSu = cv.take<D>(MM); D* H0 = cv.take<D>(MM); D* tmp = cv.take<D>(MM);
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
-    T* Kuf = cv.take<T>((size_t)M * SB); T* Text = cv.take<T>((size_t)(M + P) * SB);
+    T* Text = cv.take<T>((size_t)(M + P) * SB);
     unsigned short* plKfu = nullptr; unsigned short* plH0 = nullptr; unsigned short* plKuf = nullptr;
-    if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); if (want_grad) plKuf = cv.take<unsigned short>(3 * pl_big); }
-    T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
-    if (want_grad || use_split) Kfu = cv.take<T>((size_t)M * SB);
+    T* Kuf = nullptr; T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
+    if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); plKuf = cv.take<unsigned short>(3 * pl_big); }
+    else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
@@ -475,15 +512,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
     if (use_mat) {
         MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
+    } else if (use_split) {
+        // float32 training step: the Grams are written directly as three-term bf16 planes (6 bytes per element, never as f32):
+        // Kfu planes (operand (n, k = m)) feed the T GEMM and the w^T Kuf row, Kuf planes (operand (m, k = n)) feed Psi2
+        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
+                                      (int64_t)pl_big, sd_);
+        if (rc) return rc;
     } else {
         rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
-        if (rc) return rc;
-    }
-    if (use_split) {
-        // T GEMM operand: the transposed Gram Kfu (k = inducing index contiguous), split into bf16 planes
-        rc = mxf_gram(h, kind, dtype, 1, SB, M, Q, X, 0, Z, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kfu, M, 0, sd_);
-        if (rc) return rc;
-        rc = mxf_split_planes_internal(h, SB, M, (const float*)Kfu, M, plKfu, sd_);
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf (and the Kfu planes) ready: the T GEMM waits for it
@@ -497,7 +533,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : 128 * M;
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         if (use_split) {
-            rc = mxf_split_planes_internal(h, M, SB, (const float*)Kuf, SB, plKuf, sd_);
+            rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
+                                          (int64_t)pl_big, sd_);
             if (rc) return rc;
             if (KA > 0) {
                 rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_, psi2_ra);
@@ -577,7 +614,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
-    {
+    if (use_split) {
+        dim3 gu((unsigned)((SB + 255) / 256));
+        if (P == 1) hipLaunchKernelGGL((wt_planes_kernel<1>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, (const float*)wT, (float*)(Text + M * SB));
+        else hipLaunchKernelGGL((wt_planes_kernel<8>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, (const float*)wT, (float*)(Text + M * SB));
+    } else {
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));
         if (P == 1) hipLaunchKernelGGL((wt_kuf_kernel<T, 1>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);

@@ -277,6 +277,106 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     return 0;
 }
 
+// ---- Gram matrix written as three-term bf16 split planes (the operand format of gemm_split.hip) ------------------------------------
+// operand element (r, k) = cov(xmin[r], xmaj[k]); plane p element (r, k) at ((k / 16) * R + r) * 16 + k % 16.
+// Thread <-> (minor index r, k half): per 16-wide k block a thread evaluates 8 covariances, splits each f32 value exactly into
+// h + m + l (bf16 each) and writes ONE 16-byte unit per plane; a wave writes 1 KB contiguous per plane per k block.
+// HBM-write bound: 6 bytes per element (12.9 GB at M = 1024 x 2.1 M columns).
+typedef unsigned int gp_u32x4 __attribute__((ext_vector_type(4)));
+template <int QT, int KIND>
+__global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
+                                                          const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
+                                                          int chunks_per_block) {
+    constexpr int CH = 16;                                   // k blocks per staged chunk (256 major points)
+    __shared__ __attribute__((aligned(16))) float xs[CH * 16 * QT];
+    const int tid = threadIdx.x, rl = tid >> 1, half = tid & 1;
+    const int64_t r = (int64_t)blockIdx.x * 128 + rl;
+    const bool rvalid = r < R;
+    const float variance = var[0];
+    float z[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q += 4) *reinterpret_cast<f32x4_t*>(&z[q]) = *reinterpret_cast<const f32x4_t*>(Xmin_s + r * QT + q);   // padded
+    const int64_t K16 = (Kn + 15) / 16;
+    for (int c = 0; c < chunks_per_block; ++c) {
+        const int64_t kb0 = ((int64_t)blockIdx.y * chunks_per_block + c) * CH;
+        if (kb0 >= K16) break;
+        __syncthreads();
+        for (int i = tid * 4; i < CH * 16 * QT; i += 256 * 4)
+            *reinterpret_cast<f32x4_t*>(&xs[i]) = *reinterpret_cast<const f32x4_t*>(Xmaj_s + kb0 * 16 * QT + i);                   // padded
+        __syncthreads();
+        const int nkb = (int)((K16 - kb0) < CH ? (K16 - kb0) : CH);
+        for (int kbl = 0; kbl < nkb; ++kbl) {
+            gp_u32x4 uh, um, ul;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                float kv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int nl = kbl * 16 + half * 8 + j + e;
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < QT; q += 2) {
+                        const f32x2 xx = {xs[nl * QT + q], xs[nl * QT + q + 1]};
+                        const f32x2 zz = {z[q], z[q + 1]};
+                        const f32x2 d = xx - zz;
+                        acc2 = __builtin_elementwise_fma(d, d, acc2);
+                    }
+                    const float red = acc2.x + acc2.y;
+                    kv[e] = (kb0 * 16 + nl < Kn) ? cov_from<float, KIND>(red, variance) : 0.f;
+                }
+                unsigned hh = 0, mm = 0, ll = 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const __bf16 bh = (__bf16)kv[e];
+                    const float r1 = kv[e] - (float)bh;
+                    const __bf16 bm = (__bf16)r1;
+                    const float r2 = r1 - (float)bm;
+                    const __bf16 bl = (__bf16)r2;
+                    hh |= (unsigned)__builtin_bit_cast(unsigned short, bh) << (16 * e);
+                    mm |= (unsigned)__builtin_bit_cast(unsigned short, bm) << (16 * e);
+                    ll |= (unsigned)__builtin_bit_cast(unsigned short, bl) << (16 * e);
+                }
+                uh[j / 2] = hh; um[j / 2] = mm; ul[j / 2] = ll;
+            }
+            if (rvalid) {
+                unsigned short* dst = P + ((kb0 + kbl) * R + r) * 16 + half * 8;
+                __builtin_nontemporal_store(uh, reinterpret_cast<gp_u32x4*>(dst));
+                __builtin_nontemporal_store(um, reinterpret_cast<gp_u32x4*>(dst + pstride));
+                __builtin_nontemporal_store(ul, reinterpret_cast<gp_u32x4*>(dst + 2 * pstride));
+            }
+        }
+    }
+}
+
+template <int KIND>
+int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
+                     const float* var, unsigned short* planes, int64_t pstride, hipStream_t st) {
+    const int QT = Q <= 8 ? 8 : 16;
+    const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
+    const size_t need = (size_t)(padr + padk) * QT * sizeof(float);
+    float* buf = (float*)mxf_gram_ws(h, need);
+    if (!buf) MXF_FAIL(h, -4, "gram planes: cannot allocate %zu bytes for the pre-scaled coordinates", need);
+    float* bmaj = buf + (size_t)padr * QT;
+    const int64_t K16 = (Kn + 15) / 16, chunks = (K16 + 15) / 16, rblocks = padr / 128;
+    int cpb = 1;
+    while (rblocks * ((chunks + cpb - 1) / cpb) > 16384 && cpb < chunks) cpb *= 2;      // fewer, longer blocks once the chip is full
+    dim3 grid((unsigned)rblocks, (unsigned)((chunks + cpb - 1) / cpb));
+    if (grid.y > 65535u) MXF_FAIL(h, -3, "gram planes: grid too large");
+#define GO(QTV)                                                                                                                       \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padr * QTV + 255) / 256), 1), dim3(256), 0, st, Xmin, (int64_t)0, ls, \
+                           (int64_t)0, ard, R, Q, padr, buf);                                                                         \
+        hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
+                           (int64_t)0, ard, Kn, Q, padk, bmaj);                                                                       \
+        hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
+    } while (0)
+    if (QT == 8) GO(8); else GO(16);
+#undef GO
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
 template <typename T>
 int gram_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q,
                const void* X, int64_t sX, const void* X2, int64_t sX2, const void* ls, int ard, int64_t sls,
@@ -326,4 +426,19 @@ extern "C" int mxf_gram(mxf_handle h, int kind, int dtype, int S, int64_t N, int
         return gram_typed<double>(h, kind, S, N, N2, Q, X, strideS_X, X2, strideS_X2, lengthscale, ard, strideS_ls,
                                   variance, strideS_var, diag_add, strideS_diag, jitter, mode, K_out, ldk, strideS_K, st);
     MXF_FAIL(h, -2, "mxf_gram: bad dtype %d", dtype);
+}
+
+// Gram matrix cov(xmin[r], xmaj[k]) (r < R, k < Kn) as three-term bf16 split planes (float32 inputs, stationary kernels); see
+// gram_planes_kernel.  planes: 3 * pstride elements, pstride = mxf_split_plane_elems(R, Kn).
+int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, hipStream_t st) {
+    if (R <= 0 || Kn <= 0) return 0;
+    if (Q > 16) MXF_FAIL(h, -3, "gram planes: Q > 16 not supported");
+    switch (kind) {
+        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
+        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
+        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
+        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
+    }
+    MXF_FAIL(h, -2, "gram planes: stationary kernels only (kind %d)", kind);
 }
