@@ -490,7 +490,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
     int rc;
     static const int64_t psi2_ka = getenv("MXF_SVGP_PSI2_KA") ? atoll(getenv("MXF_SVGP_PSI2_KA")) : -1;
-    static const int psi2_ra = getenv("MXF_SVGP_PSI2_RA") ? atoi(getenv("MXF_SVGP_PSI2_RA")) : 148;
+    static const bool psi2_ra_env = getenv("MXF_SVGP_PSI2_RA") != nullptr;
+    static const int psi2_ra = psi2_ra_env ? atoi(getenv("MXF_SVGP_PSI2_RA")) : 148;
     static const int psi2_rb = getenv("MXF_SVGP_PSI2_RB") ? atoi(getenv("MXF_SVGP_PSI2_RB")) : 16;
     // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
     if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
@@ -530,14 +531,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // Two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
         // ~216 CUs, so that the core chains' f64 workgroups (a whole CU's LDS / registers each) still find free CUs; phase B (the rest)
         // fills the chip.  Same-box A/B at 4 samples per GPU: 13.65 -> 12.95 ms per step; neutral at 32 samples.
-        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : 128 * M;
+        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split ? 192 : 128) * M;
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         if (use_split) {
             rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
                                           (int64_t)pl_big, sd_);
             if (rc) return rc;
             if (KA > 0) {
-                rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_, psi2_ra);
+                // 3 workgroups of the split kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs
+                rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                             psi2_ra_env ? psi2_ra : 184);
                 if (rc) return rc;
             }
             if (KA < SB) {
