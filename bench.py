@@ -37,7 +37,7 @@ def synth(N, Q, M, seed=0):
     return X, Y, Z
 
 
-def build(N, Q, M, S_local, dtype, X, Y, Z, distributed):
+def build(N, Q, M, S_local, dtype, X, Y, Z, distributed, use_graph=False):
     from mxfusion_amd import Model, Variable
     from mxfusion_amd.components.variables import PositiveTransformation
     from mxfusion_amd.components.distributions import Normal
@@ -55,7 +55,7 @@ def build(N, Q, M, S_local, dtype, X, Y, Z, distributed):
     gp = m.Y.factor
     gp.svgp_log_pdf.jitter = 1e-6
     q = create_Gaussian_meanfield(model=m, observed=[m.Y], dtype=dtype)
-    loop = DistributedBatchInferenceLoop() if distributed else BatchInferenceLoop()
+    loop = DistributedBatchInferenceLoop(use_graph=use_graph) if distributed else BatchInferenceLoop(use_graph=use_graph)
     infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S_local, observed=[m.Y]),
                               grad_loop=loop, dtype=dtype)
     infr.initialize(Y=(N, 1))
@@ -207,6 +207,7 @@ def main():
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
     args = ap.parse_args()
@@ -227,7 +228,7 @@ def main():
 
     N, Q, M = args.N, args.Q, args.M
     X, Y, Z = synth(N, Q, M)
-    m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed)
+    m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed, use_graph=args.graph)
     td = torch.float32 if args.dtype == 'float32' else torch.float64
     Yd = torch.as_tensor(Y, dtype=td).cuda()
     dt, last_loss = time_steps(infr, loop, Yd, args.steps, args.warmup, args.lr, distributed)

@@ -27,6 +27,15 @@ class _Adam(object):
 
 
 class BatchInferenceLoop(GradLoop):
+    """use_graph=True: after two eager warm-up steps (scratch growth, lazy initialisation) the forward + reverse pass of one step
+    (~280 kernel launches on three streams) is captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; the gradient
+    exchange and the Adam kernel stay outside the graph.  The data tensors passed to step() must then be the same objects every
+    step (their contents may change)."""
+
+    def __init__(self, use_graph=False):
+        self.use_graph = use_graph
+        self._gstate = None
+
     def run(self, infr_executor, data, param_dict, ctx, optimizer='adam', learning_rate=1e-3, max_iter=1000, n_prints=10, verbose=False):
         trainer = _Adam(param_dict, learning_rate, optimizer)
         iter_step = max(max_iter // n_prints, 1)
@@ -43,10 +52,42 @@ class BatchInferenceLoop(GradLoop):
 
     def step(self, infr_executor, data, param_dict):
         """record -> forward -> backward (batch_loop.py:52-54) + the gradient exchange hook; returns the loss."""
+        if getattr(self, 'use_graph', False) and param_dict.flat.is_cuda:
+            return self._graph_step(infr_executor, data, param_dict)
         loss, loss_for_gradient = infr_executor(*data)
         loss_for_gradient.backward()
         self._exchange(param_dict)
         return loss
+
+    def _graph_step(self, infr_executor, data, param_dict):
+        st = getattr(self, '_gstate', None)
+        if st is None or st.get('flat') is not param_dict.flat:
+            st = self._gstate = {'n': 0, 'flat': param_dict.flat}
+        if 'graph' not in st:
+            if st['n'] < 2:                      # eager warm-up, on a side stream (the documented whole-step capture recipe: autograd's
+                st['n'] += 1                     # AccumulateGrad node of the flat leaf must not be bound to the default stream)
+                side = st.setdefault('stream', torch.cuda.Stream())
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    loss, loss_for_gradient = infr_executor(*data)
+                    loss_for_gradient.backward()
+                torch.cuda.current_stream().wait_stream(side)
+                self._exchange(param_dict)
+                return loss.detach()
+            torch.cuda.synchronize()
+            param_dict.flat.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, loss_for_gradient = infr_executor(*data)
+                loss_for_gradient.backward()
+            st.update(graph=g, loss=loss.detach(), grad=param_dict.flat.grad, data=[d for d in data])
+        for d, d0 in zip(data, st['data']):
+            if d is not d0:
+                d0.copy_(d)
+        st['graph'].replay()
+        param_dict.flat.grad = st['grad']
+        self._exchange(param_dict)
+        return st['loss']
 
     def _exchange(self, param_dict):
         pass
@@ -57,7 +98,8 @@ class DistributedBatchInferenceLoop(BatchInferenceLoop):
     num_samples is the LOCAL count) with the loss weighted 1/world_size, then the flat gradient is summed with one
     all-reduce.  backend 'nccl' is RCCL on ROCm; tests use 'gloo' on CPU tensors."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, use_graph=False):
+        super(DistributedBatchInferenceLoop, self).__init__(use_graph=use_graph)
         self.process_group = process_group
 
     def _exchange(self, param_dict):

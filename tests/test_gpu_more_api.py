@@ -396,3 +396,43 @@ def test_linear_bias_white_kernels_reverse_mode(square, S, ard):
     Kd = kern.Kdiag(None, dev['X'], **{k: dev[v].detach() for k, v in names.items()})
     Kdo = okern.Kdiag(ora['X'].detach(), **{k: ora[v].detach() for k, v in names.items()})
     assert np.allclose(Kd.detach().cpu().numpy(), Kdo.numpy(), rtol=1e-11)
+
+
+def test_graph_captured_step_matches_eager(golden_dir):
+    """BatchInferenceLoop(use_graph=True): the forward + reverse pass of the SVI step replayed from a hipGraph (three streams, ~280
+    launches) gives the same parameter trajectory as eager execution (deterministic injected noise)."""
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, create_Gaussian_meanfield, BatchInferenceLoop
+    g = np.load(os.path.join(golden_dir, 'kat_svi.npz'))
+    k = np.load(os.path.join(golden_dir, 'kat_svgp.npz'))
+
+    def run(use_graph):
+        from mxfusion_amd import Model, Variable
+        from mxfusion_amd.components.variables import PositiveTransformation
+        from mxfusion_amd.components.distributions import Normal
+        from mxfusion_amd.components.distributions.gp.kernels import RBF
+        from mxfusion_amd.modules.gp_modules import SVGPRegression
+        m = Model()
+        m.N = Variable()
+        m.X = Normal.define_variable(mean=0, variance=1, shape=(m.N, 3))
+        m.Z = Variable(shape=(3, 3), initial_value=_t(k['Z']))
+        m.noise_var = Variable(transformation=PositiveTransformation(), initial_value=_t(k['noise']))
+        kernel = RBF(input_dim=3, ARD=True, variance=_t(k['var']), lengthscale=_t(k['ls']), dtype=DT)
+        m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=DT)
+        m.Y.factor.svgp_log_pdf.jitter = 1e-8
+        q = create_Gaussian_meanfield(model=m, observed=[m.Y], dtype=DT)
+        # ONE step's worth of noise, replayed every step: host-side state (the mock generator's cursor) is frozen in a captured graph
+        q[m.X].factor._rand_gen = MockRandomGenerator(_t(g['eps'][0]))
+        S = g['eps'].shape[1]
+        infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S, observed=[m.Y]),
+                                  grad_loop=BatchInferenceLoop(use_graph=use_graph), dtype=DT)
+        infr.initialize(Y=g['Y'].shape)
+        infr.params[m.Y.factor._extra_graphs[0].qU_mean] = _t(g['init_qU_mean'])
+        infr.params[m.Y.factor._extra_graphs[0].qU_cov_W] = _t(g['init_qU_cov_W'])
+        infr.run(Y=_t(g['Y']), max_iter=6, learning_rate=0.05)
+        return infr.params.flat.detach().clone()
+    torch.manual_seed(0); np.random.seed(0)          # un-set parameters (q(X)) are initialised from the host RNG
+    a = run(False)
+    torch.manual_seed(0); np.random.seed(0)
+    b = run(True)
+    assert torch.allclose(a, b, rtol=1e-9, atol=1e-10), float((a - b).abs().max())
