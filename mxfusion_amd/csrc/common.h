@@ -14,7 +14,7 @@ struct mxf_ctx {
     size_t ws_bytes = 0;
     hipStream_t side = nullptr;   // internal side streams: independent chains of the SVGP step run concurrently
     hipStream_t side2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
 };
@@ -67,7 +67,8 @@ static inline bool mxf_side_init(mxf_ctx* h) {
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess) return false;
+        hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }
 

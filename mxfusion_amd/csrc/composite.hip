@@ -581,6 +581,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s2_, M, (const D*)sd, Su);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
     if (rc) return rc;
+    MXF_HIP(h, hipEventRecord(h->ev_su, s2_));           // H0 needs Su only; its Cholesky (log-det, Su^-1 for the reverse mode) is OFF the critical path
     MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, s2_));
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_);                                // Ls = chol(Su) :84
     if (rc) return rc;
@@ -593,7 +594,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
-    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));                                                // join
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su formed (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
     MXF_HIP(h, hipMemcpyAsync(H0, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
@@ -627,6 +628,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (P == 1) hipLaunchKernelGGL((wt_kuf_kernel<T, 1>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);
         else hipLaunchKernelGGL((wt_kuf_kernel<T, 8>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);   // U = w^T Kuf
     }
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
     if (S > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X (loop over samples on the host otherwise)");
     D* dnz = nullptr; D* dvdir = nullptr;
