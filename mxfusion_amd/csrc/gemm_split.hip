@@ -85,13 +85,14 @@ struct SplitArgs {
     int64_t M, N, K16;          // K16 = number of 16-wide k blocks
     int64_t pA, pB, ldc;
     float alpha, beta;
-    int splitk, lower_only, atomic, nprod;
+    int splitk, lower_only, atomic, nprod, use_dma;
     int64_t kchunk;             // k blocks per split
     int64_t tm, tn, ntiles, nwg;
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
 
+template <bool DMA>
 __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     __shared__ u32x4 smem[2][2][3][256];   // [buffer][A|B][plane][unit]  (48 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,7 +144,26 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     do {                                                                                                                           \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) { smem[buf][0][p][sunit] = ra[p]; smem[buf][1][p][sunit] = rb[p]; }          \
     } while (0)
-    if (kbeg < kend) { SLOAD(kbeg); SSTORE(0); }
+    // interior tiles: LDS-DMA (global_load_lds_dwordx4) straight into the other LDS buffer -- no staging VGPRs, no ds_write pass.
+    // The LDS destination of a wave is linear (base + lane * 16), so the XOR swizzle is applied to the SOURCE: the lane that fills
+    // LDS unit u = (row, khs) fetches global k half khs ^ ((row >> 3) & 1) of that row.
+    constexpr bool dma = DMA;     // host guarantees M, N multiples of 128 for the DMA instantiation
+    const int drow = tid >> 1, dkh = (tid & 1) ^ ((drow >> 3) & 1);
+    const unsigned short* da = g.A + (m0 + drow) * 16 + dkh * 8;
+    const unsigned short* db = g.B + (n0 + drow) * 16 + dkh * 8;
+#define SDMA(kb, buf)                                                                                                              \
+    do {                                                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                            \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + p * g.pA + (kb) * g.M * 16),     \
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][0][p][wave * 64]), 16, 0, 0);    \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + p * g.pB + (kb) * g.N * 16),     \
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][1][p][wave * 64]), 16, 0, 0);    \
+        }                                                                                                                          \
+    } while (0)
+    if (kbeg < kend) {
+        if constexpr (dma) SDMA(kbeg, 0);
+        else { SLOAD(kbeg); SSTORE(0); }
+    }
     __syncthreads();
     const int li = lane & 31, lk = lane >> 5;
     int ua[2], ub[2];
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     int cur = 0;
     for (int64_t kb = kbeg; kb < kend; ++kb) {
         const bool more = kb + 1 < kend;
-        if (more) SLOAD(kb + 1);
+        if (more) { if constexpr (dma) SDMA(kb + 1, cur ^ 1); else SLOAD(kb + 1); }
         bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -176,12 +196,13 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc, 0, 0, 0);       // h h'
                 c[x][y] = acc;
             }
-        if (more) SSTORE(cur ^ 1);
+        if constexpr (!dma) { if (more) SSTORE(cur ^ 1); }
         __syncthreads();
         cur ^= 1;
     }
 #undef SLOAD
 #undef SSTORE
+#undef SDMA
     const float alpha = g.alpha, beta = g.beta;
     const bool atomic = g.atomic != 0;
 #pragma unroll
@@ -235,6 +256,8 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     g.alpha = (float)alpha; g.beta = (float)beta; g.lower_only = lower_only;
     static const int nprod = getenv("MXF_SPLIT_NPROD") ? atoi(getenv("MXF_SPLIT_NPROD")) : 6;
     g.nprod = nprod;
+    static const int use_dma = getenv("MXF_SPLIT_DMA") ? atoi(getenv("MXF_SPLIT_DMA")) : 1;
+    g.use_dma = use_dma;
     const int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
     const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
@@ -260,7 +283,8 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M);
         hipLaunchKernelGGL(split_scale_kernel, gs, dim3(256), 0, st, C, M, N, ldc, (float)beta, lower_only);
     }
-    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    if (g.use_dma && (M % SBM) == 0 && (N % SBN) == 0) hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    else hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
