@@ -97,6 +97,14 @@ int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t M, int64_t
 int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
                    double beta, void* C, int64_t ldc, int lower_only, void* stream);
 
+/* The two halves of mxf_gemm_f32x3 for callers that reuse split operands (the SVGP step splits Kuf once for two products):
+ * mxf_f32x3_split writes the three bf16 planes of an (R x K) float32 matrix (k16-blocked, see gemm_split.hip) into `planes`
+ * (3 * mxf_f32x3_plane_elems(R, K) 16-bit elements); mxf_gemm_f32x3_planes multiplies two split operands.                         */
+int64_t mxf_f32x3_plane_elems(int64_t R, int64_t K);
+int mxf_f32x3_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* stream);
+int mxf_gemm_f32x3_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* B_planes,
+                          double beta, void* C, int64_t ldc, int lower_only, void* stream);
+
 /* in-place lower Cholesky, strictly-upper part zeroed -- linalg.potrf (gp_regression.py:61,
  * svgp_regression.py:83-84).  info: device int[S], 0 or (1-based) index of the first bad pivot.   */
 int mxf_potrf(mxf_handle h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t strideS_A,

@@ -36,6 +36,8 @@ SIGNATURES = {
                       _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_logpdf': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                         _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'mxf_f32x3_split': [_i64, _i64, _vp, _i64, _vp, _vp],
+    'mxf_gemm_f32x3_planes': [_i64, _i64, _i64, _d, _vp, _vp, _d, _vp, _i64, _i, _vp],
     'mxf_gemm_f32x3': [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i, _vp],
     'mxf_svgp_logpdf_het': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                             _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -50,6 +52,7 @@ PLAIN = {  # entry points without the (handle, ...) -> int shape
     'mxf_destroy': ([_vp], _i),
     'mxf_last_error': ([_vp], _c.c_char_p),
     'mxf_workspace_bytes': ([_vp], _i64),
+    'mxf_f32x3_plane_elems': ([_i64, _i64], _i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
 

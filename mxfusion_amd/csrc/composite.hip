@@ -463,7 +463,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
     const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
-    if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); }
+    const size_t gp_scr = use_split ? mxf_gram_planes_scratch_bytes(SB, SB, Q) : 0;      // upper bound for either orientation
+    if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
     else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
@@ -478,7 +479,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     T* Text = cv.take<T>((size_t)(M + P) * SB);
     unsigned short* plKfu = nullptr; unsigned short* plH0 = nullptr; unsigned short* plKuf = nullptr;
     T* Kuf = nullptr; T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
-    if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); plKuf = cv.take<unsigned short>(3 * pl_big); }
+    float* gscr0 = nullptr; float* gscr1 = nullptr;
+    if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); plKuf = cv.take<unsigned short>(3 * pl_big);
+                     gscr0 = (float*)cv.take<char>(gp_scr); gscr1 = (float*)cv.take<char>(gp_scr); }
     else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
@@ -508,6 +511,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipStream_t s2_ = h->side2;
     MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
     MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_fork, 0));
+    // second side stream, first thing: Su (H0 on the critical path needs it; its Cholesky comes later and is off the critical path)
+    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s2_, M, (const D*)sd, Su);
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
+    if (rc) return rc;
+    MXF_HIP(h, hipEventRecord(h->ev_su, s2_));           // H0 needs Su only; its Cholesky (log-det, Su^-1 for the reverse mode) is OFF the critical path
     // Enqueue order = priority order (the host needs ~5 us per launch and a step has ~280 of them): first the few launches that carry
     // the bulk of the device work (Grams, Psi2), then the latency-critical Kuu chain, then the Su chain.
     // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
@@ -515,15 +523,22 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
     } else if (use_split) {
         // float32 training step: the Grams are written directly as three-term bf16 planes (6 bytes per element, never as f32):
-        // Kfu planes (operand (n, k = m)) feed the T GEMM and the w^T Kuf row, Kuf planes (operand (m, k = n)) feed Psi2
-        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
-                                      (int64_t)pl_big, sd_);
+        // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
+        // (n, k = m): T GEMM and the w^T Kuf row) are then written (HBM bound) on the second side stream NEXT TO Psi2.
+        rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
+                                      (int64_t)pl_big, gscr0, sd_);
         if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));
+        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux, 0));
+        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
+                                      (int64_t)pl_big, gscr1, s2_);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes ready: the T GEMM waits for it
     } else {
         rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
         if (rc) return rc;
     }
-    MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf (and the Kfu planes) ready: the T GEMM waits for it
+    if (!use_split) MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf ready: the T GEMM waits for it
     if (want_grad && !het) {
         // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream,
         // lower blocks only, split-K.  float32: from the bf16 planes of Kuf (gemm_split.hip); float64 / fallback: from the TRANSPOSED
@@ -534,9 +549,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split ? 192 : 128) * M;
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         if (use_split) {
-            rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
-                                          (int64_t)pl_big, sd_);
-            if (rc) return rc;
             if (KA > 0) {
                 // 3 workgroups of the split kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs
                 rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
@@ -578,10 +590,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
-    hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s2_, M, (const D*)sd, Su);
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
-    if (rc) return rc;
-    MXF_HIP(h, hipEventRecord(h->ev_su, s2_));           // H0 needs Su only; its Cholesky (log-det, Su^-1 for the reverse mode) is OFF the critical path
     MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, s2_));
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_);                                // Ls = chol(Su) :84
     if (rc) return rc;

@@ -308,3 +308,21 @@ extern "C" int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, dou
     if (rc) return rc;
     return mxf_gemm_split_internal(h, M, N, K, alpha, pa, (int64_t)ea, pb, (int64_t)eb, beta, (float*)C, ldc, lower_only, st, 0);
 }
+
+// the two halves of mxf_gemm_f32x3 for callers that reuse split operands: planes = 3 * mxf_f32x3_plane_elems(R, K) bf16 (uint16) elements
+extern "C" int64_t mxf_f32x3_plane_elems(int64_t R, int64_t K) { return (R > 0 && K > 0) ? (int64_t)mxf_split_plane_elems(R, K) : 0; }
+
+extern "C" int mxf_f32x3_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* stream) {
+    if (!h) return -1;
+    if (R <= 0 || K <= 0 || !X || !planes) MXF_FAIL(h, -2, "mxf_f32x3_split: bad argument");
+    return mxf_split_planes_internal(h, R, K, (const float*)X, ld, (unsigned short*)planes, (hipStream_t)stream);
+}
+
+extern "C" int mxf_gemm_f32x3_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* B_planes,
+                                     double beta, void* C, int64_t ldc, int lower_only, void* stream) {
+    if (!h) return -1;
+    if (M <= 0 || N <= 0 || K <= 0 || !A_planes || !B_planes || !C) MXF_FAIL(h, -2, "mxf_gemm_f32x3_planes: bad argument");
+    return mxf_gemm_split_internal(h, M, N, K, alpha, (const unsigned short*)A_planes, (int64_t)mxf_split_plane_elems(M, K),
+                                   (const unsigned short*)B_planes, (int64_t)mxf_split_plane_elems(N, K), beta, (float*)C, ldc, lower_only,
+                                   (hipStream_t)stream, 0);
+}

@@ -351,12 +351,10 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
 
 template <int KIND>
 int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
-                     const float* var, unsigned short* planes, int64_t pstride, hipStream_t st) {
+                     const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st) {
     const int QT = Q <= 8 ? 8 : 16;
     const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
-    const size_t need = (size_t)(padr + padk) * QT * sizeof(float);
-    float* buf = (float*)mxf_gram_ws(h, need);
-    if (!buf) MXF_FAIL(h, -4, "gram planes: cannot allocate %zu bytes for the pre-scaled coordinates", need);
+    float* buf = scratch;     // (padr + padk) * QT floats, caller-owned: two of these run concurrently on different streams
     float* bmaj = buf + (size_t)padr * QT;
     const int64_t K16 = (Kn + 15) / 16, chunks = (K16 + 15) / 16, rblocks = padr / 128;
     int cpb = 1;
@@ -430,15 +428,22 @@ extern "C" int mxf_gram(mxf_handle h, int kind, int dtype, int S, int64_t N, int
 
 // Gram matrix cov(xmin[r], xmaj[k]) (r < R, k < Kn) as three-term bf16 split planes (float32 inputs, stationary kernels); see
 // gram_planes_kernel.  planes: 3 * pstride elements, pstride = mxf_split_plane_elems(R, Kn).
+size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q) {
+    const int QT = Q <= 8 ? 8 : 16;
+    const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
+    return (size_t)(padr + padk) * QT * sizeof(float);
+}
+
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
-                             int ard, const float* var, unsigned short* planes, int64_t pstride, hipStream_t st) {
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st) {
     if (R <= 0 || Kn <= 0) return 0;
+    if (!scratch) MXF_FAIL(h, -2, "gram planes: scratch of mxf_gram_planes_scratch_bytes() bytes required");
     if (Q > 16) MXF_FAIL(h, -3, "gram planes: Q > 16 not supported");
     switch (kind) {
-        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
-        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
-        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
-        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, st);
+        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
+        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
+        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
+        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
     }
     MXF_FAIL(h, -2, "gram planes: stationary kernels only (kind %d)", kind);
 }

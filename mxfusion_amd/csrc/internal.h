@@ -31,5 +31,6 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus = 0);
+size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
-                             int ard, const float* var, unsigned short* planes, int64_t pstride, hipStream_t st);
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st);

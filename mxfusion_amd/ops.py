@@ -95,6 +95,27 @@ def gemm_f32x3(A, B, alpha=1.0, beta=0.0, out=None, lower_only=False):
     return out
 
 
+def f32x3_split(X):
+    """Three-term bf16 split planes of a 2-D float32 matrix (operand format of gemm_f32x3_planes); returns an int16 tensor."""
+    X = _c(X)
+    if X.dtype != torch.float32 or X.dim() != 2:
+        raise ValueError('f32x3_split: 2-D float32 operand')
+    R, K = X.shape
+    n = _lib.load().mxf_f32x3_plane_elems(R, K)
+    planes = torch.empty(3 * n, dtype=torch.int16, device=X.device)
+    _lib.call('mxf_f32x3_split', _h(X), R, K, _p(X), X.stride(0), _p(planes), _stream())
+    return planes
+
+
+def gemm_f32x3_planes(A_planes, B_planes, M, N, K, alpha=1.0, beta=0.0, out=None, lower_only=False):
+    """C (M,N) = alpha A B^T + beta C from operands split with f32x3_split (A: (M,K), B: (N,K))."""
+    if out is None:
+        out = torch.zeros((M, N), dtype=torch.float32, device=A_planes.device) if lower_only else torch.empty((M, N), dtype=torch.float32, device=A_planes.device)
+    _lib.call('mxf_gemm_f32x3_planes', _h(A_planes), M, N, K, float(alpha), _p(A_planes), _p(B_planes), float(beta), _p(out), out.stride(0),
+              int(bool(lower_only)), _stream())
+    return out
+
+
 def gram_bwd(kind, X, X2, lengthscale, variance, ard, dK, need=('X', 'X2', 'ls', 'var')):
     """Reverse mode of gram(); returns (dX, dX2, dls, dvar) shaped like their primals (summed over S for
     broadcast operands)."""
