@@ -23,3 +23,30 @@ def test_gemm_vs_cpu(dtype, tol, ta, tb, M, N, K, S):
     assert np.allclose(out.cpu().numpy(), ref, rtol=tol, atol=tol * scale)
     out2 = ops.gemm(torch.as_tensor(A, dtype=dtype).cuda(), torch.as_tensor(B, dtype=dtype).cuda(), ta, tb)
     assert np.allclose(out2.cpu().numpy(), (ref + 0.3 * C0) / 0.7, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize('M,N,K,lower', [(128, 128, 16, False), (256, 384, 1024, False), (130, 70, 50, False), (1, 5, 7, False),
+                                          (1024, 1024, 4096, True), (300, 300, 333, True), (512, 8192, 512, False)])
+def test_gemm_f32x3_is_f32_accurate(M, N, K, lower):
+    """mxf_gemm_f32x3 (f32 operands split exactly into three bf16 terms, six bf16 MFMA products, f32 accumulate): the error against
+    float64 must be at the level of the plain f32-MFMA kernel (and of an f32 accumulation of K terms), for aligned, ragged, tiny,
+    split-K and lower-only shapes, with both signs and a wide dynamic range in the operands."""
+    from mxfusion_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K)
+    A = (torch.rand(M, K, device='cuda', generator=g) * 2 - 0.7) * torch.exp(torch.randn(M, 1, device='cuda', generator=g))
+    B = torch.exp(-torch.rand(N, K, device='cuda', generator=g) * 8) * (torch.rand(N, K, device='cuda', generator=g) - 0.3)
+    ref = A.double() @ B.double().T
+    C3 = ops.gemm_f32x3(A, B, lower_only=lower)
+    C1 = ops.gemm(A[None], B[None], transB=True)[0]
+    msk = torch.tril(torch.ones(M, N, device='cuda')) if lower else torch.ones(M, N, device='cuda')
+    scale = (A.double().abs() @ B.double().abs().T)                      # elementwise condition-free scale sum |a||b|
+    e3 = float((((C3.double() - ref).abs() / scale) * msk).max())
+    e1 = float((((C1.double() - ref).abs() / scale) * msk).max())
+    assert e3 < 4e-7, (e3, e1)                                              # a few f32 ulps of sum|a||b|
+    assert e3 < 2.5 * e1 + 1e-7, (e3, e1)                                   # never materially worse than the f32 MFMA kernel
+    if lower:
+        assert float((C3 * (1 - msk)).abs().max()) == 0.0                  # strictly-upper blocks / entries untouched
+    # alpha / beta and the planes-level entry points
+    out = torch.full((M, N), 2.0, device='cuda')
+    ops.gemm_f32x3_planes(ops.f32x3_split(A), ops.f32x3_split(B), M, N, K, alpha=0.5, beta=1.0, out=out)
+    assert float(((out.double() - (0.5 * ref + 2.0)).abs() / (scale + 1.0)).max()) < 4e-7
