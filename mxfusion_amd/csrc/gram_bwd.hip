@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                     const bool isq = l16 < QT;
                     float v = isq ? rs : rsR;
                     v = wave_rows_sum(v);
-                    const bool act = isq ? (a.dX != nullptr && l16 < Q) : (a.R != nullptr && (l16 - QT) < P);
-                    if (lane < 16 && act) lds_add(ra + l16, v);
+                    // lane l16 >= QT holds the R sum of index l16 & (PMAX-1) (a permutation of 0..PMAX-1 over lanes QT..QT+PMAX-1)
+                    const int rp = l16 & (PMAX - 1);
+                    const bool act = isq ? (a.dX != nullptr && l16 < Q) : (a.R != nullptr && l16 < QT + PMAX && rp < P);
+                    if (lane < 16 && act) lds_add(ra + (isq ? l16 : QT + rp), v);
                 } else if constexpr (sizeof(T) == 4) {
                     if (a.dX) { const float v = wave_rows_sum(rs); if (lane < QT && lane < Q) lds_add(ra + lane, v); }
                     if (FUSED && a.R) { const float v = wave_rows_sum(rsR); if (lane < PMAX && lane < P) lds_add(ra + QT + lane, v); }

@@ -102,6 +102,15 @@ class DistributedBatchInferenceLoop(BatchInferenceLoop):
         super(DistributedBatchInferenceLoop, self).__init__(use_graph=use_graph)
         self.process_group = process_group
 
+    def step(self, infr_executor, data, param_dict):
+        import torch.distributed as dist
+        if not getattr(self, '_synced', False) and dist.is_available() and dist.is_initialized() and \
+                dist.get_world_size(self.process_group) > 1:
+            with torch.no_grad():           # replicas must start from identical parameters (un-set ones are drawn from the host RNG)
+                dist.broadcast(param_dict.flat.data, src=0, group=self.process_group)
+            self._synced = True
+        return super(DistributedBatchInferenceLoop, self).step(infr_executor, data, param_dict)
+
     def _exchange(self, param_dict):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:

@@ -192,3 +192,37 @@ def test_svgp_logpdf_mat_vs_oracle(dtype, tol, nshape):
         if key == 'dKuu':      # autograd of the oracle gives the gradient w.r.t. an unconstrained (non-symmetric) Kuu: compare symmetrised
             got, ref = 0.5 * (got + got.T), 0.5 * (ref + ref.T)
         _close(got.reshape(ref.shape), ref, gtol, key)
+
+
+@pytest.mark.parametrize('kind', ['rbf', 'matern32'])
+@pytest.mark.parametrize('B,M,Q,P,S', [(512, 128, 8, 1, 2), (2048, 256, 3, 2, 1), (1040, 144, 16, 1, 3)])
+def test_svgp_logpdf_f32_split_path_vs_oracle(kind, B, M, Q, P, S):
+    """The float32 training step as the bench runs it: Grams written as three-term bf16 planes, both big GEMMs on the bf16 matrix
+    pipe (gemm_split.hip), w^T Kuf from the planes.  Taken when S*B and M are multiples of 16 and M >= 128 (every other f32 test in this
+    file has ragged sizes and runs the plain f32-MFMA kernels).  ELBO to 1e-5 (north_star), gradients to the f32 tolerance."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(B + M + Q)
+    X = rng.uniform(-2, 2, (S, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm, qW, qd = rng.randn(M, P) * 0.3, rng.randn(M, M) * 0.05, rng.rand(M) + 0.5
+    ls = (rng.rand(Q) * 0.3 + 0.3) * np.sqrt(Q / 3.0)          # well-conditioned Kuu (DESIGN.md section 5)
+    var, noise = np.array([1.3]), np.array([0.05])
+    k = {'rbf': O.RBF, 'matern32': O.Matern32}[kind](Q, ARD=True)
+    names = ('X', 'Y', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    vals = dict(X=X, Y=Y, Z=Z, noise=noise, qm=qm, qW=qW, qd=qd, ls=ls, var=var)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    logL = O.svgp_log_pdf(k, lv['X'], lv['Y'][None], lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-6, log_pdf_scaling=1.0)
+    grads = torch.autograd.grad(logL.mean(), [lv[n] for n in names])
+    dt = torch.float32
+    r = ops.svgp_logpdf(kind, _dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(noise, dt), _dev(qm, dt), _dev(qW, dt), _dev(qd, dt),
+                        _dev(ls, dt), _dev(var, dt), True, jitter=1e-6, scaling=1.0, gscale=1.0 / S, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, 1e-5, 'logL')
+    for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], 5e-3, key)
+    # and the forward-only call (plain f32 kernels) agrees with the training call's value
+    r0 = ops.svgp_logpdf(kind, _dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(noise, dt), _dev(qm, dt), _dev(qW, dt), _dev(qd, dt),
+                         _dev(ls, dt), _dev(var, dt), True, jitter=1e-6, scaling=1.0, gscale=1.0 / S, want_grad=False)
+    _close(r0['logL'], r['logL'].double().cpu(), 1e-4, 'fwd-only vs training value')     # the plain f32-MFMA kernels are the less accurate of the two
