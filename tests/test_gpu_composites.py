@@ -226,3 +226,40 @@ def test_svgp_logpdf_f32_split_path_vs_oracle(kind, B, M, Q, P, S):
     r0 = ops.svgp_logpdf(kind, _dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(noise, dt), _dev(qm, dt), _dev(qW, dt), _dev(qd, dt),
                          _dev(ls, dt), _dev(var, dt), True, jitter=1e-6, scaling=1.0, gscale=1.0 / S, want_grad=False)
     _close(r0['logL'], r['logL'].double().cpu(), 1e-4, 'fwd-only vs training value')     # the plain f32-MFMA kernels are the less accurate of the two
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('Q', [1, 2, 4, 7, 16])
+@pytest.mark.parametrize('P', [1, 3, 8])
+def test_svgp_logpdf_input_and_output_widths(dtype, tol, Q, P):
+    """Every (Q tile, P tile) instantiation of the fused reverse pass and of the Gram kernels: Q in {1..16}, P in {1..8} (the merged
+    LDS-atomic lane mapping differs per combination); B = 272, M = 128 takes the split path in float32."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(100 * Q + P)
+    S, B, M = 2, 272, 128
+    L = max(1.5, 0.3 * 128 ** (1.0 / Q))             # keep the 128 inducing points ~one length-scale apart (f32 needs a well-conditioned Kuu)
+    X = rng.uniform(-L, L, (S, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-L, L, (M, Q))
+    if Q == 1:                                          # random points on a line come arbitrarily close: use a jittered lattice
+        Z = (np.linspace(-L, L, M) + rng.uniform(-0.05, 0.05, M))[:, None]
+    elif Q == 2:
+        gx, gy = np.meshgrid(np.linspace(-L, L, 12), np.linspace(-L, L, 11))
+        Z = np.stack([gx.ravel(), gy.ravel()], 1)[:M] + rng.uniform(-0.05, 0.05, (M, 2))
+    qm, qW, qd = rng.randn(M, P) * 0.3, rng.randn(M, M) * 0.05, rng.rand(M) + 0.5
+    ls = (rng.rand(Q) * 0.2 + 0.25) * max(1.0, np.sqrt(Q / 3.0))
+    var, noise = np.array([1.1]), np.array([0.07])
+    k = O.RBF(Q, ARD=True)
+    names = ('X', 'Y', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    vals = dict(X=X, Y=Y, Z=Z, noise=noise, qm=qm, qW=qW, qd=qd, ls=ls, var=var)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    logL = O.svgp_log_pdf(k, lv['X'], lv['Y'][None], lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-5)
+    grads = torch.autograd.grad(logL.mean(), [lv[n] for n in names])
+    r = ops.svgp_logpdf('rbf', _dev(X, dtype), _dev(Y[None], dtype), _dev(Z, dtype), _dev(noise, dtype), _dev(qm, dtype), _dev(qW, dtype),
+                        _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-5, gscale=1.0 / S, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')
+    gtol = tol * 1000 if dtype == torch.float64 else 5e-3
+    for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
