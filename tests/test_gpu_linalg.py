@@ -60,9 +60,11 @@ def test_potrf_not_positive_definite_reports_info():
 KINDS = {'rbf': O.RBF, 'matern12': O.Matern12, 'matern32': O.Matern32, 'matern52': O.Matern52}
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 2e-4)])
 @pytest.mark.parametrize('kind', list(KINDS))
-@pytest.mark.parametrize('N,N2,Q,S,ard', [(7, 5, 3, 1, True), (70, 300, 8, 2, True), (130, None, 5, 2, False), (64, 257, 16, 1, True)])
-def test_gram_bwd_vs_autograd(kind, N, N2, Q, S, ard):
+@pytest.mark.parametrize('N,N2,Q,S,ard', [(7, 5, 3, 1, True), (70, 300, 8, 2, True), (130, None, 5, 2, False), (64, 257, 16, 1, True),
+                                          (33, 700, 1, 1, True), (100, 260, 2, 1, False), (90, 1000, 12, 1, True)])
+def test_gram_bwd_vs_autograd(kind, N, N2, Q, S, ard, dtype, tol):
     from mxfusion_amd import ops
     rng = np.random.RandomState(N + Q)
     X = rng.uniform(-2, 2, (S, N, Q))
@@ -75,14 +77,17 @@ def test_gram_bwd_vs_autograd(kind, N, N2, Q, S, ard):
     tX2 = None if X2 is None else O.T(X2).clone().requires_grad_(True)
     K = k.K(tX, tX2, **{k.name + '_lengthscale': tls, k.name + '_variance': tvar})
     (K * O.T(dK)).sum().backward()
-    dX, dX2, dls, dvar = ops.gram_bwd(kind, _dev(X), None if X2 is None else _dev(X2), _dev(ls), _dev(var), ard, _dev(dK))
+    if kind == 'matern12' and Q == 1:
+        tol = max(tol, 1e-6)     # |x - z| of the closest pairs from the reference's expansion form x^2 - 2xz + z^2 carries ~1e-8 relative noise
+    dX, dX2, dls, dvar = ops.gram_bwd(kind, _dev(X, dtype), None if X2 is None else _dev(X2, dtype), _dev(ls, dtype), _dev(var, dtype), ard,
+                                      _dev(dK, dtype))
     for got, ref, name in ((dX, tX.grad, 'dX'), (dX2, None if tX2 is None else tX2.grad, 'dX2'), (dls, tls.grad, 'dls'),
                            (dvar, tvar.grad, 'dvar')):
         if ref is None:
             assert got is None
             continue
         r = ref.numpy()
-        assert np.allclose(got.cpu().numpy(), r, rtol=1e-9, atol=1e-9 * max(1., np.abs(r).max())), name
+        assert np.allclose(got.cpu().numpy(), r, rtol=tol, atol=tol * max(1., np.abs(r).max())), name
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-12), (torch.float32, 1e-5)])
