@@ -71,6 +71,79 @@ def build(N, Q, M, S_local, dtype, X, Y, Z, distributed, use_graph=False):
     return m, q, infr, loop, qX
 
 
+def build_deepgp(N, Q, M, Dh, S_local, dtype, X, Y, distributed):
+    """BASELINE.json configs[4]: two chained SVGPRegression modules, first layer Matern52 + RBF (AddKernel), hidden layer H (N x Dh) with a
+    mean-field q(H), second layer RBF-ARD on the sampled H.  Built purely from the API."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, create_Gaussian_meanfield, \
+        BatchInferenceLoop, DistributedBatchInferenceLoop
+    rng = np.random.default_rng(3)
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    side = int(math.ceil(M ** (1.0 / Dh)))
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z0 = Variable(shape=(M, Q), initial_value=X[rng.permutation(N)[:M]].copy())
+    # second-layer inducing inputs on a lattice over the range of H with a length-scale of about one lattice spacing: Kuu stays well
+    # conditioned, which the float32 streaming form needs (DESIGN.md section 5)
+    side = int(math.ceil(M ** (1.0 / Dh)))
+    grid = np.stack(np.meshgrid(*[np.linspace(-1.2, 1.2, side)] * Dh, indexing='ij'), -1).reshape(-1, Dh)[:M]
+    m.Z1 = Variable(shape=(M, Dh), initial_value=grid + 0.01 * rng.standard_normal((M, Dh)))
+    m.noise0 = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.noise1 = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    k0 = Matern52(Q, ARD=True, variance=1., lengthscale=np.full(Q, 2.0), dtype=dtype) + RBF(Q, ARD=True, variance=1., lengthscale=np.full(Q, 2.0), dtype=dtype)
+    k1 = RBF(Dh, ARD=True, variance=1., lengthscale=np.full(Dh, 2.4 / max(side - 1, 1)), name='rbf_top', dtype=dtype)
+    m.H = SVGPRegression.define_variable(X=m.X, kernel=k0, noise_var=m.noise0, inducing_inputs=m.Z0, shape=(m.N, Dh), dtype=dtype)
+    m.Y = SVGPRegression.define_variable(X=m.H, kernel=k1, noise_var=m.noise1, inducing_inputs=m.Z1, shape=(m.N, 1), dtype=dtype)
+    for gp in (m.H.factor, m.Y.factor):
+        gp.svgp_log_pdf.jitter = 1e-5
+    q = create_Gaussian_meanfield(model=m, observed=[m.X, m.Y], dtype=dtype)
+    loop = DistributedBatchInferenceLoop() if distributed else BatchInferenceLoop()
+    infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S_local, observed=[m.X, m.Y]), grad_loop=loop,
+                              dtype=dtype)
+    infr.initialize(X=(N, Q), Y=(N, 1))
+    dev = infr.mxnet_context
+    for gp, P in ((m.H.factor, Dh), (m.Y.factor, 1)):
+        post = gp._extra_graphs[0]
+        infr.params[post.qU_mean] = torch.zeros(M, P, dtype=td, device=dev)
+        infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td, device=dev)
+        infr.params[post.qU_cov_diag] = torch.ones(M, dtype=td, device=dev)
+    qH = q[m.H].factor
+    infr.params[qH.mean] = torch.as_tensor(np.tanh(X[:, :Dh]), dtype=td).to(dev)
+    infr.params[qH.variance] = torch.full((N, Dh), 1e-2, dtype=td, device=dev)
+    return infr, loop
+
+
+def time_steps_multi(infr, loop, data, steps, warmup, lr, distributed):
+    from mxfusion_amd.inference.batch_loop import _Adam
+    import torch.distributed as dist
+    executor = infr.create_executor()
+    trainer = _Adam(infr.params, lr)
+    loss = None
+    for _ in range(warmup):
+        loss = loop.step(executor, data, infr.params)
+        trainer.step(batch_size=1)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = loop.step(executor, data, infr.params)
+        trainer.step(batch_size=1)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(loss.detach())
+
+
 def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     from mxfusion_amd.inference.batch_loop import _Adam
     import torch.distributed as dist
@@ -220,6 +293,8 @@ def main():
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--workload', default='svgp', choices=['svgp', 'deepgp'], help="'svgp' = the headline (configs[2]); 'deepgp' = configs[4]")
+    ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
@@ -239,6 +314,25 @@ def main():
     S_local = args.samples // world
     torch.manual_seed(1234 + rank)
 
+    if args.workload == 'deepgp':      # secondary workload: BASELINE.json configs[4] (2-layer SVGP deep GP, Matern52+RBF, N=131072 D=16 M=512/layer)
+        N, Q, M, Dh = (131072 if args.N == 65536 else args.N), (16 if args.Q == 8 else args.Q), (512 if args.M == 1024 else args.M), args.hidden
+        X, Y, _ = synth(N, Q, M)
+        infr, loop = build_deepgp(N, Q, M, Dh, S_local, args.dtype, X, Y, distributed)
+        td = torch.float32 if args.dtype == 'float32' else torch.float64
+        data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]
+        dt, last_loss = time_steps_multi(infr, loop, data, args.steps, args.warmup, args.lr, distributed)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "ELBO-steps/sec, 2-layer SVGP deep GP (BASELINE.json configs[4])", "value": args.steps / dt, "unit": "ELBO-steps/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
+                "config": {"workload": "deep GP: SVGPRegression(Matern52+RBF, Q=%d) -> H (N x %d, mean-field q(H)) -> SVGPRegression(RBF-ARD), N=%d, "
+                                       "M=%d per layer, %d MC samples" % (Q, Dh, N, M, args.samples), "samples_per_gpu": S_local},
+                "last_loss": last_loss}))
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     N, Q, M = args.N, args.Q, args.M
     X, Y, Z = synth(N, Q, M)
     m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed, use_graph=args.graph)

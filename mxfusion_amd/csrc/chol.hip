@@ -109,7 +109,7 @@ __global__ __launch_bounds__(128) void solve_rows_kernel(T* __restrict__ A, int6
 // instead of two (diag + solve), and no dependent launch gap between them.
 template <typename T>
 __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int64_t lda, int64_t sA, int64_t k0, int nb, int64_t n,
-                                                           int* __restrict__ info) {
+                                                           int* __restrict__ info, int* __restrict__ arrived) {
     __shared__ T a[NB][NB + 1];
     __shared__ T lc[4][NB];
     __shared__ T invd[NB];
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
         a[i][c] = v;
     }
     __syncthreads();
+    // Every workgroup re-factors the diagonal block from the UNFACTORED values in global memory, and workgroup 0 writes the factor back
+    // in place: it may do so only after all the others have taken their copy (they can start arbitrarily late when other kernels hold
+    // the CUs).  Arrival counter: one per batch item, zero on entry, reset to zero by workgroup 0.
+    if (blockIdx.x != 0 && tid == 0) { __threadfence(); atomicAdd(arrived + b, 1); }
     for (int jb = 0; jb < NB; jb += 4) {
         if (tid < NB && tid >= jb) {
             // 4x4 Cholesky of the current diagonal sub-block, redundantly in every participating thread
@@ -170,6 +174,12 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
         __syncthreads();
     }
     if (blockIdx.x == 0) {
+        if (tid == 0) {
+            const int others = (int)gridDim.x - 1;
+            while (__hip_atomic_load(arrived + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_store(arrived + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
         for (int e = tid; e < nb * nb; e += 128) {
             const int i = e / nb, c = e % nb;
             D[(int64_t)i * lda + c] = (c <= i) ? a[i][c] : (T)0;     // MXNet potrf zeroes the strict upper part
@@ -325,7 +335,10 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 if (rc) return rc;
             }
             const int64_t below = n - (j0 + nb);
-            hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(1 + (below + 127) / 128), S), dim3(128), 0, st, A, lda, sA, j0, nb, n, info);
+            int* arrived = mxf_flags(h, (unsigned)S);
+            if (!arrived) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
+            hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(1 + (below + 127) / 128), S), dim3(128), 0, st, A, lda, sA, j0, nb, n, info,
+                               arrived);
         }
         if (pe < n) {   // trailing update, lower blocks only: A22 -= L21 L21^T with K = panel width
             int rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe, n - pe, pe - c0, -1.0, A + pe * lda + c0, lda, sA,

@@ -17,7 +17,22 @@ struct mxf_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
+    int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
+    unsigned flag_cursor = 0;
 };
+constexpr unsigned MXF_NFLAGS = 1u << 18;
+// a fresh run of `count` zeroed counters (rotating; a slot is reused only after 2^18 / count later launches have been queued)
+static inline int* mxf_flags(mxf_ctx* h, unsigned count) {
+    if (!h->flags) {
+        if (hipMalloc((void**)&h->flags, MXF_NFLAGS * sizeof(int)) != hipSuccess) { h->flags = nullptr; return nullptr; }
+        if (hipMemset(h->flags, 0, MXF_NFLAGS * sizeof(int)) != hipSuccess) return nullptr;
+    }
+    if (count > MXF_NFLAGS) return nullptr;
+    if (h->flag_cursor + count > MXF_NFLAGS) h->flag_cursor = 0;
+    int* p = h->flags + h->flag_cursor;
+    h->flag_cursor += count;
+    return p;
+}
 
 #define MXF_FAIL(h, code, ...)                                   \
     do {                                                         \

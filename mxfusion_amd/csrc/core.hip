@@ -19,6 +19,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (!h) return -1;
     if (h->ws) (void)hipFree(h->ws);
     if (h->gram_ws) (void)hipFree(h->gram_ws);
+    if (h->flags) (void)hipFree(h->flags);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);

@@ -141,3 +141,30 @@ def test_elementwise_kernels(dtype, tol):
         p = opt.step(p, {'w': O.T(g)}, batch_size=4)
         ops.adam_step_(wd, _dev(g, dtype), m, v, 0.05, t, rescale_grad=0.25)
     assert np.allclose(wd.cpu().numpy(), p['w'].numpy(), rtol=tol * 10, atol=tol * 10)
+
+
+def test_potrf_is_race_free_under_cu_contention():
+    """Regression: every workgroup of the fused potrf panel kernel re-factors the diagonal block from the un-factored values while
+    workgroup 0 writes the factor back in place; when other kernels hold the CUs (the SVGP step runs big GEMMs on side streams) the
+    late workgroups used to read the already-factored block.  Factor repeatedly while another stream saturates the chip."""
+    from mxfusion_amd import ops
+    torch.manual_seed(3)
+    n = 1024
+    A = torch.randn(n, n, device='cuda', dtype=torch.float64)
+    K = A @ A.T / n + torch.eye(n, device='cuda', dtype=torch.float64)
+    ref = torch.linalg.cholesky(K)
+    big_a = torch.randn(1, 4096, 4096, device='cuda')
+    big_b = torch.randn(1, 4096, 16384, device='cuda')
+    out = torch.empty(1, 4096, 16384, device='cuda')
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ops.gemm(big_a, big_b, out=out)
+        L, info = ops.potrf_(K[None].clone())
+        torch.cuda.synchronize()
+        if int(info.abs().sum()) != 0 or float((L[0] - ref).abs().max()) > 1e-11:
+            bad += 1
+    assert bad == 0, bad
