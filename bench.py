@@ -350,6 +350,8 @@ def main():
                    "samples_per_gpu": S_local, "parallelism": "mc-samples sharded x%d, 1 RCCL all-reduce of the flat gradient/step" % world,
                    "core_precision": "float64 (M x M factorisations), streaming %s" % args.dtype},
         "last_loss": last_loss,
+        # LAPACK-style info of the last step's Cholesky factorisations (0 = every pivot positive)
+        "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum()),
     }
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q

@@ -1,5 +1,5 @@
 import os, sys, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mxfusion_amd import ops
 def bench(fn, reps=5):
     fn(); torch.cuda.synchronize()

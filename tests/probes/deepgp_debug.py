@@ -1,5 +1,5 @@
 import sys, os, json
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from mxfusion_amd.inference.batch_loop import _Adam

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mxfusion_amd import ops
 M, N, K = 1024, 262144, 1024
 A = torch.randn(1, M, K, device='cuda', dtype=torch.float32); B = torch.randn(1, K, N, device='cuda', dtype=torch.float32)

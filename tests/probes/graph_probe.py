@@ -1,6 +1,6 @@
 """probe: which library calls survive hipGraph capture (torch.cuda.graph)."""
 import os, sys, faulthandler
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 faulthandler.enable()
 import torch
 from mxfusion_amd import ops

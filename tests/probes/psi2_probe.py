@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mxfusion_amd import ops
 M, K = 1024, 2097152
 A = torch.randn(1, K, M, device='cuda', dtype=torch.float32)

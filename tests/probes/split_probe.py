@@ -1,6 +1,6 @@
 """probe: f32x3 (bf16-split) GEMM vs plain f32 MFMA GEMM -- accuracy against float64 and time, at the SVGP step's two shapes."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mxfusion_amd import ops
 
