@@ -484,6 +484,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
                      gscr0 = (float*)cv.take<char>(gp_scr); gscr1 = (float*)cv.take<char>(gp_scr); }
     else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
+    D* G = nullptr; D* T1 = nullptr; D* AKi = nullptr; D* T2 = nullptr; D* dKuu = nullptr; D* dSu = nullptr;
+    D* Gw = nullptr; D* dmud = nullptr; D* dZc = nullptr; D* dlsc = nullptr; D* dvc = nullptr;
+    if (want_grad) {
+        G = cv.take<D>(MM); T1 = cv.take<D>(MM); AKi = cv.take<D>(MM); T2 = cv.take<D>(MM); dKuu = cv.take<D>(MM); dSu = cv.take<D>(MM);
+        Gw = cv.take<D>(MP); dmud = cv.take<D>(MP); dZc = cv.take<D>(M * Q); dlsc = cv.take<D>(lsn); dvc = cv.take<D>(4);
+    }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
@@ -620,6 +626,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st);
         if (rc) return rc;
     }
+    MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     if (use_split)   // T = H0 Kuf = H0 Kfu^T on the bf16 pipe (f32-equivalent three-term splitting)
         rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0);
@@ -635,6 +642,32 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));
         if (P == 1) hipLaunchKernelGGL((wt_kuf_kernel<T, 1>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);
         else hipLaunchKernelGGL((wt_kuf_kernel<T, 8>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);   // U = w^T Kuf
+    }
+    // the part of the core reverse mode that depends on Psi2 only (not on R): dSu = -Ki G Ki + bP/2 (Su^-1 - Ki), dW = 2 dSu W,
+    // dSdiag = diag(dSu), T1 = G Ki Su.  Streaming path: queued on the side stream right behind Psi2, so it runs under the T GEMM /
+    // the reverse pass instead of in the step's tail.
+    auto su_reverse = [&](hipStream_t s_, bool with_t1) -> int {
+        int r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, s_);            // T3 = Ki G
+        if (r_) return r_;
+        hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s_, MM, 1.0, (const D*)Sui, -1.0, (const D*)Ki, dSu);   // Sui - Ki
+        r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, tmp, M, 0, Ki, M, 0, 0.5 * bw * P, dSu, M, 0, 1, 0, s_);
+        if (r_) return r_;
+        if (dW) {
+            r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, Lsinv, M, 0, 1, 0, s_);     // dW = 2 dSu W (Lsinv buffer is free)
+            if (r_) return r_;
+            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, s_, MM, (T)1, (const D*)Lsinv, dW, 0);
+        }
+        if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, s_, M, (const D*)dSu, M, dSdiag);
+        if (with_t1) r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, s_);           // T1 = G Ki Su
+        return r_;
+    };
+    if (want_grad && !het) {
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu (main)
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
+        hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
+        rc = su_reverse(sd_, true);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
@@ -692,35 +725,22 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (!want_grad) return 0;
     }
 
-    D* G = cv.take<D>(MM); D* T1 = cv.take<D>(MM); D* AKi = cv.take<D>(MM); D* T2 = cv.take<D>(MM); D* dKuu = cv.take<D>(MM); D* dSu = cv.take<D>(MM);
-    D* Gw = cv.take<D>(MP); D* dmud = cv.take<D>(MP); D* dZc = cv.take<D>(M * Q); D* dlsc = cv.take<D>(lsn); D* dvc = cv.take<D>(4);
     if (het) {
         hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const T*)Psi2, MM, G, MM);
         hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const T*)R, MP, Gw, MP);
+        // ---- core reverse mode (float64): the Su part on the side stream next to the Kuu part ---------------------------------
+        MXF_HIP(h, hipEventRecord(h->ev_fork, st));
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
+        rc = su_reverse(sd_, false);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, st);           // T1 = G Ki Su
+        if (rc) return rc;
     } else {
-        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Psi2 from the side stream
-        hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
+        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // side stream: Psi2 -> G, T1, dSu / dW / dSdiag (already done)
         hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
     }
-    // ---- core reverse mode (float64): the Su chain runs on the side stream next to the Kuu chain ----------------------
-    MXF_HIP(h, hipEventRecord(h->ev_fork, st));
-    MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
-    // side: dSu = -Ki G Ki + bP/2 (Sui - Ki); dW = 2 dSu W; dSdiag = diag(dSu)
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);            // T3 = Ki G
-    if (rc) return rc;
-    hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, 1.0, (const D*)Sui, -1.0, (const D*)Ki, dSu);   // Sui - Ki
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, tmp, M, 0, Ki, M, 0, 0.5 * bw * P, dSu, M, 0, 1, 0, sd_);
-    if (rc) return rc;
-    if (dW) {
-        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, Lsinv, M, 0, 1, 0, sd_);     // dW = 2 dSu W (Lsinv buffer is free)
-        if (rc) return rc;
-        hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (T)1, (const D*)Lsinv, dW, 0);
-    }
-    if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, sd_, M, (const D*)dSu, M, dSdiag);
-    MXF_HIP(h, hipEventRecord(h->ev_join, sd_));
     // main: dKuu = -Ki A_Ki Ki - bP/2 Ki; dmu = Ki Gw - b w
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, st);           // T1 = G Ki Su
-    if (rc) return rc;
     hipLaunchKernelGGL(aki_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)G, (const D*)T1, (const D*)Gw, (const D*)mud, (const D*)Su, bw, AKi);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, AKi, M, 0, 0.0, T2, M, 0, 1, 0, st);           // T2 = Ki A_Ki
     if (rc) return rc;
