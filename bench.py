@@ -117,6 +117,48 @@ def build_deepgp(N, Q, M, Dh, S_local, dtype, X, Y, distributed):
     return infr, loop
 
 
+def build_gp(N, Q, dtype, X, Y):
+    """BASELINE.json configs[1]: GPRegression, RBF-ARD, exact Cholesky (MAP of the kernel hyper-parameters and the noise)."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    kernel = RBF(input_dim=Q, ARD=True, variance=1., lengthscale=np.ones(Q), dtype=dtype)
+    m.Y = GPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, shape=(m.N, 1), dtype=dtype)
+    loop = BatchInferenceLoop()
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=loop, dtype=dtype)
+    infr.initialize(X=(N, Q), Y=(N, 1))
+    return m, infr, loop
+
+
+def cpu_baseline_gp(N, Q, X, Y, reps=2):
+    """The oracle's MAP step of the exact GP (Gram, potrf, trsm, autograd backward, Adam; float64, torch-CPU LAPACK/BLAS) at the full N."""
+    from oracle import gp_oracle as O
+    T = O.T
+    kern = O.RBF(Q, ARD=True)
+    raw = {'lengthscale': O.inv_softplus(T(np.ones(Q))), 'variance': O.inv_softplus(T([1.0])), 'noise_var': O.inv_softplus(T([0.01]))}
+    opt = O.MXNetAdam(1e-3)
+    hw = os.cpu_count() or 1
+    th = min(hw, 32)
+    torch.set_num_threads(th)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        lv = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        loss = O.map_gp_loss(kern, T(X), T(Y), lv, jitter=0.)
+        loss.backward()
+        raw = opt.step({k: v.detach() for k, v in lv.items()}, {k: v.grad for k, v in lv.items()})
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return {"value": 1.0 / t, "unit": "MAP-steps/sec", "cores": th, "kind": "port",
+            "sample": "oracle MAP step of the exact GP at the full N=%d (fwd + autograd bwd + Adam, float64, torch-CPU, %d threads): %.2f s" % (N, th, t)}
+
+
 def time_steps_multi(infr, loop, data, steps, warmup, lr, distributed):
     from mxfusion_amd.inference.batch_loop import _Adam
     import torch.distributed as dist
@@ -293,7 +335,7 @@ def main():
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--lr', type=float, default=1e-3)
-    ap.add_argument('--workload', default='svgp', choices=['svgp', 'deepgp'], help="'svgp' = the headline (configs[2]); 'deepgp' = configs[4]")
+    ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -314,6 +356,28 @@ def main():
     S_local = args.samples // world
     torch.manual_seed(1234 + rank)
 
+    if args.workload == 'gp':          # secondary workload: BASELINE.json configs[1] (exact GP, N=8192 D=8; does not shard: replicas only)
+        N, Q = (8192 if args.N == 65536 else args.N), args.Q
+        X, Y, _ = synth(N, Q, 1)
+        m, infr, loop = build_gp(N, Q, args.dtype, X, Y)
+        td = torch.float32 if args.dtype == 'float32' else torch.float64
+        data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]
+        dt, last_loss = time_steps_multi(infr, loop, data, args.steps, args.warmup, args.lr, False)
+        out = {"metric": "MAP-steps/sec, exact GPRegression (BASELINE.json configs[1])", "value": world * args.steps / dt, "unit": "MAP-steps/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
+               "config": {"workload": "GPRegression RBF-ARD N=%d Q=%d: Gram + potrf + trsm + closed-form reverse mode + Adam per step; "
+                                      "dense N x N Cholesky does not shard (replicas only)" % (N, Q)},
+               "last_loss": last_loss, "potrf_info": int(m.Y.factor.gp_log_pdf._last_info.abs().sum()),
+               "algorithmic_flops_per_step": N ** 3 / 3.0 + 2.0 * N ** 3 + 2.0 * N ** 3 / 3.0}
+        if rank == 0 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_gp(N, Q, X, Y)
+        if rank == 0:
+            print(json.dumps(out))
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.workload == 'deepgp':      # secondary workload: BASELINE.json configs[4] (2-layer SVGP deep GP, Matern52+RBF, N=131072 D=16 M=512/layer)
         N, Q, M, Dh = (131072 if args.N == 65536 else args.N), (16 if args.Q == 8 else args.Q), (512 if args.M == 1024 else args.M), args.hidden
         X, Y, _ = synth(N, Q, M)
