@@ -345,10 +345,14 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         static const int sk_env = getenv("MXF_GEMM_SPLITK") ? atoi(getenv("MXF_GEMM_SPLITK")) : 0;
         if (sk_env > 0 && K >= 4096) splitk = sk_env;
     }
-    int64_t kchunk = (K + splitk - 1) / splitk;
-    kchunk = (kchunk + BK - 1) / BK * BK;
-    splitk = (int)((K + kchunk - 1) / kchunk);
-    if (K == 0) { splitk = 1; kchunk = BK; }
+    int64_t kchunk = BK;
+    if (K > 0) {
+        kchunk = (K + splitk - 1) / splitk;
+        kchunk = (kchunk + BK - 1) / BK * BK;
+        splitk = (int)((K + kchunk - 1) / kchunk);
+    } else {
+        splitk = 1;      // empty contraction: C = beta C
+    }
     g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm: lower_only needs a square output");
     g.tm = tm; g.tn = tn;

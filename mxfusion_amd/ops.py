@@ -60,6 +60,8 @@ def gram(kind, X, X2, lengthscale, variance, ard, diag_add=None, jitter=0.0, out
     N2 = N if X2 is None else X2.shape[-2]
     if out is None:
         out = torch.empty((S, N, N2), dtype=X.dtype, device=X.device)
+    if N == 0 or N2 == 0:       # empty operand: nothing to compute (an empty tensor has a null data pointer, which the ABI reads as "no X2")
+        return out
     _lib.call('mxf_gram', _h(X), KIND[kind] if isinstance(kind, str) else kind, _dt(X), S, N, N2, Q,
               _p(X), _ss(X), _p(X2), _ss(X2), _p(lengthscale), int(bool(ard)), _ss(lengthscale),
               _p(variance), _ss(variance), _p(diag_add), _ss(diag_add), float(jitter), mode,
