@@ -436,3 +436,106 @@ def test_graph_captured_step_matches_eager(golden_dir):
     torch.manual_seed(0); np.random.seed(0)
     b = run(True)
     assert torch.allclose(a, b, rtol=1e-9, atol=1e-10), float((a - b).abs().max())
+
+
+def test_active_dims_and_their_gradients():
+    """kernel_test.py:302-369: kernels restricted to a subset of the input columns (kernel.py:119-123), alone and inside Add / Multiply;
+    the gradient w.r.t. the full input must vanish on the inactive columns."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern32, Linear
+    rng = np.random.RandomState(21)
+    N, N2, D = 11, 6, 5
+    X, X2 = rng.randn(2, N, D), rng.randn(1, N2, D)
+    G = rng.randn(2, N, N2)
+    kern = RBF(2, ARD=True, active_dims=[0, 3], dtype=DT) + Matern32(1, active_dims=[1], dtype=DT) * Linear(2, ARD=True, active_dims=[2, 4], dtype=DT)
+    okern = O.AddKernel([O.RBF(2, ARD=True, active_dims=[0, 3]),
+                         O.MultiplyKernel([O.Matern32(1, active_dims=[1]), O.Linear(2, ARD=True, active_dims=[2, 4])])])
+    vals = {'add_rbf_lengthscale': rng.rand(1, 2) + 0.6, 'add_rbf_variance': rng.rand(1, 1) + 0.5,
+            'add_mul_matern32_lengthscale': rng.rand(1, 1) + 0.8, 'add_mul_matern32_variance': rng.rand(1, 1) + 0.5,
+            'add_mul_linear_variances': rng.rand(1, 2) + 0.3}
+    assert sorted(kern.parameters) == sorted(vals)
+    dX, dX2 = _t(X).requires_grad_(True), _t(X2).requires_grad_(True)
+    dp = {k: _t(v).requires_grad_(True) for k, v in vals.items()}
+    oX, oX2 = O.T(X).clone().requires_grad_(True), O.T(X2).clone().requires_grad_(True)
+    op = {k: O.T(v).clone().requires_grad_(True) for k, v in vals.items()}
+    K, Ko = kern.K(None, dX, dX2, **dp), okern.K(oX, oX2, **op)
+    assert np.allclose(K.detach().cpu().numpy(), Ko.detach().numpy(), rtol=1e-11, atol=1e-12)
+    (K * _t(G)).sum().backward()
+    (Ko * O.T(G)).sum().backward()
+    assert np.allclose(dX.grad.cpu().numpy(), oX.grad.numpy(), rtol=1e-9, atol=1e-10)
+    assert np.allclose(dX2.grad.cpu().numpy(), oX2.grad.numpy(), rtol=1e-9, atol=1e-10)
+    for k in vals:
+        assert np.allclose(dp[k].grad.cpu().numpy(), op[k].grad.numpy(), rtol=1e-9, atol=1e-10), k
+    Kd = kern.Kdiag(None, dX.detach(), **{k: v.detach() for k, v in dp.items()})
+    assert np.allclose(Kd.cpu().numpy(), okern.Kdiag(oX.detach(), **{k: v.detach() for k, v in op.items()}).numpy(), rtol=1e-11)
+
+
+@pytest.mark.parametrize('module', ['gp', 'sgp'])
+def test_with_samples_gp_and_sparse_gp(module, golden_dir):
+    """gpregression_test.py:309-350 / sparsegpregression_test.py:287-330 (test_with_samples; smoke tests in the reference): latent
+    X ~ N(0, 1) with a mean-field q(X), S injected-noise samples, one SVI step -- here loss and flat gradient are checked against the oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression, SparseGPRegression
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, BatchInferenceLoop, create_Gaussian_meanfield
+    rng = np.random.RandomState(5)
+    N, Q, D, M, S = 10, 3, 2, 4, 5
+    Y, Z = rng.rand(N, D), rng.rand(M, Q)
+    ls, var, noise = rng.rand(Q) + 0.5, rng.rand(1) + 0.5, rng.rand(1) * 0.3 + 0.1
+    xm, xv, eps = rng.randn(N, Q), rng.rand(N, Q) * 0.1 + 0.01, rng.randn(S, N, Q)
+    m = Model()
+    m.N = Variable()
+    m.X = Normal.define_variable(mean=0, variance=1, shape=(m.N, Q))
+    m.noise_var = Variable(transformation=PositiveTransformation(), initial_value=_t(noise))
+    kernel = RBF(input_dim=Q, ARD=True, variance=_t(var), lengthscale=_t(ls), dtype=DT)
+    if module == 'gp':
+        m.Y = GPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, shape=(m.N, D), dtype=DT)
+    else:
+        m.Z = Variable(shape=(M, Q), initial_value=_t(Z))
+        m.Y = SparseGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, D), dtype=DT)
+        m.Y.factor.sgp_log_pdf.jitter = 1e-8
+    q = create_Gaussian_meanfield(model=m, observed=[m.Y], dtype=DT)
+    qX = q[m.X].factor
+    qX._rand_gen = MockRandomGenerator(_t(eps.reshape(-1)))
+    grads, losses = [], []
+
+    class Rec(BatchInferenceLoop):
+        def _exchange(self, param_dict):
+            grads.append(param_dict.flat.grad.clone())
+
+        def run(self, infr_executor, data, **kw):
+            def wrapped(*a):
+                out = infr_executor(*a)
+                losses.append(float(out[0].detach()))
+                return out
+            return super(Rec, self).run(wrapped, data, **kw)
+    infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S, observed=[m.Y]), grad_loop=Rec(), dtype=DT)
+    infr.initialize(Y=Y.shape)
+    infr.params[qX.mean] = _t(xm)
+    infr.params[qX.variance] = _t(xv)
+    infr.run(Y=_t(Y), max_iter=1, learning_rate=1e-3)
+
+    sp = O.softplus
+    raw = {n: O.inv_softplus(O.T(v)).clone().requires_grad_(True) for n, v in dict(ls=ls, var=var, noise=noise, xv=xv).items()}
+    lin = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(xm=xm, Z=Z).items()}
+    k = O.RBF(Q, ARD=True)
+    kp = {'rbf_lengthscale': sp(raw['ls'])[None], 'rbf_variance': sp(raw['var'])[None]}
+    Xs = lin['xm'][None] + O.T(eps) * torch.sqrt(sp(raw['xv']))[None]
+    if module == 'gp':
+        logL = O.gp_log_pdf(k, Xs, O.T(Y)[None], sp(raw['noise'])[None], kp)
+    else:
+        logL = O.sgp_log_pdf(k, Xs, O.T(Y)[None], lin['Z'][None], sp(raw['noise'])[None], kp, jitter=1e-8)
+    logq = O.normal_log_pdf(lin['xm'][None], sp(raw['xv'])[None], Xs).reshape(S, -1).sum(-1)
+    logp = O.normal_log_pdf(torch.zeros(1, dtype=torch.float64), torch.ones(1, dtype=torch.float64), Xs).reshape(S, -1).sum(-1)
+    obj = -(logL + logp - logq).mean()
+    obj.backward()
+    assert abs(losses[0] - float(obj)) < 1e-9 * max(1.0, abs(float(obj)))
+    P = infr.params
+    checks = [(m.noise_var, raw['noise']), (kernel.lengthscale, raw['ls']), (kernel.variance, raw['var']), (qX.mean, lin['xm']), (qX.variance, raw['xv'])]
+    if module == 'sgp':
+        checks.append((m.Z, lin['Z']))
+    for v, ref in checks:
+        o, n, _ = P._slices[v.uuid]
+        assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), v
