@@ -25,85 +25,6 @@ __device__ __forceinline__ double inv_sqrt(double d) {
 }
 constexpr int NBO = 512;   // outer panel
 
-// ---- 64x64 diagonal block Cholesky in LDS, one workgroup per batch item --------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, int64_t lda, int64_t sA, int64_t k0, int nb,
-                                                          int* __restrict__ info) {
-    __shared__ T a[NB][NB + 1];
-    __shared__ T col[NB];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    T* Ab = A + (int64_t)b * sA + k0 * lda + k0;
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, c = e % nb;
-        a[i][c] = (c <= i) ? Ab[(int64_t)i * lda + c] : (T)0;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        T d = a[j][j];
-        if (!(d > (T)0)) {   // not positive definite (or NaN): record the first failing pivot, keep going finite
-            if (tid == 0 && info && info[b] == 0) info[b] = (int)(k0 + j + 1);
-            d = (T)1;
-        }
-        const T rs = (T)1 / sqrt(d);
-        if (tid >= j && tid < nb) col[tid] = (tid == j) ? d * rs : a[tid][j] * rs;
-        __syncthreads();
-        {   // trailing update of the lower triangle: thread (tid&63) owns a column, rows strided by 4
-            const int c = j + 1 + (tid & 63);
-            if (c < nb) {
-                const T cc = col[c];
-                for (int i = c + (tid >> 6); i < nb; i += 4) a[i][c] -= col[i] * cc;
-            }
-        }
-        if (tid >= j && tid < nb) a[tid][j] = col[tid];
-        __syncthreads();
-    }
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, c = e % nb;
-        Ab[(int64_t)i * lda + c] = (c <= i) ? a[i][c] : (T)0;   // MXNet potrf zeroes the strict upper part
-    }
-}
-
-// ---- X L11^T = A21 (X overwrites A21): one row per lane, L11 broadcast from LDS ---------------------------
-template <typename T>
-__global__ __launch_bounds__(128) void solve_rows_kernel(T* __restrict__ A, int64_t lda, int64_t sA, int64_t k0, int nb,
-                                                          int64_t r0, int64_t nrows) {
-    __shared__ T l[NB][NB + 1];
-    __shared__ T t[128][NB + 1];
-    const int tid = threadIdx.x, b = blockIdx.y;
-    T* Ab = A + (int64_t)b * sA;
-    const T* L11 = Ab + k0 * lda + k0;
-    const int64_t rb = r0 + (int64_t)blockIdx.x * 128;
-    for (int e = tid; e < NB * NB; e += 128) {
-        const int i = e / NB, c = e % NB;
-        T v = (T)0;
-        if (i < nb && c < nb) { if (c <= i) v = L11[(int64_t)i * lda + c]; }
-        else if (i == c) v = (T)1;      // identity padding for ragged last block
-        l[i][c] = v;
-    }
-    for (int e = tid; e < 128 * NB; e += 128) {
-        const int r = e / NB, c = e % NB;
-        t[r][c] = (rb + r < r0 + nrows && c < nb) ? Ab[(rb + r) * lda + k0 + c] : (T)0;
-    }
-    __syncthreads();
-    T x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        T s = t[tid][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s = fma(-x[k], l[j][k], s);
-        x[j] = s / l[j][j];
-        __builtin_amdgcn_sched_barrier(0);   // keep the 2016 broadcast LDS reads from being hoisted (register blow-up)
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; ++j) t[tid][j] = x[j];
-    __syncthreads();
-    for (int e = tid; e < 128 * NB; e += 128) {
-        const int r = e / NB, c = e % NB;
-        if (rb + r < r0 + nrows && c < nb) Ab[(rb + r) * lda + k0 + c] = t[r][c];
-    }
-}
-
 // ---- fused panel step: every workgroup re-factors the 64x64 diagonal block in LDS (rank-4 blocked: 16 barrier pairs instead of
 // 64) and then solves its own 128 rows against it; workgroup 0 owns the diagonal block itself.  One launch per 64-wide block column
 // instead of two (diag + solve), and no dependent launch gap between them.
