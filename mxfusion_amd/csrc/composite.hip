@@ -369,22 +369,15 @@ __global__ void add_diag_kernel(int64_t n, double* __restrict__ A, double v) {
 // one thread per column n: beta_d = 1/noise[n|0][d|0], bs = sum_d beta_d, e = y - u, q = k^T H0 k;
 //   l_s += -1/2 sum_d (beta_d e_d^2 + log 2pi + log noise_d) - 1/2 bs (var - q)
 // reverse: dY = -a1 beta.e ; Eb = a1 beta.e (for Gw = Kuf Eb) ; T[:,n] <- a1 (bs T[:,n] + w (beta.e)) = dKuf ; Ksc = 1/2 a1 bs Kuf[:,n]
+// per-column quantities shared by the two passes below
 template <typename T>
-__global__ __launch_bounds__(256) void svgp_het_mid_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf, T* __restrict__ Text,
-                                                           const T* __restrict__ Y, int64_t sY, const T* __restrict__ w, const T* __restrict__ noise,
-                                                           int64_t nrows, int ncols, const double* __restrict__ var,
-                                                           const T* __restrict__ kdiag /* per column, or NULL -> var[0] */, double a1,
-                                                           int want_grad, T* __restrict__ Eb, T* __restrict__ Ksc, T* __restrict__ dY,
-                                                           int dY_shared, T* __restrict__ dnoise, T* __restrict__ dkdiag,
-                                                           double* __restrict__ scal /* [S][2]: l_s, sum bs */) {
-    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (n >= SB) return;
-    const int64_t s = n / B, nb = n % B;
-    const int64_t nr = (nrows > 1) ? nb : 0;
-    constexpr int PMAX = 8;
-    double be[PMAX], beta[PMAX], e2b = 0, lg = 0, bs = 0;
+__device__ __forceinline__ void het_column(int64_t n, int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Text, const T* __restrict__ Y,
+                                           int64_t sY, const T* __restrict__ noise, int64_t nrows, int ncols, double (&be)[8], double (&beta)[8],
+                                           double& e2b, double& lg, double& bs) {
+    const int64_t s = n / B, nb = n % B, nr = (nrows > 1) ? nb : 0;
+    e2b = 0; lg = 0; bs = 0;
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
+    for (int p = 0; p < 8; ++p) {
         be[p] = 0; beta[p] = 0;
         if (p < P) {
             const double nz = (double)noise[nr * ncols + (ncols > 1 ? p : 0)];
@@ -394,31 +387,81 @@ __global__ __launch_bounds__(256) void svgp_het_mid_kernel(int64_t SB, int64_t B
             e2b += be[p] * e; lg += LOG2PI + log(nz); bs += beta[p];
         }
     }
+}
+// pass 1, grid (column tiles, row chunks of RCH rows): q_n partial sums (atomics into qbuf) and, for the reverse mode, the in-place
+// T[:,n] <- a1 (bs T[:,n] + w (beta.e)) and Ksc = 1/2 a1 bs Kuf[:,n].  Rows are split over blockIdx.y so that M x S*B pairs fill the chip
+// (one thread per column alone left it latency bound: 4 ms at 512 x 131072).
+constexpr int HET_RCH = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void svgp_het_rows_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf, T* __restrict__ Text,
+                                                            const T* __restrict__ Y, int64_t sY, const T* __restrict__ w, const T* __restrict__ noise,
+                                                            int64_t nrows, int ncols, double a1, int want_grad, T* __restrict__ Ksc,
+                                                            T* __restrict__ qbuf) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= SB) return;
+    double be[8], beta[8], e2b, lg, bs;
+    het_column<T>(n, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
+    const int64_t m0 = (int64_t)blockIdx.y * HET_RCH, m1 = (m0 + HET_RCH < M) ? m0 + HET_RCH : M;
     double q = 0;
-    for (int64_t m = 0; m < M; ++m) {
+    for (int64_t m = m0; m < m1; ++m) {
         const double k = (double)Kuf[m * SB + n], t = (double)Text[m * SB + n];
         q = fma(k, t, q);
         if (want_grad) {
             double we = 0;
 #pragma unroll
-            for (int p = 0; p < PMAX; ++p) if (p < P) we = fma((double)w[m * P + p], be[p], we);
+            for (int p = 0; p < 8; ++p) if (p < P) we = fma((double)w[m * P + p], be[p], we);
             Text[m * SB + n] = (T)(a1 * (bs * t + we));
             Ksc[m * SB + n] = (T)(0.5 * a1 * bs * k);
         }
     }
-    const double vk = kdiag ? (double)kdiag[n] : var[0];
-    if (want_grad && dkdiag) dkdiag[n] = (T)(-0.5 * a1 * bs);
-    atomic_add(scal + 2 * s, -0.5 * (e2b + lg) - 0.5 * bs * (vk - q));
-    atomic_add(scal + 2 * s + 1, bs);
+    atomic_add(qbuf + n, (T)q);
+}
+// pass 2, one thread per column: l_s, sum bs, dY, Eb, dnoise, dKdiag.  Sums that land on ONE address (the per-sample scalars; dnoise when the
+// noise is shared by all rows) are reduced over the block first -- 131 072 same-address float64 atomics cost 4 ms.
+template <typename T>
+__global__ __launch_bounds__(256) void svgp_het_cols_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Text,
+                                                            const T* __restrict__ Y, int64_t sY, const T* __restrict__ noise, int64_t nrows,
+                                                            int ncols, const double* __restrict__ var,
+                                                            const T* __restrict__ kdiag /* per column, or NULL -> var[0] */, double a1,
+                                                            int want_grad, const T* __restrict__ qbuf, T* __restrict__ Eb, T* __restrict__ dY,
+                                                            int dY_shared, T* __restrict__ dnoise, T* __restrict__ dkdiag,
+                                                            double* __restrict__ scal /* [S][2]: l_s, sum bs */) {
+    __shared__ double red[16];
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = n < SB;
+    const int64_t nn = valid ? n : SB - 1;
+    const int64_t s = nn / B, nb = nn % B, nr = (nrows > 1) ? nb : 0;
+    double be[8], beta[8], e2b, lg, bs;
+    // NOTE: U (rows M.. of Text) is untouched by pass 1, so e is recomputed from the same values
+    het_column<T>(nn, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
+    const double q = (double)qbuf[nn];
+    const double vk = kdiag ? (double)kdiag[nn] : var[0];
+    if (valid && want_grad && dkdiag) dkdiag[n] = (T)(-0.5 * a1 * bs);
+    const double lval = valid ? -0.5 * (e2b + lg) - 0.5 * bs * (vk - q) : 0.0, bval = valid ? bs : 0.0;
+    const int64_t n0 = (int64_t)blockIdx.x * 256, n1 = (n0 + 255 < SB - 1) ? n0 + 255 : SB - 1;
+    const bool one_sample = (n0 / B) == (n1 / B);
+    if (one_sample) {
+        const double ls_ = block_sum<double>(lval, red), bb_ = block_sum<double>(bval, red);
+        if (threadIdx.x == 0) { atomic_add(scal + 2 * (n0 / B), ls_); atomic_add(scal + 2 * (n0 / B) + 1, bb_); }
+    } else if (valid) {
+        atomic_add(scal + 2 * s, lval);
+        atomic_add(scal + 2 * s + 1, bval);
+    }
     if (!want_grad) return;
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p)
+    for (int p = 0; p < 8; ++p)
         if (p < P) {
-            Eb[n * P + p] = (T)(a1 * be[p]);
-            if (dY) { const T g = (T)(-a1 * be[p]); if (dY_shared) atomic_add(dY + nb * P + p, g); else dY[n * P + p] = g; }
+            if (valid) {
+                Eb[n * P + p] = (T)(a1 * be[p]);
+                if (dY) { const T g = (T)(-a1 * be[p]); if (dY_shared) atomic_add(dY + nb * P + p, g); else dY[n * P + p] = g; }
+            }
             if (dnoise) {
-                const double g = a1 * (0.5 * be[p] * be[p] - 0.5 * beta[p] + 0.5 * (vk - q) * beta[p] * beta[p]);
-                atomic_add(dnoise + nr * ncols + (ncols > 1 ? p : 0), (T)g);
+                const double g = valid ? a1 * (0.5 * be[p] * be[p] - 0.5 * beta[p] + 0.5 * (vk - q) * beta[p] * beta[p]) : 0.0;
+                if (nrows > 1) { if (valid) atomic_add(dnoise + nr * ncols + (ncols > 1 ? p : 0), (T)g); }
+                else {
+                    const double gs = block_sum<double>(g, red);          // shared noise: one address per output column
+                    if (threadIdx.x == 0) atomic_add(dnoise + (ncols > 1 ? p : 0), (T)gs);
+                }
             }
         }
 }
@@ -458,7 +501,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     for (int i = 0; i < 9; ++i) acc(MM, 8);   // L, Linv, Ki, Su(Ls), Lsinv, Sui, KiSu, H0, tmp
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
-    acc((size_t)(M + P) * SB, sizeof(T));
+    acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB, sizeof(T));
     // float32 streaming: the two big GEMMs run on the bf16 matrix pipe from three-term split planes of their operands (gemm_split.hip)
     static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
@@ -476,7 +519,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* Sui = cv.take<D>(MM); D* KiSu = cv.take<D>(MM); D* H0 = cv.take<D>(MM); D* tmp = cv.take<D>(MM);
     D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
-    T* Text = cv.take<T>((size_t)(M + P) * SB);
+    T* Text = cv.take<T>((size_t)(M + P) * SB); T* qbuf = cv.take<T>((size_t)SB);
     unsigned short* plKfu = nullptr; unsigned short* plH0 = nullptr; unsigned short* plKuf = nullptr;
     T* Kuf = nullptr; T* Kfu = nullptr; T* Psi2 = nullptr; T* R = nullptr; T* Eb = nullptr;
     float* gscr0 = nullptr; float* gscr1 = nullptr;
@@ -684,9 +727,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             if (dnoise) MXF_HIP(h, hipMemsetAsync(dnoise, 0, sizeof(T) * (size_t)nrows * ncols, st));
         }
         T* Ksc = Kfu;   // the transposed-Gram slot is unused on this path
-        hipLaunchKernelGGL((svgp_het_mid_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Kuf, Text, Y, sY,
-                           (const T*)wT, noise, nrows, ncols, (const D*)vard, mat.Kdiag, a1, want_grad, Eb, Ksc, dY, dY_shared, dnoise,
-                           mat.dKdiag, scal);
+        MXF_HIP(h, hipMemsetAsync(qbuf, 0, sizeof(T) * (size_t)SB, st));
+        hipLaunchKernelGGL((svgp_het_rows_kernel<T>), dim3((unsigned)((SB + 255) / 256), (unsigned)((M + HET_RCH - 1) / HET_RCH)), dim3(256), 0, st, SB, B, M,
+                           P, (const T*)Kuf, Text, Y, sY, (const T*)wT, noise, nrows, ncols, a1, want_grad, Ksc, qbuf);
+        hipLaunchKernelGGL((svgp_het_cols_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Text, Y, sY, noise,
+                           nrows, ncols, (const D*)vard, mat.Kdiag, a1, want_grad, (const T*)qbuf, Eb, dY, dY_shared, dnoise, mat.dKdiag, scal);
         hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
                            (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
         MXF_LAUNCH_CHECK(h);
