@@ -207,12 +207,13 @@ int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int64_t B, int
 
 /* The same bound from MATERIALISED Gram matrices, ONE sample per call: for kernels whose K is composed on the host
  * (AddKernel / MultiplyKernel, add_kernel.py:44-68, multiply_kernel.py:44-67 -- the deep-GP configuration's Matern52+RBF).
- *   Kuu (M,M) WITHOUT jitter (added here, svgp_regression.py:70-72), Kuf (M,B), Kdiag (B), Y (B,P) [minus mean],
+ *   Kuu (M,M) WITHOUT jitter (added here, svgp_regression.py:70-72), Kuf (M,B), Kdiag (B), Y (S,B,P) [minus mean]: S samples of the
+ *   outputs over the SAME inputs (a hidden layer of a deep GP); logL (S), dY (S,B,P); the other gradients are summed over the samples;
  *   noise_var (noise_rows, noise_cols) as above.
  * if want_grad: gscale * d logL / d(.) WRITTEN into dKuu (M,M) dKuf (M,B) dKdiag (B) dY dnoise dmu dW dSdiag; the caller chains
  * dKuu / dKuf / dKdiag into the kernels' own reverse mode (mxf_gram_bwd).                                                        */
-int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int64_t B, int64_t M, int P, const void* Kuu, const void* Kuf, const void* Kdiag,
-                        const void* Y, const void* noise_var, int64_t noise_rows, int noise_cols, const void* qU_mean,
+int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int S, int64_t B, int64_t M, int P, const void* Kuu, const void* Kuf, const void* Kdiag,
+                        const void* Y, int64_t strideS_Y, const void* noise_var, int64_t noise_rows, int noise_cols, const void* qU_mean,
                         const void* qU_cov_W, const void* qU_cov_diag, double jitter, double scaling, double gscale, void* logL,
                         int* info, int want_grad, void* dKuu, void* dKuf, void* dKdiag, void* dY, void* dnoise, void* dmu,
                         void* dW, void* dSdiag, void* stream);

@@ -369,12 +369,13 @@ __global__ void add_diag_kernel(int64_t n, double* __restrict__ A, double v) {
 // one thread per column n: beta_d = 1/noise[n|0][d|0], bs = sum_d beta_d, e = y - u, q = k^T H0 k;
 //   l_s += -1/2 sum_d (beta_d e_d^2 + log 2pi + log noise_d) - 1/2 bs (var - q)
 // reverse: dY = -a1 beta.e ; Eb = a1 beta.e (for Gw = Kuf Eb) ; T[:,n] <- a1 (bs T[:,n] + w (beta.e)) = dKuf ; Ksc = 1/2 a1 bs Kuf[:,n]
-// per-column quantities shared by the two passes below
+// per-column quantities of one Y sample (shared by the two passes below).  ys = index of the Y sample: the column's own sample, or -- when
+// X (hence Kuf) is shared and only Y is sampled -- one of the SY samples that share the column
 template <typename T>
-__device__ __forceinline__ void het_column(int64_t n, int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Text, const T* __restrict__ Y,
-                                           int64_t sY, const T* __restrict__ noise, int64_t nrows, int ncols, double (&be)[8], double (&beta)[8],
-                                           double& e2b, double& lg, double& bs) {
-    const int64_t s = n / B, nb = n % B, nr = (nrows > 1) ? nb : 0;
+__device__ __forceinline__ void het_column(int64_t n, int64_t ys, int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Text,
+                                           const T* __restrict__ Y, int64_t sY, const T* __restrict__ noise, int64_t nrows, int ncols,
+                                           double (&be)[8], double (&beta)[8], double& e2b, double& lg, double& bs) {
+    const int64_t nb = n % B, nr = (nrows > 1) ? nb : 0;
     e2b = 0; lg = 0; bs = 0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -382,25 +383,30 @@ __device__ __forceinline__ void het_column(int64_t n, int64_t SB, int64_t B, int
         if (p < P) {
             const double nz = (double)noise[nr * ncols + (ncols > 1 ? p : 0)];
             beta[p] = 1.0 / nz;
-            const double e = (double)Y[s * sY + nb * P + p] - (double)Text[(M + p) * SB + n];
+            const double e = (double)Y[ys * sY + nb * P + p] - (double)Text[(M + p) * SB + n];
             be[p] = beta[p] * e;
             e2b += be[p] * e; lg += LOG2PI + log(nz); bs += beta[p];
         }
     }
 }
 // pass 1, grid (column tiles, row chunks of RCH rows): q_n partial sums (atomics into qbuf) and, for the reverse mode, the in-place
-// T[:,n] <- a1 (bs T[:,n] + w (beta.e)) and Ksc = 1/2 a1 bs Kuf[:,n].  Rows are split over blockIdx.y so that M x S*B pairs fill the chip
-// (one thread per column alone left it latency bound: 4 ms at 512 x 131072).
+// T[:,n] <- a1 (SY bs T[:,n] + w sum_ys(beta.e)) and Ksc = 1/2 a1 SY bs Kuf[:,n].  Rows are split over blockIdx.y so that M x S*B pairs fill
+// the chip (one thread per column alone left it latency bound: 4 ms at 512 x 131072).
 constexpr int HET_RCH = 32;
 template <typename T>
-__global__ __launch_bounds__(256) void svgp_het_rows_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Kuf, T* __restrict__ Text,
-                                                            const T* __restrict__ Y, int64_t sY, const T* __restrict__ w, const T* __restrict__ noise,
-                                                            int64_t nrows, int ncols, double a1, int want_grad, T* __restrict__ Ksc,
-                                                            T* __restrict__ qbuf) {
+__global__ __launch_bounds__(256) void svgp_het_rows_kernel(int64_t SB, int64_t B, int64_t M, int P, int SY, const T* __restrict__ Kuf,
+                                                            T* __restrict__ Text, const T* __restrict__ Y, int64_t sY, const T* __restrict__ w,
+                                                            const T* __restrict__ noise, int64_t nrows, int ncols, double a1, int want_grad,
+                                                            T* __restrict__ Ksc, T* __restrict__ qbuf) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= SB) return;
-    double be[8], beta[8], e2b, lg, bs;
-    het_column<T>(n, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
+    double be[8], beta[8], e2b, lg, bs, besum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ys = 0; ys < SY; ++ys) {
+        het_column<T>(n, SY > 1 ? ys : n / B, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) besum[p] += be[p];
+    }
+    const double bst = bs * (double)SY;
     const int64_t m0 = (int64_t)blockIdx.y * HET_RCH, m1 = (m0 + HET_RCH < M) ? m0 + HET_RCH : M;
     double q = 0;
     for (int64_t m = m0; m < m1; ++m) {
@@ -409,9 +415,9 @@ __global__ __launch_bounds__(256) void svgp_het_rows_kernel(int64_t SB, int64_t 
         if (want_grad) {
             double we = 0;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) if (p < P) we = fma((double)w[m * P + p], be[p], we);
-            Text[m * SB + n] = (T)(a1 * (bs * t + we));
-            Ksc[m * SB + n] = (T)(0.5 * a1 * bs * k);
+            for (int p = 0; p < 8; ++p) if (p < P) we = fma((double)w[m * P + p], besum[p], we);
+            Text[m * SB + n] = (T)(a1 * (bst * t + we));
+            Ksc[m * SB + n] = (T)(0.5 * a1 * bst * k);
         }
     }
     atomic_add(qbuf + n, (T)q);
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) void svgp_het_rows_kernel(int64_t SB, int64_t 
 // pass 2, one thread per column: l_s, sum bs, dY, Eb, dnoise, dKdiag.  Sums that land on ONE address (the per-sample scalars; dnoise when the
 // noise is shared by all rows) are reduced over the block first -- 131 072 same-address float64 atomics cost 4 ms.
 template <typename T>
-__global__ __launch_bounds__(256) void svgp_het_cols_kernel(int64_t SB, int64_t B, int64_t M, int P, const T* __restrict__ Text,
+__global__ __launch_bounds__(256) void svgp_het_cols_kernel(int64_t SB, int64_t B, int64_t M, int P, int SY, const T* __restrict__ Text,
                                                             const T* __restrict__ Y, int64_t sY, const T* __restrict__ noise, int64_t nrows,
                                                             int ncols, const double* __restrict__ var,
                                                             const T* __restrict__ kdiag /* per column, or NULL -> var[0] */, double a1,
@@ -431,32 +437,48 @@ __global__ __launch_bounds__(256) void svgp_het_cols_kernel(int64_t SB, int64_t 
     const bool valid = n < SB;
     const int64_t nn = valid ? n : SB - 1;
     const int64_t s = nn / B, nb = nn % B, nr = (nrows > 1) ? nb : 0;
-    double be[8], beta[8], e2b, lg, bs;
-    // NOTE: U (rows M.. of Text) is untouched by pass 1, so e is recomputed from the same values
-    het_column<T>(nn, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
     const double q = (double)qbuf[nn];
     const double vk = kdiag ? (double)kdiag[nn] : var[0];
-    if (valid && want_grad && dkdiag) dkdiag[n] = (T)(-0.5 * a1 * bs);
-    const double lval = valid ? -0.5 * (e2b + lg) - 0.5 * bs * (vk - q) : 0.0, bval = valid ? bs : 0.0;
     const int64_t n0 = (int64_t)blockIdx.x * 256, n1 = (n0 + 255 < SB - 1) ? n0 + 255 : SB - 1;
     const bool one_sample = (n0 / B) == (n1 / B);
-    if (one_sample) {
-        const double ls_ = block_sum<double>(lval, red), bb_ = block_sum<double>(bval, red);
-        if (threadIdx.x == 0) { atomic_add(scal + 2 * (n0 / B), ls_); atomic_add(scal + 2 * (n0 / B) + 1, bb_); }
-    } else if (valid) {
-        atomic_add(scal + 2 * s, lval);
-        atomic_add(scal + 2 * s + 1, bval);
+    double besum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bs = 0;
+    for (int ys = 0; ys < SY; ++ys) {
+        double be[8], beta[8], e2b, lg;
+        // NOTE: U (rows M.. of Text) is untouched by pass 1, so e is recomputed from the same values
+        const int64_t sidx = SY > 1 ? ys : s;
+        het_column<T>(nn, sidx, SB, B, M, P, Text, Y, sY, noise, nrows, ncols, be, beta, e2b, lg, bs);
+        const double lval = valid ? -0.5 * (e2b + lg) - 0.5 * bs * (vk - q) : 0.0, bval = valid ? bs : 0.0;
+        if (one_sample || SY > 1) {
+            const double ls_ = block_sum<double>(lval, red), bb_ = block_sum<double>(bval, red);
+            const int64_t sw = SY > 1 ? ys : n0 / B;
+            if (threadIdx.x == 0) { atomic_add(scal + 2 * sw, ls_); atomic_add(scal + 2 * sw + 1, bb_); }
+        } else if (valid) {
+            atomic_add(scal + 2 * s, lval);
+            atomic_add(scal + 2 * s + 1, bval);
+        }
+        if (want_grad) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if (p < P) {
+                    besum[p] += be[p];
+                    gn[p] += a1 * (0.5 * be[p] * be[p] - 0.5 * beta[p] + 0.5 * (vk - q) * beta[p] * beta[p]);
+                    if (valid && dY) {
+                        const T g = (T)(-a1 * be[p]);
+                        if (SY > 1) dY[(ys * B + nb) * P + p] = g;
+                        else if (dY_shared) atomic_add(dY + nb * P + p, g);
+                        else dY[n * P + p] = g;
+                    }
+                }
+        }
     }
     if (!want_grad) return;
+    if (valid && dkdiag) dkdiag[n] = (T)(-0.5 * a1 * bs * (double)SY);
 #pragma unroll
     for (int p = 0; p < 8; ++p)
         if (p < P) {
-            if (valid) {
-                Eb[n * P + p] = (T)(a1 * be[p]);
-                if (dY) { const T g = (T)(-a1 * be[p]); if (dY_shared) atomic_add(dY + nb * P + p, g); else dY[n * P + p] = g; }
-            }
+            if (valid) Eb[n * P + p] = (T)(a1 * besum[p]);
             if (dnoise) {
-                const double g = valid ? a1 * (0.5 * be[p] * be[p] - 0.5 * beta[p] + 0.5 * (vk - q) * beta[p] * beta[p]) : 0.0;
+                const double g = valid ? gn[p] : 0.0;
                 if (nrows > 1) { if (valid) atomic_add(dnoise + nr * ncols + (ncols > 1 ? p : 0), (T)g); }
                 else {
                     const double gs = block_sum<double>(g, red);          // shared noise: one address per output column
@@ -484,12 +506,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (P > 8) MXF_FAIL(h, -3, "mxf_svgp_logpdf: P > 8 outputs not supported");
     if ((nrows != 1 && nrows != B) || (ncols != 1 && ncols != P)) MXF_FAIL(h, -2, "mxf_svgp_logpdf: noise_var must be (1|B, 1|P)");
     const bool use_mat = mat.Kuu != nullptr;
-    if (use_mat && S != 1) MXF_FAIL(h, -3, "mxf_svgp_logpdf_mat: one sample per call");
-    const bool het = nrows > 1 || ncols > 1 || use_mat;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
+    // sampled Y over shared X (hence shared Kuf, T, U): the S samples share the B columns -- generic path, the data term is quadratic in Y
+    const bool ysamp = S > 1 && sX == 0 && sY != 0;
+    if (ysamp && sY != B * P) MXF_FAIL(h, -2, "mxf_svgp_logpdf: Y samples must be contiguous");
+    const bool het = nrows > 1 || ncols > 1 || use_mat || ysamp;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
-    const int SS = (sX == 0 && sY == 0) ? 1 : S;   // samples that need their own columns
-    // when X is shared but Y is sampled we still lay S copies of the columns (rare); X columns repeat
-    if (SS > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: sampled Y with shared X not supported in the fused path");
+    if (S > 1 && sX == 0 && sY == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S > 1 with neither X nor Y sampled");
+    const int SS = (sX == 0) ? 1 : S;   // samples that need their own columns
+    const int SYc = ysamp ? S : 1;     // Y samples per column
     const int64_t SB = (int64_t)SS * B, MM = M * M, MP = M * P;
     const int lsn = ard ? Q : 1;
     const double a1 = gscale * scaling, bw = gscale * (double)S;
@@ -714,12 +738,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
-    if (S > 1 && sX == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S>1 requires sampled X (loop over samples on the host otherwise)");
     D* dnz = nullptr; D* dvdir = nullptr;
     if (het) {
         if (want_grad) {
             dvdir = sc + 5;
-            if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(sY == 0 ? B : SB) * P, st));
+            if (dY) MXF_HIP(h, hipMemsetAsync(dY, 0, sizeof(T) * (size_t)(ysamp ? (int64_t)S * B : (sY == 0 ? B : SB)) * P, st));
             if (dZ && !use_mat) MXF_HIP(h, hipMemsetAsync(dZ, 0, sizeof(T) * M * Q, st));
             if (dls && !use_mat) MXF_HIP(h, hipMemsetAsync(dls, 0, sizeof(T) * lsn, st));
             if (dvar && !use_mat) MXF_HIP(h, hipMemsetAsync(dvar, 0, sizeof(T), st));
@@ -729,8 +752,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         T* Ksc = Kfu;   // the transposed-Gram slot is unused on this path
         MXF_HIP(h, hipMemsetAsync(qbuf, 0, sizeof(T) * (size_t)SB, st));
         hipLaunchKernelGGL((svgp_het_rows_kernel<T>), dim3((unsigned)((SB + 255) / 256), (unsigned)((M + HET_RCH - 1) / HET_RCH)), dim3(256), 0, st, SB, B, M,
-                           P, (const T*)Kuf, Text, Y, sY, (const T*)wT, noise, nrows, ncols, a1, want_grad, Ksc, qbuf);
-        hipLaunchKernelGGL((svgp_het_cols_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, (const T*)Text, Y, sY, noise,
+                           P, SYc, (const T*)Kuf, Text, Y, sY, (const T*)wT, noise, nrows, ncols, a1, want_grad, Ksc, qbuf);
+        hipLaunchKernelGGL((svgp_het_cols_kernel<T>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, SB, B, M, P, SYc, (const T*)Text, Y, sY, noise,
                            nrows, ncols, (const D*)vard, mat.Kdiag, a1, want_grad, (const T*)qbuf, Eb, dY, dY_shared, dnoise, mat.dKdiag, scal);
         hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
                            (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
@@ -1067,19 +1090,21 @@ extern "C" int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int
                          dnoise, dmu, dW, dSdiag, dls, dvar, stream);
 }
 
-extern "C" int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int64_t B, int64_t M, int P, const void* Kuu, const void* Kuf, const void* Kdiag,
-                                   const void* Y, const void* noise_var, int64_t noise_rows, int noise_cols, const void* qU_mean,
+extern "C" int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int S, int64_t B, int64_t M, int P, const void* Kuu, const void* Kuf, const void* Kdiag,
+                                   const void* Y, int64_t strideS_Y, const void* noise_var, int64_t noise_rows, int noise_cols, const void* qU_mean,
                                    const void* qU_cov_W, const void* qU_cov_diag, double jitter, double scaling, double gscale, void* logL,
                                    int* info, int want_grad, void* dKuu, void* dKuf, void* dKdiag, void* dY, void* dnoise, void* dmu,
                                    void* dW, void* dSdiag, void* stream) {
     if (!h) return -1;
-    if (B <= 0 || M <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: bad shape");
+    if (S <= 0 || B <= 0 || M <= 0 || P <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: bad shape");
+    if (S > 1 && strideS_Y != B * P) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: S > 1 needs contiguous Y samples (S, B, P)");
+    const int64_t sYv = S > 1 ? strideS_Y : 0;
     if (!Kuu || !Kuf || !Kdiag || !Y || !noise_var || !qU_mean || !qU_cov_W || !qU_cov_diag || !logL) MXF_FAIL(h, -2, "mxf_svgp_logpdf_mat: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MXF_F32) {
         SvgpMat<float> m; m.Kuu = (const float*)Kuu; m.Kuf = (const float*)Kuf; m.Kdiag = (const float*)Kdiag;
         m.dKuu = (float*)dKuu; m.dKuf = (float*)dKuf; m.dKdiag = (float*)dKdiag;
-        return svgp_logpdf_typed<float>(h, MXF_K_RBF, dtype, 1, B, M, 1, P, (const float*)Kuf /*unused X*/, 0, (const float*)Y, 0, nullptr,
+        return svgp_logpdf_typed<float>(h, MXF_K_RBF, dtype, S, B, M, 1, P, (const float*)Kuf /*unused X*/, 0, (const float*)Y, sYv, nullptr,
                                         (const float*)noise_var, noise_rows, noise_cols, (const float*)qU_mean, (const float*)qU_cov_W,
                                         (const float*)qU_cov_diag, nullptr, 0, nullptr, jitter, scaling, gscale, (float*)logL, info, want_grad,
                                         nullptr, (float*)dY, nullptr, (float*)dnoise, (float*)dmu, (float*)dW, (float*)dSdiag, nullptr, nullptr, st, m);
@@ -1087,7 +1112,7 @@ extern "C" int mxf_svgp_logpdf_mat(mxf_handle h, int dtype, int64_t B, int64_t M
     if (dtype == MXF_F64) {
         SvgpMat<double> m; m.Kuu = (const double*)Kuu; m.Kuf = (const double*)Kuf; m.Kdiag = (const double*)Kdiag;
         m.dKuu = (double*)dKuu; m.dKuf = (double*)dKuf; m.dKdiag = (double*)dKdiag;
-        return svgp_logpdf_typed<double>(h, MXF_K_RBF, dtype, 1, B, M, 1, P, (const double*)Kuf, 0, (const double*)Y, 0, nullptr,
+        return svgp_logpdf_typed<double>(h, MXF_K_RBF, dtype, S, B, M, 1, P, (const double*)Kuf, 0, (const double*)Y, sYv, nullptr,
                                          (const double*)noise_var, noise_rows, noise_cols, (const double*)qU_mean, (const double*)qU_cov_W,
                                          (const double*)qU_cov_diag, nullptr, 0, nullptr, jitter, scaling, gscale, (double*)logL, info, want_grad,
                                          nullptr, (double*)dY, nullptr, (double*)dnoise, (double*)dmu, (double*)dW, (double*)dSdiag, nullptr, nullptr,

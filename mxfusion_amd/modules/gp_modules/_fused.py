@@ -58,23 +58,25 @@ class SVGPLogPdfFn(torch.autograd.Function):
 
 
 class SVGPMatLogPdfFn(torch.autograd.Function):
-    """mxf_svgp_logpdf_mat for ONE sample (arrays carry a unit sample axis): the bound from materialised Kuu / Kuf / Kdiag; their
-    gradients flow on into the kernels' own reverse mode (combination kernels)."""
+    """mxf_svgp_logpdf_mat: the bound from materialised Kuu / Kuf / Kdiag (one sample of the inputs: unit sample axes) for S >= 1 samples of Y;
+    the gradients of mean_S(logL) flow on into the kernels' own reverse mode (combination kernels)."""
 
     @staticmethod
     def forward(ctx, jitter, scaling, Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag):
         want = any(ctx.needs_input_grad[2:])
-        r = ops.svgp_logpdf_mat(Kuu[0], Kuf[0], Kdiag[0], Y[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0],
-                                jitter=jitter, scaling=scaling, gscale=1.0, want_grad=want)
+        S = Y.shape[0]
+        r = ops.svgp_logpdf_mat(Kuu[0], Kuf[0], Kdiag[0], Y if S > 1 else Y[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0],
+                                sdiag[0], jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
         if want:
             ctx.grads = (r['dKuu'], r['dKuf'], r['dKdiag'], r['dY'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'])
             ctx.shapes = tuple(t.shape for t in (Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag))
+            ctx.S = S
         ctx.mark_non_differentiable(r['info'])
         return r['logL'], r['info']
 
     @staticmethod
     def backward(ctx, g, *_):
-        c = g.sum()
+        c = g.sum()          # gradients were produced for mean_S(logL) (gscale = 1/S): scale by sum(grad_output), as SVGPLogPdfFn does
         out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:])]
         return (None, None) + tuple(out)
 

@@ -51,7 +51,7 @@ class SVGPRegressionLogPdf(VariationalInference):
             Y = Y - variables[self.model.mean]
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
         scaling = float(self.log_pdf_scaling)
-        if all(_S(t) == 1 for t in shared) and not (_S(X) == 1 and _S(Y) > 1):
+        if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
             logL, info = SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
         else:
             # sampled hyper-parameters / inducing inputs (runtime_variable.py:102-118 broadcast semantics): one fused
@@ -75,6 +75,11 @@ class SVGPRegressionLogPdf(VariationalInference):
         Kuf = kern.K(F, Z, X, **kern_params)
         Kdiag = kern.Kdiag(F, X, **kern_params)
         ops_in = (Kuu, Kuf, Kdiag, Y, noise_var, mu, S_W, S_diag)
+        if all(_S(t) == 1 for t in (Kuu, Kuf, Kdiag, noise_var, mu, S_W, S_diag)):
+            # shared inputs and parameters, Y possibly sampled (a hidden layer of a deep GP): ONE call for all samples of Y
+            logL, info = SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *ops_in)
+            self._last_info = info
+            return logL * 1.0
         S = max(_S(t) for t in ops_in)
         pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
         outs = [SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *[pick(t, s) for t in ops_in]) for s in range(S)]

@@ -277,25 +277,27 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
 
 
 def svgp_logpdf_mat(Kuu, Kuf, Kdiag, Y, noise_var, qU_mean, qU_cov_W, qU_cov_diag, jitter=0.0, scaling=1.0, gscale=1.0, want_grad=False):
-    """SVGP bound from materialised Grams, one sample: Kuu (M,M) without jitter, Kuf (M,B), Kdiag (B,), Y (B,P), noise_var
-    (1,) | (P,) | (B,1) | (B,P).  Returns dict(logL (1,), info, and -- if want_grad -- dKuu, dKuf, dKdiag, dY, dnoise, dmu, dW, dSdiag)."""
+    """SVGP bound from materialised Grams: Kuu (M,M) without jitter, Kuf (M,B), Kdiag (B,), Y (B,P) or (S,B,P) [S samples of the outputs over
+    the same inputs], noise_var (1,) | (P,) | (B,1) | (B,P).  Returns dict(logL (S,), info, and -- if want_grad -- dKuu, dKuf, dKdiag, dY,
+    dnoise, dmu, dW, dSdiag of gscale * sum_s logL[s])."""
     Kuu, Kuf, Kdiag, Y, noise_var, qU_mean, qU_cov_W, qU_cov_diag = [_c(t) for t in (Kuu, Kuf, Kdiag, Y, noise_var, qU_mean, qU_cov_W, qU_cov_diag)]
     M, B, P = Kuf.shape[-2], Kuf.shape[-1], Y.shape[-1]
+    S = Y.shape[0] if Y.dim() == 3 else 1
     dev, dt = Kuf.device, Kuf.dtype
     if noise_var.dim() == 1:
         noise_var = noise_var.reshape(1, -1)
     nrows, ncols = noise_var.shape
     if nrows not in (1, B) or ncols not in (1, P):
         raise ValueError('svgp_logpdf_mat: noise_var must be (1|B, 1|P), got %s' % (tuple(noise_var.shape),))
-    out = {'logL': torch.empty(1, dtype=dt, device=dev), 'info': torch.zeros(1, dtype=torch.int32, device=dev)}
+    out = {'logL': torch.empty(S, dtype=dt, device=dev), 'info': torch.zeros(1, dtype=torch.int32, device=dev)}
     g = {}
     if want_grad:
         E = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
-        g = {'dKuu': E(M, M), 'dKuf': E(M, B), 'dKdiag': E(B), 'dY': E(B, P), 'dnoise': E(nrows, ncols), 'dmu': E(M, P), 'dW': E(M, M),
+        g = {'dKuu': E(M, M), 'dKuf': E(M, B), 'dKdiag': E(B), 'dY': E(*Y.shape), 'dnoise': E(nrows, ncols), 'dmu': E(M, P), 'dW': E(M, M),
              'dSdiag': E(M)}
-    _lib.call('mxf_svgp_logpdf_mat', _h(Kuf), _dt(Kuf), B, M, P, _p(Kuu), _p(Kuf), _p(Kdiag), _p(Y), _p(noise_var), nrows, ncols,
-              _p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), float(jitter), float(scaling), float(gscale), _p(out['logL']), _p(out['info']),
-              int(want_grad), _p(g.get('dKuu')), _p(g.get('dKuf')), _p(g.get('dKdiag')), _p(g.get('dY')), _p(g.get('dnoise')),
+    _lib.call('mxf_svgp_logpdf_mat', _h(Kuf), _dt(Kuf), S, B, M, P, _p(Kuu), _p(Kuf), _p(Kdiag), _p(Y), B * P if S > 1 else 0, _p(noise_var),
+              nrows, ncols, _p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), float(jitter), float(scaling), float(gscale), _p(out['logL']),
+              _p(out['info']), int(want_grad), _p(g.get('dKuu')), _p(g.get('dKuf')), _p(g.get('dKdiag')), _p(g.get('dY')), _p(g.get('dnoise')),
               _p(g.get('dmu')), _p(g.get('dW')), _p(g.get('dSdiag')), _stream())
     out.update(g)
     return out

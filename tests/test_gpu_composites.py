@@ -263,3 +263,45 @@ def test_svgp_logpdf_input_and_output_widths(dtype, tol, Q, P):
     gtol = tol * 1000 if dtype == torch.float64 else 5e-3
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('B,M,Q,P,S', [(300, 20, 3, 2, 4), (1000, 130, 8, 1, 3)])
+def test_svgp_logpdf_sampled_outputs_over_shared_inputs(dtype, tol, B, M, Q, P, S):
+    """Y sampled (S,B,P), X shared (1,B,Q) -- the first layer of a deep GP (its output H is a sample of q(H), its input is data): the S
+    samples share Kuf, T and U, one call instead of a per-sample loop; through the stationary-kernel entry point and through
+    mxf_svgp_logpdf_mat."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(B + S)
+    X = rng.uniform(-2, 2, (1, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P))[None] + 0.3 * rng.randn(S, B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm, qW, qd = rng.randn(M, P) * 0.3, rng.randn(M, M) * 0.1, rng.rand(M) + 0.5
+    ls = rng.rand(Q) * 0.5 + (1.0 if dtype == torch.float64 else 0.25)
+    var, noise = np.array([1.3]), np.array([0.05])
+    k = O.RBF(Q, ARD=True)
+    names = ('X', 'Y', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    vals = dict(X=X, Y=Y, Z=Z, noise=noise, qm=qm, qW=qW, qd=qd, ls=ls, var=var)
+    lv = {n: O.T(vals[n]).clone().requires_grad_(True) for n in names}
+    kp = {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}
+    logL = O.svgp_log_pdf(k, lv['X'], lv['Y'], lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None], kp,
+                          jitter=1e-6, log_pdf_scaling=2.0)
+    assert logL.shape == (S,)
+    grads = torch.autograd.grad(logL.mean(), [lv[n] for n in names])
+    r = ops.svgp_logpdf('rbf', _dev(X, dtype), _dev(Y, dtype), _dev(Z, dtype), _dev(noise, dtype), _dev(qm, dtype), _dev(qW, dtype),
+                        _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=2.0, gscale=1.0 / S, want_grad=True)
+    assert int(r['info'].abs().sum()) == 0
+    _close(r['logL'], logL, tol, 'logL')
+    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
+    # the same through the materialised-Gram entry point
+    with torch.no_grad():
+        Kuu = k.K(O.T(Z)[None], **{a: b.detach() for a, b in kp.items()})[0]
+        Kuf = k.K(O.T(Z)[None], O.T(X), **{a: b.detach() for a, b in kp.items()})[0]
+        Kd = k.Kdiag(O.T(X), **{a: b.detach() for a, b in kp.items()})[0]
+    rm = ops.svgp_logpdf_mat(_dev(Kuu.numpy(), dtype), _dev(Kuf.numpy(), dtype), _dev(Kd.numpy(), dtype), _dev(Y, dtype), _dev(noise, dtype),
+                             _dev(qm, dtype), _dev(qW, dtype), _dev(qd, dtype), jitter=1e-6, scaling=2.0, gscale=1.0 / S, want_grad=True)
+    _close(rm['logL'], logL, tol, 'logL (mat)')
+    for key in ('dY', 'dnoise', 'dmu', 'dW', 'dSdiag'):
+        _close(rm[key].reshape(r[key].shape), r[key].double().cpu(), gtol, key + ' (mat)')
