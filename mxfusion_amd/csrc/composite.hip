@@ -146,9 +146,21 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
     if (rc) return rc;
     rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st);                        // :61
     if (rc) return rc;
-    hipLaunchKernelGGL((bcast_copy_kernel<T>), dim3(gridn(S * NP)), dim3(256), 0, st, S, NP, Y, sY, LinvY, (T)1);
-    rc = mxf_trsm_internal(h, dtype, 0, S, N, P, L, N, NN, LinvY, P, NP, 0, st);        // :66
-    if (rc) return rc;
+    // L^-1 Y (:66).  Large N with gradients: the reverse mode needs L^-1 anyway, and L^-1 Y as ONE product replaces N / 64 dependent
+    // block steps (6.9 ms at N = 8192); small N keeps the reference's trsm.
+    T* Linv = nullptr;
+    const bool via_inverse = want_grad && N >= 2048;
+    if (via_inverse) {
+        Linv = cv.take<T>((size_t)S * NN);
+        rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
+        if (rc) return rc;
+        rc = mxf_gemm_internal(h, dtype, 0, 0, N, P, N, 1.0, Linv, N, NN, Y, P, sY, 0.0, LinvY, P, NP, S, 0, st);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL((bcast_copy_kernel<T>), dim3(gridn(S * NP)), dim3(256), 0, st, S, NP, Y, sY, LinvY, (T)1);
+        rc = mxf_trsm_internal(h, dtype, 0, S, N, P, L, N, NN, LinvY, P, NP, 0, st);
+        if (rc) return rc;
+    }
     rc = mxf_sumlogdiag_internal(h, dtype, S, N, L, N, NN, sld, st);                    // :67
     if (rc) return rc;
     hipLaunchKernelGGL((sumsq_kernel<T>), dim3(S), dim3(256), 0, st, NP, LinvY, NP, ss);
@@ -157,16 +169,18 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
     if (!want_grad) return 0;
 
     // reverse mode: dlogL/dK = 1/2 (alpha alpha^T - P K^-1), alpha = K^-1 Y; dlogL/dY = -alpha
-    T* Linv = cv.take<T>((size_t)S * NN);
+    if (!via_inverse) {
+        Linv = cv.take<T>((size_t)S * NN);
+        rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
+        if (rc) return rc;
+    }
     T* dK = cv.take<T>((size_t)S * NN);
     T* alpha = cv.take<T>((size_t)S * NP);
-    rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
-    if (rc) return rc;
     rc = mxf_gemm_internal(h, dtype, 1, 0, N, P, N, 1.0, Linv, N, NN, LinvY, P, NP, 0.0, alpha, P, NP, S, 0, st);   // alpha = Linv^T LinvY
     if (rc) return rc;
     rc = mxf_gemm_internal(h, dtype, 0, 1, N, N, P, 0.5, alpha, P, NP, alpha, P, NP, 0.0, dK, N, NN, S, 1, st);     // 1/2 alpha alpha^T (lower)
     if (rc) return rc;
-    rc = mxf_gemm_internal(h, dtype, 1, 0, N, N, N, -0.5 * P, Linv, N, NN, Linv, N, NN, 1.0, dK, N, NN, S, 1, st);  // - P/2 Linv^T Linv (lower)
+    rc = mxf_gemm_internal(h, dtype, 1, 0, N, N, N, -0.5 * P, Linv, N, NN, Linv, N, NN, 1.0, dK, N, NN, S, 1, st, 0, 1);  // - P/2 Linv^T Linv (lower; L^-1 lower triangular: tile (i, j <= i) needs k >= i only)
     if (rc) return rc;
     hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32), S), dim3(256), 0, st, dK, N, N, NN);
     if (dY) hipLaunchKernelGGL((bcast_copy_kernel<T>), dim3(gridn(S * NP)), dim3(256), 0, st, S, NP, (const T*)alpha, NP, dY, (T)-1);

@@ -45,6 +45,7 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
     T alpha, beta;
     int splitk, lower_only, atomic, vecA, vecB;
+    int k_from_m;     // TN product of LOWER-TRIANGULAR operands (L^T L): output tile (m0, n0 <= m0) only needs k >= m0
     int64_t kchunk;
     int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
 };
@@ -253,8 +254,9 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
     const T* __restrict__ B = g.B + (int64_t)batch * g.sB;
     T* __restrict__ C = g.C + (int64_t)batch * g.sC;
 
-    const int64_t kbeg = (int64_t)split * g.kchunk;
+    int64_t kbeg = (int64_t)split * g.kchunk;
     const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m) { const int64_t kf = m0 / BK * BK; if (kf > kbeg) kbeg = kf; }
 
     Acc<T> acc;
     acc.zero();
@@ -313,8 +315,9 @@ __global__ void scale_kernel(T* C, int64_t M, int64_t N, int64_t ldc, int64_t sC
 template <typename T>
 int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
                int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta, void* C, int64_t ldc, int64_t sC,
-               int batch, int lower_only, hipStream_t st, int reserve_cus) {
+               int batch, int lower_only, hipStream_t st, int reserve_cus, int k_from_m) {
     GemmArgs<T> g;
+    g.k_from_m = (k_from_m && lower_only && ta && !tb) ? 1 : 0;
     g.A = (const T*)A; g.B = (const T*)B; g.C = (T*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.alpha = (T)alpha; g.beta = (T)beta; g.lower_only = lower_only;
@@ -333,7 +336,7 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     // reserve_cus: leave that many CUs without a workgroup of this (register-saturating) kernel, so that latency-bound
     // kernels of a concurrent stream can still be scheduled (the split-K grid is sized to the remaining CUs)
     const int64_t slots = (256 - reserve_cus) * (sizeof(T) == 4 ? 2 : 1);
-    if (tiles < slots && K >= 256) {
+    if (tiles < slots && K >= 256 && !g.k_from_m) {
         const int64_t maxsplit = K / 128 > 0 ? K / 128 : 1;     // small latency-bound GEMMs of the (M x M) core split too
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;   // one round would leave >25% of the slots idle: use two
@@ -377,10 +380,10 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
 
 int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
-                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus) {
+                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus, int k_from_m) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    if (dtype == MXF_F32) return gemm_typed<float>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus);
-    if (dtype == MXF_F64) return gemm_typed<double>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus);
+    if (dtype == MXF_F32) return gemm_typed<float>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus, k_from_m);
+    if (dtype == MXF_F64) return gemm_typed<double>(h, ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch, lower_only, st, reserve_cus, k_from_m);
     MXF_FAIL(h, -2, "mxf_gemm: bad dtype %d", dtype);
 }
 

@@ -5,7 +5,7 @@
 // C = alpha op(A) op(B) + beta C; lower_only: skip blocks / entries strictly above the diagonal (syrk-style update)
 int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
-                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus = 0);
+                      void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus = 0, int k_from_m = 0);
 
 int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st);
 // rhs_lower: B is block-lower-triangular (trtri); only columns < (k+1)*64 of block row k are touched
