@@ -312,6 +312,129 @@ __global__ void scale_kernel(T* C, int64_t M, int64_t N, int64_t ldc, int64_t sC
     }
 }
 
+// ---- small-tile float64 variant for the latency-bound (M x M) core --------------------------------------------------------------------
+// 64 x 64 block tile, BK = 16, 4 waves of 32 x 32 (2 x 2 v_mfma_f64_16x16x4_f64), 34 KB of LDS and < 64 VGPRs: four of these fit a CU NEXT
+// TO the big streaming kernels (the 128 x 128 kernel needs a whole CU's LDS and registers, so its workgroups used to wait for a CU to
+// drain), 4x more tiles for a 1024^2 output, and the 64-wide panel updates of potrf waste no half tile.  Guarded scalar loaders only.
+constexpr int SBM_ = 64, SBK_ = 16, SLD_ = 66;
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_small_f64_kernel(GemmArgs<double> g) {
+    __shared__ double sm[2][2][SBK_ * SLD_];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int64_t wid = blockIdx.x;
+    const int64_t zs = wid / g.ntiles;
+    const int64_t t = wid % g.ntiles;
+    int64_t tile_m, tile_n;
+    if (g.lower_only) {
+        int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        tile_m = row; tile_n = t - row * (row + 1) / 2;
+    } else { tile_m = t % g.tm; tile_n = t / g.tm; }
+    const int64_t m0 = tile_m * SBM_, n0 = tile_n * SBM_;
+    const int batch = (int)(zs / g.splitk), split = (int)(zs % g.splitk);
+    const double* __restrict__ A = g.A + (int64_t)batch * g.sA;
+    const double* __restrict__ B = g.B + (int64_t)batch * g.sB;
+    double* __restrict__ C = g.C + (int64_t)batch * g.sC;
+    int64_t kbeg = (int64_t)split * g.kchunk;
+    const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m) { const int64_t kf = m0 / SBK_ * SBK_; if (kf > kbeg) kbeg = kf; }
+    f64x4 c[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[x][y][r] = 0.0;
+    // loaders: 64 x 16 elements per operand per k tile = 4 per thread; element (mn = tid & 63, k = (tid >> 6) + 4 j)
+    const int lmn = tid & 63, lk0 = tid >> 6;
+    double ra[4], rb[4];
+    auto load = [&](int64_t k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t kk = k0 + lk0 + 4 * j, ia = m0 + lmn, ib = n0 + lmn;
+            ra[j] = (ia < g.M && kk < kend) ? (TA ? A[kk * g.lda + ia] : A[ia * g.lda + kk]) : 0.0;
+            rb[j] = (ib < g.N && kk < kend) ? (TB ? B[ib * g.ldb + kk] : B[kk * g.ldb + ib]) : 0.0;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sm[buf][0][(lk0 + 4 * j) * SLD_ + lmn] = ra[j]; sm[buf][1][(lk0 + 4 * j) * SLD_ + lmn] = rb[j]; }
+    };
+    if (kbeg < kend) { load(kbeg); store(0); }
+    __syncthreads();
+    const int li = lane & 15, lkk = lane >> 4;
+    int cur = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += SBK_) {
+        const bool more = k0 + SBK_ < kend;
+        if (more) load(k0 + SBK_);
+        const double* As = sm[cur][0];
+        const double* Bs = sm[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < SBK_; ks += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { a[x] = As[(ks + lkk) * SLD_ + wm + 16 * x + li]; b[x] = Bs[(ks + lkk) * SLD_ + wn + 16 * x + li]; }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], c[x][y], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const double alpha = g.alpha, beta = g.beta;
+    const bool atomic = g.atomic != 0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm + x * 16 + (lane >> 4) + 4 * r, col = n0 + wn + y * 16 + (lane & 15);
+                if (row < g.M && col < g.N && !(g.lower_only && col > row)) {
+                    double* p = C + row * g.ldc + col;
+                    if (atomic) atomic_add(p, alpha * c[x][y][r]);
+                    else *p = (beta == 0.0) ? alpha * c[x][y][r] : alpha * c[x][y][r] + beta * (*p);
+                }
+            }
+}
+
+// launch of the small-tile variant; returns false when the problem should take the 128 x 128 kernel instead
+template <typename T>
+bool gemm_small_launch(mxf_ctx*, GemmArgs<T>&, int, int, int64_t, int64_t, int64_t, double, int, int, hipStream_t, int&) { return false; }
+template <>
+bool gemm_small_launch<double>(mxf_ctx* h, GemmArgs<double>& g, int ta, int tb, int64_t M, int64_t N, int64_t K, double beta, int batch, int lower_only,
+                               hipStream_t st, int& rc) {
+    static const int small_env = getenv("MXF_GEMM_SMALL") ? atoi(getenv("MXF_GEMM_SMALL")) : 1;
+    const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (!small_env || t128 > 64 || M > 65535) return false;       // the big kernel fills at least a quarter of the chip: keep it
+    const int64_t tm = (M + SBM_ - 1) / SBM_, tn = (N + SBM_ - 1) / SBM_;
+    if (lower_only && tm != tn) return false;
+    const int64_t tiles = (lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    int64_t splitk = 1;
+    const int64_t slots = 1024;                                      // 4 workgroups per CU
+    if (tiles < slots && K >= 128 && !g.k_from_m) { splitk = slots / tiles; const int64_t mx = K / 64 > 0 ? K / 64 : 1; if (splitk > mx) splitk = mx; if (splitk < 1) splitk = 1; }
+    int64_t kchunk = SBK_;
+    if (K > 0) { kchunk = (K + splitk - 1) / splitk; kchunk = (kchunk + SBK_ - 1) / SBK_ * SBK_; splitk = (K + kchunk - 1) / kchunk; } else splitk = 1;
+    g.splitk = (int)splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
+    g.tm = tm; g.tn = tn; g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn; g.nwg = g.ntiles * batch * splitk;
+    rc = 0;
+    if (g.atomic && beta != 1.0) {
+        dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
+        hipLaunchKernelGGL((scale_kernel<double>), gs, dim3(256), 0, st, g.C, M, N, g.ldc, g.sC, beta, lower_only);
+    }
+    dim3 grid((unsigned)g.nwg, 1, 1);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_small_f64_kernel<false, false>), grid, dim3(256), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_small_f64_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_small_f64_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_small_f64_kernel<true, true>), grid, dim3(256), 0, st, g);
+    if (hipGetLastError() != hipSuccess) rc = -5;
+    return true;
+}
+
 template <typename T>
 int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
                int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta, void* C, int64_t ldc, int64_t sC,
@@ -325,6 +448,13 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         constexpr int VEC = Vec16<T>::n;
         auto ok = [&](const void* p, int64_t ld, int64_t st) { return ((uintptr_t)p % 16 == 0) && (ld % VEC == 0) && (st % VEC == 0); };
         g.vecA = ok(A, lda, sA); g.vecB = ok(B, ldb, sB);
+    }
+    {   // latency-bound float64 products of the (M x M) core: small-tile variant
+        int rc_small = 0;
+        if (gemm_small_launch<T>(h, g, ta, tb, M, N, K, beta, batch, lower_only, st, rc_small)) {
+            if (rc_small) MXF_FAIL(h, -5, "mxf_gemm: small-tile launch failed");
+            return 0;
+        }
     }
     const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
     // split K when the output grid cannot fill 256 CUs and K is long
