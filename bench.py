@@ -338,6 +338,7 @@ def main():
     ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
+    ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
     args = ap.parse_args()
@@ -345,7 +346,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist      # --force-dist: run the RCCL code path (init, broadcast, all-reduce, barriers) even with one rank
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
