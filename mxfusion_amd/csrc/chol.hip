@@ -115,20 +115,56 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
         t[r][c] = (rb + r < r0 + nrows && c < nb) ? Ab[(rb + r) * lda + k0 + c] : (T)0;
     }
     __syncthreads();
-    T x[NB];
+    // Blocked substitution: 16 columns at a time by plain substitution (one row per lane, x[16] in registers), then the remaining columns of
+    // the tile are updated with MFMA:  T[:, J] -= X[:, blk] L11[J, blk]^T.  The un-blocked form (one row per lane, 64 dependent steps,
+    // 2016 broadcast LDS reads with x[64] pinning 128 VGPRs) kept only two LDS reads in flight and took ~40 us of the 84 us kernel.
+    {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+        for (int blk = 0; blk < NB; blk += 16) {
+            T x[16];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        T s0 = t[tid][j], s1 = (T)0;              // two accumulators: halves the dependent-FMA chain
+            for (int c = 0; c < 16; ++c) {
+                T s0 = t[tid][blk + c], s1 = (T)0;          // two accumulators: halves the dependent-FMA chain
 #pragma unroll
-        for (int k = 0; k + 1 < j; k += 2) { s0 = fma(-x[k], a[j][k], s0); s1 = fma(-x[k + 1], a[j][k + 1], s1); }
-        if (j & 1) s0 = fma(-x[j - 1], a[j][j - 1], s0);
-        x[j] = (s0 + s1) * invd[j];
-        __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k + 1 < c; k += 2) { s0 = fma(-x[k], a[blk + c][blk + k], s0); s1 = fma(-x[k + 1], a[blk + c][blk + k + 1], s1); }
+                if (c & 1) s0 = fma(-x[c - 1], a[blk + c][blk + c - 1], s0);
+                x[c] = (s0 + s1) * invd[blk + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[tid][blk + c] = x[c];
+            __syncthreads();
+            if (blk + 16 < NB) {
+                for (int rt = wave * 4; rt < wave * 4 + 4; ++rt) {          // 8 row tiles of 16 rows, 4 per wave
+                    const int rr = rt * 16;
+                    T af[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) af[q] = -t[rr + li][blk + 4 * q + lq];
+                    for (int J0 = blk + 16; J0 < NB; J0 += 16) {
+                        if constexpr (sizeof(T) == 8) {
+                            typedef double f64x4_ __attribute__((ext_vector_type(4)));
+                            f64x4_ cf;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cf[r] = t[rr + lq + 4 * r][J0 + li];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], a[J0 + li][blk + 4 * q + lq], cf, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) t[rr + lq + 4 * r][J0 + li] = cf[r];
+                        } else {
+                            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                            f32x4_ cf;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cf[r] = t[rr + lq * 4 + r][J0 + li];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], a[J0 + li][blk + 4 * q + lq], cf, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) t[rr + lq * 4 + r][J0 + li] = cf[r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; ++j) t[tid][j] = x[j];
-    __syncthreads();
     for (int e = tid; e < 128 * NB; e += 128) {
         const int r = e / NB, c = e % NB;
         if (rb + r < r0 + nrows && c < nb) Ab[(rb + r) * lda + k0 + c] = t[r][c];
