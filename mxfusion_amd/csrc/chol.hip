@@ -25,6 +25,14 @@ __device__ __forceinline__ double inv_sqrt(double d) {
 }
 constexpr int NBO = 512;   // outer panel
 
+__device__ __forceinline__ float readlane_t(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double readlane_t(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // ---- fused panel step: every workgroup re-factors the 64x64 diagonal block in LDS (rank-4 blocked: 16 barrier pairs instead of
 // 64) and then solves its own 128 rows against it; workgroup 0 owns the diagonal block itself.  One launch per 64-wide block column
 // instead of two (diag + solve), and no dependent launch gap between them.
@@ -32,7 +40,6 @@ template <typename T>
 __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int64_t lda, int64_t sA, int64_t k0, int nb, int64_t n,
                                                            int* __restrict__ info, int* __restrict__ arrived) {
     __shared__ T a[NB][NB + 1];
-    __shared__ T lc[4][NB];
     __shared__ T invd[NB];
     __shared__ T t[128][NB + 1];
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -50,49 +57,83 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     // in place: it may do so only after all the others have taken their copy (they can start arbitrarily late when other kernels hold
     // the CUs).  Arrival counter: one per batch item, zero on entry, reset to zero by workgroup 0.
     if (blockIdx.x != 0 && tid == 0) { __threadfence(); atomicAdd(arrived + b, 1); }
-    for (int jb = 0; jb < NB; jb += 4) {
-        if (tid < NB && tid >= jb) {
-            // 4x4 Cholesky of the current diagonal sub-block, redundantly in every participating thread
-            T L00, L10, L11, L20, L21, L22, L30, L31, L32, L33;
-            int bad = -1;
-            T d = a[jb][jb];                                          if (!(d > (T)0)) { if (bad < 0) bad = 0; d = (T)1; }
-            const T i0 = inv_sqrt(d); L00 = d * i0;
-            L10 = a[jb + 1][jb] * i0; L20 = a[jb + 2][jb] * i0; L30 = a[jb + 3][jb] * i0;
-            d = a[jb + 1][jb + 1] - L10 * L10;                        if (!(d > (T)0)) { if (bad < 0) bad = 1; d = (T)1; }
-            const T i1 = inv_sqrt(d); L11 = d * i1;
-            L21 = (a[jb + 2][jb + 1] - L20 * L10) * i1; L31 = (a[jb + 3][jb + 1] - L30 * L10) * i1;
-            d = a[jb + 2][jb + 2] - L20 * L20 - L21 * L21;            if (!(d > (T)0)) { if (bad < 0) bad = 2; d = (T)1; }
-            const T i2 = inv_sqrt(d); L22 = d * i2;
-            L32 = (a[jb + 3][jb + 2] - L30 * L20 - L31 * L21) * i2;
-            d = a[jb + 3][jb + 3] - L30 * L30 - L31 * L31 - L32 * L32; if (!(d > (T)0)) { if (bad < 0) bad = 3; d = (T)1; }
-            const T i3 = inv_sqrt(d); L33 = d * i3;
-            if (tid == jb) { invd[jb] = i0; invd[jb + 1] = i1; invd[jb + 2] = i2; invd[jb + 3] = i3; }
-            if (bad >= 0 && tid == jb && blockIdx.x == 0 && jb + bad < nb && info && info[b] == 0) info[b] = (int)(k0 + jb + bad + 1);
-            const int r = tid - jb;                                   // position relative to the sub-block
-            T l0, l1, l2, l3;
-            if (r == 0) { l0 = L00; l1 = 0; l2 = 0; l3 = 0; }
-            else if (r == 1) { l0 = L10; l1 = L11; l2 = 0; l3 = 0; }
-            else if (r == 2) { l0 = L20; l1 = L21; l2 = L22; l3 = 0; }
-            else if (r == 3) { l0 = L30; l1 = L31; l2 = L32; l3 = L33; }
-            else {
-                l0 = a[tid][jb] * i0;
-                l1 = (a[tid][jb + 1] - l0 * L10) * i1;
-                l2 = (a[tid][jb + 2] - l0 * L20 - l1 * L21) * i2;
-                l3 = (a[tid][jb + 3] - l0 * L30 - l1 * L31 - l2 * L32) * i3;
+    // 64 x 64 diagonal block, 16 columns at a time: (1) the 16 x 16 sub-block by ONE wave with a row per lane in registers (pivots and
+    // columns travel by v_readlane: no LDS round trip, no barrier), (2) the rows below it by substitution (one row per thread, x[16]),
+    // (3) the trailing lower triangle by MFMA:  A22 -= X X^T.  (The rank-4 LDS version it replaces spent ~40 us in 32 barriers and
+    // dependent LDS round trips.)
+    {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+        for (int blk = 0; blk < NB; blk += 16) {
+            if (wave == 0) {                                   // (1)
+                T r[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) r[c] = a[blk + li][blk + c];       // lanes 16..63 mirror lanes 0..15 (harmless)
+                int bad = -1;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    T d = readlane_t(r[j], j);
+                    if (!(d > (T)0)) { if (bad < 0) bad = j; d = (T)1; }        // not positive definite (or NaN): record, keep going finite
+                    const T inv = inv_sqrt(d);
+                    const T l = (li == j) ? d * inv : r[j] * inv;
+                    r[j] = l;
+                    if (lane == 0) invd[blk + j] = inv;
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) r[c] = fma(-l, readlane_t(l, c), r[c]);
+                }
+                if (bad >= 0 && lane == 0 && blockIdx.x == 0 && blk + bad < nb && info && info[b] == 0) info[b] = (int)(k0 + blk + bad + 1);
+                if (lane < 16) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) a[blk + lane][blk + c] = (c <= lane) ? r[c] : (T)0;
+                }
             }
-            lc[0][tid] = l0; lc[1][tid] = l1; lc[2][tid] = l2; lc[3][tid] = l3;
-        }
-        __syncthreads();
-        if (tid < NB && tid >= jb) { a[tid][jb] = lc[0][tid]; a[tid][jb + 1] = lc[1][tid]; a[tid][jb + 2] = lc[2][tid]; a[tid][jb + 3] = lc[3][tid]; }
-        {   // rank-4 trailing update of the lower triangle
-            const int c = jb + 4 + (tid & 63);
-            if (c < NB) {
-                const T c0 = lc[0][c], c1 = lc[1][c], c2 = lc[2][c], c3 = lc[3][c];
-                for (int i = c + (tid >> 6); i < NB; i += 2)
-                    a[i][c] -= lc[0][i] * c0 + lc[1][i] * c1 + lc[2][i] * c2 + lc[3][i] * c3;
+            __syncthreads();
+            if (blk + 16 < NB) {
+                const int i = blk + 16 + tid;                   // (2) rows below the sub-block: X L_bb^T = A_ib
+                if (i < NB) {
+                    T x[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        T s0 = a[i][blk + c], s1 = (T)0;
+#pragma unroll
+                        for (int k = 0; k + 1 < c; k += 2) { s0 = fma(-x[k], a[blk + c][blk + k], s0); s1 = fma(-x[k + 1], a[blk + c][blk + k + 1], s1); }
+                        if (c & 1) s0 = fma(-x[c - 1], a[blk + c][blk + c - 1], s0);
+                        x[c] = (s0 + s1) * invd[blk + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) a[i][blk + c] = x[c];
+                }
+                __syncthreads();
+                // (3) trailing update, lower tiles (I0 >= J0) of 16 x 16, dealt to the two waves
+                int tix = 0;
+                for (int I0 = blk + 16; I0 < NB; I0 += 16)
+                    for (int J0 = blk + 16; J0 <= I0; J0 += 16, ++tix) {
+                        if ((tix & 1) != wave) continue;
+                        T af[4], bf[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { af[q] = -a[I0 + li][blk + 4 * q + lq]; bf[q] = a[J0 + li][blk + 4 * q + lq]; }
+                        if constexpr (sizeof(T) == 8) {
+                            typedef double f64x4_ __attribute__((ext_vector_type(4)));
+                            f64x4_ cf;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cf[r] = a[I0 + lq + 4 * r][J0 + li];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[q], cf, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a[I0 + lq + 4 * r][J0 + li] = cf[r];
+                        } else {
+                            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                            f32x4_ cf;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) cf[r] = a[I0 + lq * 4 + r][J0 + li];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], cf, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a[I0 + lq * 4 + r][J0 + li] = cf[r];
+                        }
+                    }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
     if (blockIdx.x == 0) {
         if (tid == 0) {
