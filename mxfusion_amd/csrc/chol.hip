@@ -264,12 +264,39 @@ __global__ __launch_bounds__(256) void solve_cols_kernel(const T* __restrict__ L
     }
 }
 
-// ---- inverse of every 64x64 diagonal block of L in ONE launch (one workgroup per block, one column of the inverse per lane) ----
+// ---- inverse of every 64x64 diagonal block of L in ONE launch (one wave per block) -----------------------------------------------------
+// Blocked: the four 16 x 16 diagonal sub-blocks by substitution (16 lanes per sub-block, one column of the inverse per lane, the column in
+// registers), then two merge levels  inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]  as 16 x 16 MFMA products on the LDS image.
+// (The un-blocked form -- one column per lane, 64 dependent steps through LDS -- took ~120 us.)
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+    typedef double vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(double a, double b, vec c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lq, int r) { return lq + 4 * r; }       // C/D: row = (lane >> 4) + 4 r
+};
+template <> struct Mfma16<float> {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(float a, float b, vec c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lq, int r) { return lq * 4 + r; }       // C/D: row = (lane >> 4) * 4 + r
+};
+// D (16 x 16 at Dst[d0r.., d0c..]) = sgn * A (16 x K16) * B (K16 x 16), A at As[a0r.., a0c..], B at Bs[b0r.., b0c..]; K16 = 16 * kt
+template <typename T>
+__device__ __forceinline__ void lds_mm16(T (*Dst)[NB + 1], int d0r, int d0c, T (*As)[NB + 1], int a0r, int a0c, T (*Bs)[NB + 1], int b0r, int b0c,
+                                         int kt, T sgn, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    typename Mfma16<T>::vec c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = (T)0;
+    for (int k = 0; k < 16 * kt; k += 4) c = Mfma16<T>::mma(sgn * As[a0r + li][a0c + k + lq], Bs[b0r + k + lq][b0c + li], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dst[d0r + Mfma16<T>::row(lq, r)][d0c + li] = c[r];
+}
 template <typename T>
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L, int64_t ldl, int64_t sL, T* __restrict__ Li, int64_t ldi,
                                                         int64_t sI, int64_t n) {
     __shared__ T l[NB][NB + 1];
     __shared__ T x[NB][NB + 1];
+    __shared__ T w[NB][NB + 1];              // products L21 I11 of the merge levels
     const int tid = threadIdx.x, b = blockIdx.y;
     const int64_t k0 = (int64_t)blockIdx.x * NB;
     const int nb = (int)((k0 + NB < n) ? NB : n - k0);
@@ -279,16 +306,42 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L,
         const int i = e / NB, m = e % NB;
         T v = (T)0;
         if (i < nb && m < nb) { if (m <= i) v = Lkk[(int64_t)i * ldl + m]; }
-        else if (i == m) v = (T)1;
+        else if (i == m) v = (T)1;          // identity padding of a ragged last block
         l[i][m] = v;
+        x[i][m] = (T)0;
     }
     __syncthreads();
-    const int c = tid;                       // column c of the inverse: x_i = (delta_ic - sum_{m=c}^{i-1} l_im x_m) / l_ii, i >= c
-    for (int i = 0; i < NB; ++i) {
-        T sacc = (i == c) ? (T)1 : (T)0;
-        if (i > c) for (int m = c; m < i; ++m) sacc = fma(-l[i][m], x[m][c], sacc);
-        x[i][c] = (i >= c) ? sacc / l[i][i] : (T)0;
+    {   // 16 x 16 diagonal sub-blocks: lane group g = tid / 16 owns sub-block g, lane c = tid % 16 column c of its inverse
+        const int g0 = (tid >> 4) * 16, c = tid & 15;
+        T xc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            T sacc = (i == c) ? (T)1 : (T)0;
+#pragma unroll
+            for (int m = 0; m < i; ++m) sacc = fma(-l[g0 + i][g0 + m], (m >= c) ? xc[m] : (T)0, sacc);
+            xc[i] = (i >= c) ? sacc / l[g0 + i][g0 + i] : (T)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[g0 + i][g0 + c] = xc[i];
     }
+    __syncthreads();
+    // merge 16 -> 32: pairs (0,1) and (2,3):  X21 = -I22 (L21 I11)
+    for (int p = 0; p < 2; ++p) {
+        const int o = 32 * p;
+        lds_mm16<T>(w, o + 16, o, l, o + 16, o, x, o, o, 1, (T)1, tid);                 // W = L21 I11
+    }
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) {
+        const int o = 32 * p;
+        lds_mm16<T>(x, o + 16, o, x, o + 16, o + 16, w, o + 16, o, 1, (T)-1, tid);      // X21 = -I22 W
+    }
+    __syncthreads();
+    // merge 32 -> 64: L21 = l[32:64][0:32], I11 = x[0:32][0:32], I22 = x[32:64][32:64] (both lower triangular, explicit zeros above)
+    for (int ti = 0; ti < 2; ++ti)
+        for (int tj = 0; tj < 2; ++tj) lds_mm16<T>(w, 32 + 16 * ti, 16 * tj, l, 32 + 16 * ti, 0, x, 0, 16 * tj, 2, (T)1, tid);
+    __syncthreads();
+    for (int ti = 0; ti < 2; ++ti)
+        for (int tj = 0; tj < 2; ++tj) lds_mm16<T>(x, 32 + 16 * ti, 16 * tj, x, 32 + 16 * ti, 32, w, 32, 16 * tj, 2, (T)-1, tid);
     __syncthreads();
     for (int e = tid; e < nb * nb; e += 64) {
         const int i = e / nb, m = e % nb;
