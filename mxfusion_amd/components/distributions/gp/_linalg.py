@@ -90,3 +90,74 @@ class MatmulFn(torch.autograd.Function):
 
 def matmul(A, B, transA=False, transB=False):
     return MatmulFn.apply(A, B, transA, transB)
+
+
+class TrsmFn(torch.autograd.Function):
+    """X = op(L)^-1 B through mxf_trsm (L lower triangular, shared over the sample axis when its leading extent is 1).
+    Reverse mode: dB = op(L)^-T G (a second mxf_trsm); dL = -tril(dB X^T) (op = identity) or -tril(X dB^T) (op = transpose)."""
+
+    @staticmethod
+    def forward(ctx, L, B, transpose):
+        ctx.transpose = bool(transpose)
+        X = ops.trsm_(L, B.contiguous().clone(), transpose=transpose)
+        ctx.save_for_backward(L, X)
+        return X
+
+    @staticmethod
+    def backward(ctx, G):
+        L, X = ctx.saved_tensors
+        dB = ops.trsm_(L, G.contiguous().clone(), transpose=not ctx.transpose)
+        dL = None
+        if ctx.needs_input_grad[0]:
+            dL = ops.gemm(X, dB, transB=True, alpha=-1.0) if ctx.transpose else ops.gemm(dB, X, transB=True, alpha=-1.0)
+            dL = torch.tril(dL)
+            if L.shape[0] == 1 and dL.shape[0] > 1:
+                dL = dL.sum(0, keepdim=True)
+        return dL, (dB if ctx.needs_input_grad[1] else None), None
+
+
+class ColdotFn(torch.autograd.Function):
+    """out[s, n] = sum_m A[s, m, n] B[s, m, n] through mxf_coldot; dA = B * g[:, None, :], dB = A * g[:, None, :]."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return ops.coldot(A, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g = g.unsqueeze(-2)
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            gA = B * g
+            if A.shape[0] == 1 and gA.shape[0] > 1:
+                gA = gA.sum(0, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            gB = A * g
+            if B.shape[0] == 1 and gB.shape[0] > 1:
+                gB = gB.sum(0, keepdim=True)
+        return gA, gB
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+def trsm(L, B, transpose=False):
+    """op(L)^-1 B; differentiable when an operand requires grad, the plain in-place-on-a-copy call otherwise."""
+    if _needs_grad(L, B):
+        return TrsmFn.apply(L, B, transpose)
+    return ops.trsm_(L, B.contiguous().clone(), transpose=transpose)
+
+
+def gemm(A, B, transA=False, transB=False):
+    if _needs_grad(A, B):
+        return MatmulFn.apply(A, B, transA, transB)
+    return ops.gemm(A, B, transA=transA, transB=transB)
+
+
+def coldot(A, B):
+    if _needs_grad(A, B):
+        return ColdotFn.apply(A, B)
+    return ops.coldot(A, B)

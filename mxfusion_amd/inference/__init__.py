@@ -1,5 +1,5 @@
 from .inference import Inference, TransferInference  # noqa: F401
-from .grad_based_inference import GradBasedInference  # noqa: F401
+from .grad_based_inference import GradBasedInference, GradTransferInference  # noqa: F401
 from .inference_alg import InferenceAlgorithm, SamplingAlgorithm  # noqa: F401
 from .variational import VariationalInference, StochasticVariationalInference  # noqa: F401
 from .map import MAP  # noqa: F401
@@ -8,3 +8,4 @@ from .batch_loop import BatchInferenceLoop, DistributedBatchInferenceLoop  # noq
 from .minibatch_loop import MinibatchInferenceLoop  # noqa: F401
 from .prediction import ModulePredictionAlgorithm  # noqa: F401
 from .forward_sampling import ForwardSamplingAlgorithm  # noqa: F401
+from .pilco_alg import PILCOAlgorithm  # noqa: F401

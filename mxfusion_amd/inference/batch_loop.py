@@ -23,7 +23,7 @@ class _Adam(object):
         self.t += 1
         flat = self.params.flat
         ops.adam_step_(flat.detach(), flat.grad, self.m, self.v, self.lr, self.t, rescale_grad=1.0 / batch_size)
-        flat.grad = None
+        self.params.zero_grad()
 
 
 class BatchInferenceLoop(GradLoop):
@@ -75,7 +75,7 @@ class BatchInferenceLoop(GradLoop):
                 self._exchange(param_dict)
                 return loss.detach()
             torch.cuda.synchronize()
-            param_dict.flat.grad = None
+            param_dict.zero_grad()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss, loss_for_gradient = infr_executor(*data)

@@ -33,3 +33,26 @@ class GradBasedInference(Inference):
                                        update_shape_constants=update_shape_constants)
         return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
                                    optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
+
+
+class GradTransferInference(GradBasedInference):
+    """grad_based_inference.py:106-140: gradient-based optimisation of EXTERNAL parameters (`train_params`, e.g. a policy network)
+    through an algorithm whose model parameters are inherited from a finished inference and held fixed.
+
+    The reference stores `train_params` but hands only its own (all-fixed) ParameterDict to the Trainer (grad_based_inference.py:130,
+    100-104), so there nothing is ever updated; here `train_params` are what the loop optimises, which is what the PILCO example needs."""
+
+    def __init__(self, inference_algorithm, infr_params, train_params, grad_loop=None, var_tie=None, constants=None, hybridize=False,
+                 dtype=None, context=None):
+        self._var_tie = var_tie if var_tie is not None else {}
+        self._inherited_params = infr_params
+        self.train_params = train_params
+        if dtype is None:
+            dtype = infr_params.dtype
+        super(GradTransferInference, self).__init__(inference_algorithm=inference_algorithm, grad_loop=grad_loop, constants=constants,
+                                                    hybridize=hybridize, dtype=dtype, context=context)
+
+    def _initialize_params(self):
+        self.params.initialize_params(self._graphs, self.observed_variable_UUIDs, carry=self._inherited_params.export_raw())
+        self.params.fix_all()
+        self.params.set_train_params(self.train_params)

@@ -27,6 +27,7 @@ class InferenceParameters(object):
         self._fixed = {}        # uuid -> tensor: non-trainable stores (posterior caches written through SET_)
         self._vars = {}         # uuid -> Variable
         self._views = None
+        self._train_flat = None  # GradTransferInference: the externally owned trainable tensors, re-homed into one flat buffer
 
     # ---- construction ---------------------------------------------------------------------------------
     @property
@@ -96,10 +97,41 @@ class InferenceParameters(object):
                 continue
         return self
 
+    def fix_all(self):
+        """inference_parameters.py:139-141 (grad_req = 'null' on every parameter): the inherited buffer stops being a trainable leaf."""
+        self._flat = self._flat.detach().requires_grad_(False)
+
+    def set_train_params(self, tensors):
+        """GradTransferInference's `train_params` (grad_based_inference.py:124-130): tensors owned by the caller (e.g. the parameters of
+        a torch.nn policy network).  They are re-homed as views of ONE flat buffer, their .grad as views of one flat gradient, so that
+        the optimiser stays one mxf_adam_step launch and the data-parallel exchange one all-reduce; `flat` then names that buffer."""
+        ts = list(tensors.values()) if isinstance(tensors, dict) else list(tensors)
+        total = sum(t.numel() for t in ts)
+        flat = torch.zeros(max(total, 1), dtype=self.dtype, device=self.device)
+        grad = torch.zeros_like(flat)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            flat[off:off + n] = t.detach().reshape(-1).to(device=self.device, dtype=self.dtype)
+            t.data = flat[off:off + n].view(t.shape)
+            t.grad = grad[off:off + n].view(t.shape)
+            t.requires_grad_(True)
+            off += n
+        self._train_flat = flat.requires_grad_(True)
+        self._train_flat.grad = grad
+        self._train_tensors = ts
+
+    def zero_grad(self):
+        if self._train_flat is not None:
+            self._train_flat.grad.zero_()
+        else:
+            self._flat.grad = None
+
     # ---- access ----------------------------------------------------------------------------------------------
     @property
     def flat(self):
-        return self._flat
+        """The buffer the optimiser steps and the gradient exchange reduces."""
+        return self._train_flat if self._train_flat is not None else self._flat
 
     def tensors(self):
         """uuid -> raw (unconstrained) tensor; trainable ones are views of the flat leaf (autograd-connected)."""

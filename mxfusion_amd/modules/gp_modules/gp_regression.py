@@ -17,6 +17,7 @@ from ...components.variables.runtime_variable import arrays_as_samples
 from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
+from ...components.distributions.gp import _linalg as lin
 from ...components.distributions.gp._linalg import CholLogPdfFn
 from ._fused import GPLogPdfFn
 
@@ -97,6 +98,12 @@ class GPRegressionSampling(SamplingAlgorithm):
         return samples
 
 
+def _grad_mode(Xt):
+    """Prediction records an autograd graph only when the test inputs are themselves differentiable (the PILCO rollout feeds the
+    policy's actions back in as inputs, pilco_alg.py:76-88); plain prediction from data runs without one."""
+    return torch.enable_grad() if (torch.is_grad_enabled() and Xt.requires_grad) else torch.no_grad()
+
+
 class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
     """gp_regression.py:138-196."""
 
@@ -114,22 +121,23 @@ class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
         Kxt = kern.K(F, X_cond, X, **kern_params)                    # (S, N, Nt)
-        LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())             # V = L^-1 Kxt
-        S = LinvKxt.shape[0]
-        mu = ops.gemm(LinvKxt, LinvY, transA=True)                   # V^T LinvY (LinvY broadcast over S by stride 0)
+        LinvKxt = lin.trsm(L, Kxt)                                   # V = L^-1 Kxt
+        mu = lin.gemm(LinvKxt, LinvY, transA=True)                   # V^T LinvY (LinvY broadcast over S by stride 0)
         if self.model.F.factor.has_mean:
             mu = mu + variables[self.model.mean]
         return X, noise_var, kern, kern_params, LinvKxt, mu
 
     def compute(self, F, variables):
-        with torch.no_grad():
+        with _grad_mode(variables[self.model.X]):
             X, noise_var, kern, kern_params, LinvKxt, mu = self._mean_and_V(F, variables)
             N = X.shape[-2]
             if self.diagonal_variance:
                 Ktt = kern.Kdiag(F, X, **kern_params)
-                var = Ktt - ops.coldot(LinvKxt, LinvKxt)
+                var = Ktt - lin.coldot(LinvKxt, LinvKxt)
                 if not self.noise_free:
                     var = var + noise_var
+            elif torch.is_grad_enabled():
+                var = kern.K(F, X, **kern_params) - lin.gemm(LinvKxt, LinvKxt, transA=True)
             else:
                 Ktt = kern.K(F, X, **kern_params)
                 var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt.contiguous().clone())
@@ -151,16 +159,19 @@ class GPRegressionSamplingPrediction(GPRegressionMeanVariancePrediction):
         self.jitter = jitter
 
     def compute(self, F, variables):
-        with torch.no_grad():
+        with _grad_mode(variables[self.model.X]):
             X, noise_var, kern, kern_params, LinvKxt, mu = self._mean_and_V(F, variables)
             N = X.shape[-2]
             out_shape = (self.num_samples,) + tuple(mu.shape[1:])
             die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
             if self.diagonal_variance:
-                var = kern.Kdiag(F, X, **kern_params) - ops.coldot(LinvKxt, LinvKxt)
+                var = kern.Kdiag(F, X, **kern_params) - lin.coldot(LinvKxt, LinvKxt)
                 if not self.noise_free:
                     var = var + noise_var
                 samples = mu + die * torch.sqrt(var.unsqueeze(-1))
+            elif torch.is_grad_enabled():
+                raise NotImplementedError('GPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
+                                          'test inputs here (it needs a reverse-mode Cholesky); use diagonal_variance=True')
             else:
                 cov = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=kern.K(F, X, **kern_params).contiguous().clone())
                 eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)

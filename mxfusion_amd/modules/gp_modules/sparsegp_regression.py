@@ -14,6 +14,8 @@ from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
 from ._fused import SGPLogPdfFn
+from ...components.distributions.gp import _linalg as lin
+from .gp_regression import _grad_mode
 
 
 class SparseGPRegressionLogPdf(VariationalInference):
@@ -61,7 +63,7 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         self.diagonal_variance = diagonal_variance
 
     def compute(self, F, variables):
-        with torch.no_grad():
+        with _grad_mode(variables[self.model.X]):       # differentiable w.r.t. the test inputs (PILCO rollouts)
             X = variables[self.model.X]
             N = X.shape[-2]
             Z = variables[self.model.inducing_inputs]
@@ -72,15 +74,19 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             kern = self.model.kernel
             kern_params = kern.fetch_parameters(variables)
             Kxt = kern.K(F, Z, X, **kern_params)
-            mu = ops.gemm(Kxt, wv, transA=True)
+            mu = lin.gemm(Kxt, wv, transA=True)
             if self.model.F.factor.has_mean:
                 mu = mu + variables[self.model.mean]
-            LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())
-            LAinvLinvKxt = ops.trsm_(LA, LinvKxt.clone())
+            LinvKxt = lin.trsm(L, Kxt)
+            LAinvLinvKxt = lin.trsm(LA, LinvKxt)
             if self.diagonal_variance:
-                var = kern.Kdiag(F, X, **kern_params) - ops.coldot(LinvKxt, LinvKxt) + ops.coldot(LAinvLinvKxt, LAinvLinvKxt)
+                var = kern.Kdiag(F, X, **kern_params) - lin.coldot(LinvKxt, LinvKxt) + lin.coldot(LAinvLinvKxt, LAinvLinvKxt)
                 if not self.noise_free:
                     var = var + noise_var
+            elif torch.is_grad_enabled():
+                var = kern.K(F, X, **kern_params) - lin.gemm(LinvKxt, LinvKxt, transA=True) + lin.gemm(LAinvLinvKxt, LAinvLinvKxt, transA=True)
+                if not self.noise_free:
+                    var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
             else:
                 Ktt = kern.K(F, X, **kern_params).contiguous().clone()
                 var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt)

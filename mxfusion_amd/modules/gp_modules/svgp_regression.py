@@ -16,6 +16,8 @@ from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
 from ._fused import SVGPLogPdfFn, SVGPMatLogPdfFn
+from ...components.distributions.gp import _linalg as lin
+from .gp_regression import _grad_mode
 
 
 def _S(t):
@@ -107,28 +109,34 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         M = Z.shape[-2]
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
-        S = ops.gemm(S_W, S_W, transB=True) + torch.diag_embed(S_diag)                  # :145
-        Kuu = kern.K(F, Z, **kern_params).contiguous().clone()
-        if self.jitter > 0.:
-            Kuu = Kuu + torch.eye(M, dtype=Z.dtype, device=Z.device) * self.jitter
-        L, _ = ops.potrf_(Kuu)
-        Ls, _ = ops.potrf_(S)
-        LinvLs = ops.trsm_(L, Ls.clone())
-        Linvmu = ops.trsm_(L, mu.contiguous().clone())
-        LinvSLinvT = ops.gemm(LinvLs, LinvLs, transB=True)
-        wv = ops.trsm_(L, Linvmu.clone(), transpose=True)
+        with torch.no_grad():       # everything that does not depend on the test inputs
+            S = ops.gemm(S_W, S_W, transB=True) + torch.diag_embed(S_diag)                  # :145
+            Kuu = kern.K(F, Z, **kern_params).contiguous().clone()
+            if self.jitter > 0.:
+                Kuu = Kuu + torch.eye(M, dtype=Z.dtype, device=Z.device) * self.jitter
+            L, _ = ops.potrf_(Kuu)
+            Ls, _ = ops.potrf_(S)
+            LinvLs = ops.trsm_(L, Ls.clone())
+            Linvmu = ops.trsm_(L, mu.contiguous().clone())
+            LinvSLinvT = ops.gemm(LinvLs, LinvLs, transB=True)
+            wv = ops.trsm_(L, Linvmu.clone(), transpose=True)
         Kxt = kern.K(F, Z, X, **kern_params)
-        mu_t = ops.gemm(Kxt, wv, transA=True)
+        mu_t = lin.gemm(Kxt, wv, transA=True)
         if self.model.F.factor.has_mean:
             mu_t = mu_t + variables[self.model.mean]
-        LinvKxt = ops.trsm_(L, Kxt.contiguous().clone())
-        tmp = ops.gemm(LinvSLinvT, LinvKxt)
+        LinvKxt = lin.trsm(L, Kxt)
+        tmp = lin.gemm(LinvSLinvT, LinvKxt)
         if self.diagonal_variance:
             Ktt = kern.Kdiag(F, X, **kern_params)
-            var = Ktt - ops.coldot(LinvKxt, LinvKxt) + ops.coldot(tmp, LinvKxt)
+            var = Ktt - lin.coldot(LinvKxt, LinvKxt) + lin.coldot(tmp, LinvKxt)
             var = var.unsqueeze(-1)
             if not self.noise_free:
                 var = var + noise_var
+        elif torch.is_grad_enabled():
+            var = kern.K(F, X, **kern_params) - lin.gemm(LinvKxt, LinvKxt, transA=True) + lin.gemm(LinvKxt, tmp, transA=True)
+            var = var.unsqueeze(-1)
+            if not self.noise_free:
+                var = var + torch.eye(N, dtype=X.dtype, device=X.device).reshape(1, N, N, 1) * noise_var.unsqueeze(-2)
         else:
             Ktt = kern.K(F, X, **kern_params).contiguous().clone()
             var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt)
@@ -139,7 +147,7 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         return mu_t, var
 
     def compute(self, F, variables):
-        with torch.no_grad():
+        with _grad_mode(variables[self.model.X]):      # differentiable w.r.t. the test inputs only (PILCO rollouts); parameters are constants here
             mu, var = self._moments(F, variables)
         outcomes = {self.model.Y.uuid: (mu, var)}
         if self.target_variables:
@@ -156,7 +164,10 @@ class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
         self._rand_gen = TorchRandomGenerator if rand_gen is None else rand_gen
 
     def compute(self, F, variables):
-        with torch.no_grad():
+        with _grad_mode(variables[self.model.X]):
+            if torch.is_grad_enabled() and not self.diagonal_variance:
+                raise NotImplementedError('SVGPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
+                                          'test inputs here; use diagonal_variance=True')
             jit, self.jitter = self.jitter, 0.      # the reference adds `jitter` to the predictive covariance here (:268-270)
             try:
                 mu, var = self._moments(F, variables)

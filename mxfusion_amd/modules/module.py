@@ -131,7 +131,13 @@ class Module(Factor):
         return alg
 
     # ---- runtime ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _uuids(targets):
+        """Targets may be given as Variables (pilco_alg.py:80 passes [model.Y]; a reference Variable hashes and compares as its UUID)."""
+        return None if targets is None else [getattr(t, 'uuid', t) for t in targets]
+
     def _names(self, variables, targets):
+        targets = self._uuids(targets)
         if targets is None:
             target_names = tuple(sorted(self.output_names))
         else:
@@ -151,7 +157,7 @@ class Module(Factor):
         target_names, conditionals_names = self._names(variables, targets)
         alg = self._get_algorithm_for_target_conditional_pair(self._draw_samples_algorithms, target_names, conditionals_names)
         alg.num_samples = num_samples
-        alg.target_variables = targets
+        alg.target_variables = self._uuids(targets)
         return alg.compute(F, variables)
 
     def predict(self, F, variables, num_samples=1, targets=None):
@@ -159,5 +165,5 @@ class Module(Factor):
         target_names, conditionals_names = self._names(variables, targets)
         alg = self._get_algorithm_for_target_conditional_pair(self._prediction_algorithms, target_names, conditionals_names, exact_match=True)
         alg.num_samples = num_samples
-        alg.target_variables = targets
+        alg.target_variables = self._uuids(targets)
         return alg.compute(F, variables)

@@ -764,3 +764,23 @@ def run_map_gp_notebook(X, Y, max_iter=100, lr=0.05, record=(10, 20, 30, 40, 50,
                        {k: v.grad for k, v in leaves.items()}, batch_size=1)
     final = {k: float(softplus(v)[0]) for k, v in raw.items()}
     return losses, final
+
+
+# ----------------------------------------------------------------------------
+# PILCO rollout: mxfusion/inference/pilco_alg.py:55-90
+# ----------------------------------------------------------------------------
+def pilco_rollout(predict, policy, cost_function, s_0, n_time_steps):
+    """pilco_alg.py:72-90 with `predict(x_t) -> (mean, variance)` standing for `model.Y.factor.predict(...)[0]` (:80).
+    s_0: (S, state_dim); states and actions travel as (S, 1, dim) (the action is given that shape from the first step on).
+    Differentiable through torch autograd w.r.t. whatever `policy` closes over."""
+    S = s_0.shape[0]
+    a_t = policy(s_0).reshape(S, 1, -1)
+    x_t = torch.cat([s_0.reshape(S, 1, -1), a_t], dim=2)
+    cost = 0
+    for t in range(n_time_steps):
+        res = predict(x_t)
+        s_next = res[0]
+        cost = cost + cost_function(s_next, a_t)
+        a_t = policy(s_next).reshape(S, 1, -1)
+        x_t = torch.cat([s_next, a_t], dim=2)
+    return torch.sum(cost)

@@ -1,0 +1,182 @@
+"""GPU parity of the PILCO rollout: prediction differentiable w.r.t. its test inputs for the three GP modules,
+PILCOAlgorithm + GradTransferInference against the oracle's rollout (mxfusion/inference/pilco_alg.py:55-90,
+grad_based_inference.py:106-140; testing/inference/pilco_test.py builds the same pendulum-shaped problem)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+DT = 'float64'
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float64).cuda()
+
+
+def _data(rng, N=40, ds=3, da=1):
+    X = rng.rand(N, ds + da)
+    Y = np.stack([np.sin(X @ rng.randn(ds + da)) for _ in range(ds)], 1) + 0.05 * rng.randn(N, ds)
+    return X, Y
+
+
+class Policy(torch.nn.Module):
+    """testing/inference/pilco_test.py:29-37 (Dense relu -> Dense tanh, times 2); tanh hidden layer here so that the loss is smooth."""
+
+    def __init__(self, ds, hidden=16):
+        super().__init__()
+        self.l1 = torch.nn.Linear(ds, hidden)
+        self.l2 = torch.nn.Linear(hidden, 1)
+
+    def forward(self, x):
+        return torch.tanh(self.l2(torch.tanh(self.l1(x)))) * 2
+
+
+def cost_fn(state, action):
+    """testing/inference/pilco_test.py:39-58."""
+    a = (2. * (state[:, :, 0:1] - 1) ** 2).sum(-1)
+    b = (.001 * action ** 2).sum(-1)
+    c = (.1 * state[:, :, 2:3] ** 2).sum(-1)
+    return a + c + b
+
+
+def _fit_gp(X, Y, max_iter=3):
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, X.shape[-1]))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.kernel = RBF(input_dim=X.shape[-1], variance=1, lengthscale=1, ARD=True, dtype=DT)
+    m.Y = GPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, shape=(m.N, Y.shape[-1]), dtype=DT)
+    m.Y.factor.gp_log_pdf.jitter = 1e-6
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=max_iter, learning_rate=0.1)
+    return m, infr
+
+
+def _oracle_gp_predictor(m, infr, X, Y):
+    """The fitted GP restated in the oracle: posterior recomputed from the trained hyper-parameters (gp_regression.py:55-75)."""
+    k = O.RBF(X.shape[-1], ARD=True)
+    ls = infr.params[m.kernel.lengthscale].double().cpu()
+    var = infr.params[m.kernel.variance].double().cpu()
+    noise = infr.params[m.noise_var].double().cpu()
+    kp = {'rbf_lengthscale': ls[None], 'rbf_variance': var[None]}
+    post = O.gp_log_pdf(k, O.T(X)[None], O.T(Y)[None], noise[None], kp, jitter=1e-6, return_posterior=True)[1]
+    return lambda xt: O.gp_predict(k, xt, noise[None], post[0][None], post[1][None], post[2][None], kp)
+
+
+def test_pilco_cost_and_policy_gradient_vs_oracle():
+    from mxfusion_amd.inference import GradTransferInference, PILCOAlgorithm
+    rng = np.random.RandomState(0)
+    X, Y = _data(rng)
+    m, infr = _fit_gp(X, Y)
+    S, T = 5, 4
+    s0 = rng.rand(S, 3)
+    torch.manual_seed(0)
+    policy = Policy(3).double()
+    ref_policy = Policy(3).double()
+    ref_policy.load_state_dict(policy.state_dict())
+    policy.cuda()
+    alg = PILCOAlgorithm(model=m, observed=[m.X, m.Y], cost_function=cost_fn, policy=policy, n_time_steps=T,
+                         initial_state_generator=lambda n: _t(s0[:n]), num_samples=S)
+    infr_p = GradTransferInference(alg, infr_params=infr.params, train_params=list(policy.parameters()), dtype=DT)
+    infr_p.initialize(X=_t(X), Y=_t(Y))
+    ex = infr_p.create_executor()
+    loss, loss_g = ex(_t(X), _t(Y))
+    loss_g.backward()
+    ref = O.pilco_rollout(_oracle_gp_predictor(m, infr, X, Y), ref_policy, cost_fn, O.T(s0), T)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-9 * abs(float(ref.detach()))
+    for p, q in zip(policy.parameters(), ref_policy.parameters()):
+        assert np.allclose(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-7, atol=1e-10 * float(q.grad.abs().max()))
+    assert infr_p.params.flat.grad.abs().sum() > 0            # the policy's gradients live in the flat buffer the optimiser steps
+    infr_p.params.zero_grad()
+
+    # two Adam steps through the driver == two oracle steps (MXNet Adam, batch_size 1); the GP's parameters do not move
+    before = {k: v.clone() for k, v in infr.params.export_raw().items()}
+    infr_p.run(max_iter=2, learning_rate=1e-2, X=_t(X), Y=_t(Y))
+    opt = O.MXNetAdam(1e-2)
+    names = [n for n, _ in ref_policy.named_parameters()]
+    raw = {n: p.detach().clone() for n, p in ref_policy.named_parameters()}
+    pred = _oracle_gp_predictor(m, infr, X, Y)
+    for _ in range(2):
+        for n, p in ref_policy.named_parameters():
+            p.data.copy_(raw[n])
+            p.grad = None
+        O.pilco_rollout(pred, ref_policy, cost_fn, O.T(s0), T).backward()
+        raw = opt.step(raw, {n: p.grad.clone() for n, p in ref_policy.named_parameters()}, batch_size=1)
+    for n, p in zip(names, policy.parameters()):
+        assert np.allclose(p.detach().cpu().numpy(), raw[n].numpy(), rtol=1e-8, atol=1e-10), n
+    for k, v in infr_p.params.export_raw().items():
+        if k in before:
+            assert torch.equal(v, before[k])
+
+
+@pytest.mark.parametrize('module', ['gp', 'svgp', 'sgp'])
+def test_prediction_gradient_wrt_test_inputs(module):
+    """d(sum of predictive mean and variance)/dX* through mxf_gram_bwd + transposed mxf_trsm == autograd through the oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import GPRegression, SVGPRegression, SparseGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP
+    rng = np.random.RandomState(3)
+    X, Y = _data(rng, N=30)
+    Q, P, Mi = X.shape[1], Y.shape[1], 7
+    Z = X[rng.permutation(30)[:Mi]] + 0.01 * rng.randn(Mi, Q)
+    ls, var, noise = rng.rand(Q) + 0.5, np.array([1.3]), np.array([0.05])
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(noise))
+    kern = (Matern52 if module == 'sgp' else RBF)(input_dim=Q, ARD=True, variance=_t(var), lengthscale=_t(ls), dtype=DT)
+    ok = (O.Matern52 if module == 'sgp' else O.RBF)(Q, ARD=True)
+    kp = {ok.name + '_lengthscale': O.T(ls)[None], ok.name + '_variance': O.T(var)[None]}
+    if module == 'gp':
+        m.Y = GPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, shape=(m.N, P), dtype=DT)
+    elif module == 'svgp':
+        m.Z = Variable(shape=(Mi, Q), initial_value=_t(Z))
+        m.Y = SVGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, P), dtype=DT)
+    else:
+        m.Z = Variable(shape=(Mi, Q), initial_value=_t(Z))
+        m.Y = SparseGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, P), dtype=DT)
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=1e-12)       # one evaluation stores the posterior; parameters stay put
+    gp = m.Y.factor
+    S, Nt = 3, 4
+    Xt = rng.rand(S, Nt, Q)
+    xt = _t(Xt).requires_grad_(True)
+    from mxfusion_amd.inference import TransferInference, SamplingAlgorithm
+
+    class _Predict(SamplingAlgorithm):          # the seam PILCOAlgorithm uses (pilco_alg.py:79-80): overwrite X, call the module's predict
+        def compute(self, F, variables):
+            variables[self.model.X] = xt
+            return self.model.Y.factor.predict(F, variables, targets=[self.model.Y], num_samples=S)[0]
+
+    tr = TransferInference(_Predict(model=m, observed=[m.X]), infr_params=infr.params, dtype=DT)
+    tr.initialize(X=_t(X))
+    mu, v = tr.create_executor()(_t(X))
+    w1, w2 = rng.randn(*mu.shape), rng.randn(*v.shape)
+    (mu * _t(w1)).sum().add((v * _t(w2)).sum()).backward()
+    xr = O.T(Xt).clone().requires_grad_(True)
+    nz = O.T(noise)[None]
+    if module == 'gp':
+        post = O.gp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], nz, kp, return_posterior=True)[1]
+        mr, vr = O.gp_predict(ok, xr, nz, post[0][None], post[1][None], post[2][None], kp)
+    elif module == 'svgp':
+        post = gp._extra_graphs[0]
+        qm, qW, qd = (infr.params[post.qU_mean].double().cpu(), infr.params[post.qU_cov_W].double().cpu(), infr.params[post.qU_cov_diag].double().cpu())
+        mr, vr = O.svgp_predict(ok, xr, O.T(Z)[None], nz, qm[None], qW[None], qd[None], kp)
+    else:
+        post = O.sgp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], O.T(Z)[None], nz, kp, return_posterior=True)[1]
+        mr, vr = O.sgp_predict(ok, xr, O.T(Z)[None], nz, post[1][None], post[2][None], post[0][None], kp)
+    assert np.allclose(mu.detach().cpu().numpy(), mr.detach().numpy(), rtol=1e-8, atol=1e-10)
+    assert np.allclose(v.detach().cpu().numpy(), vr.detach().numpy().reshape(v.shape), rtol=1e-7, atol=1e-10)
+    ((mr * O.T(w1)).sum() + (vr.reshape(w2.shape) * O.T(w2)).sum()).backward()
+    assert np.allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-7, atol=1e-9)
