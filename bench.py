@@ -136,6 +136,103 @@ def build_gp(N, Q, dtype, X, Y):
     return m, infr, loop
 
 
+class _PendulumPolicy(torch.nn.Module):
+    """testing/inference/pilco_test.py:29-37: Dense(100, relu) -> Dense(1, tanh), times 2."""
+
+    def __init__(self, ds):
+        super().__init__()
+        self.l1 = torch.nn.Linear(ds, 100)
+        self.l2 = torch.nn.Linear(100, 1)
+
+    def forward(self, x):
+        return torch.tanh(self.l2(torch.relu(self.l1(x)))) * 2
+
+
+def _pendulum_cost(state, action):
+    """testing/inference/pilco_test.py:39-58."""
+    return (2. * (state[:, :, 0:1] - 1) ** 2).sum(-1) + (.001 * action ** 2).sum(-1) + (.1 * state[:, :, 2:3] ** 2).sum(-1)
+
+
+def bench_pilco(N, S, T, dtype, steps, warmup, use_graph, cpu_baseline=True):
+    """the PILCO rollout (pilco_alg.py:72-90) as a GP-predict-in-a-loop latency benchmark.  A GPRegression dynamics
+    model on N conditioning points (3 state + 1 action inputs, 3 outputs; the pendulum shapes of testing/inference/pilco_test.py), S
+    trajectories rolled T time steps under a Dense(100)-Dense(1) policy; one step = rollout + reverse pass + Adam on the policy."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, GradTransferInference, PILCOAlgorithm, BatchInferenceLoop
+    from mxfusion_amd.inference.batch_loop import _Adam
+    td = torch.float64 if dtype == 'float64' else torch.float32
+    rng = np.random.RandomState(0)
+    X = rng.rand(N, 4)
+    Y = np.stack([np.sin(X @ rng.randn(4)) for _ in range(3)], 1) + 0.05 * rng.randn(N, 3)
+    s0 = rng.rand(S, 3)
+    t = lambda a: torch.as_tensor(a, dtype=td).cuda()
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 4))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.kernel = RBF(input_dim=4, variance=1, lengthscale=1, ARD=True, dtype=dtype)
+    m.Y = GPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, shape=(m.N, 3), dtype=dtype)
+    m.Y.factor.gp_log_pdf.jitter = 1e-6
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), dtype=dtype)
+    infr.run(X=t(X), Y=t(Y), max_iter=3, learning_rate=0.1)
+    torch.manual_seed(0)
+    policy = _PendulumPolicy(3).to(td)
+    ref_state = {k: v.clone() for k, v in policy.state_dict().items()}
+    policy.cuda()
+    s0d = t(s0)
+    alg = PILCOAlgorithm(model=m, observed=[m.X, m.Y], cost_function=_pendulum_cost, policy=policy, n_time_steps=T,
+                         initial_state_generator=lambda n: s0d, num_samples=S)
+    loop = BatchInferenceLoop(use_graph=bool(use_graph))
+    ip = GradTransferInference(alg, infr_params=infr.params, train_params=list(policy.parameters()), grad_loop=loop, dtype=dtype)
+    Xd, Yd = t(X), t(Y)
+    ip.initialize(X=Xd, Y=Yd)
+    ex = ip.create_executor()
+    opt = _Adam(ip.params, 1e-3)
+    first = None
+    for _ in range(max(warmup, 3 if use_graph else 1)):
+        loss = loop.step(ex, [Xd, Yd], ip.params)
+        first = float(loss.detach()) if first is None else first
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = loop.step(ex, [Xd, Yd], ip.params)
+        opt.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"metric": "policy-gradient steps/sec, PILCO rollout over a GPRegression dynamics model (SURVEY 8(f) rank 4)", "value": 1.0 / dt,
+           "unit": "policy-gradient steps/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3,
+           "us_per_rollout_time_step": dt / T * 1e6, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64" if dtype == 'float64' else "f32", "data": "synthetic",
+           "config": {"workload": "PILCOAlgorithm: GPRegression RBF-ARD N=%d (4 inputs, 3 outputs), %d trajectories x %d time steps, "
+                                  "Dense(100)-Dense(1) policy; step = rollout + reverse pass + Adam%s" % (N, S, T, ", hipGraph replay" if use_graph else "")},
+           "first_loss": first, "last_loss": float(loss.detach())}
+    if cpu_baseline:
+        from oracle import gp_oracle as O
+        k = O.RBF(4, ARD=True)
+        ls, var, noise = (infr.params[v].double().cpu() for v in (m.kernel.lengthscale, m.kernel.variance, m.noise_var))
+        kp = {'rbf_lengthscale': ls[None], 'rbf_variance': var[None]}
+        post = O.gp_log_pdf(k, O.T(X)[None], O.T(Y)[None], noise[None], kp, jitter=1e-6, return_posterior=True)[1]
+        pol = _PendulumPolicy(3).double()
+        pol.load_state_dict({k_: v.double() for k_, v in ref_state.items()})
+        pred = lambda xt: O.gp_predict(k, xt, noise[None], post[0][None], post[1][None], post[2][None], kp)
+        times = []
+        for _ in range(3):
+            for p_ in pol.parameters():
+                p_.grad = None
+            c0 = time.perf_counter()
+            ref = O.pilco_rollout(pred, pol, _pendulum_cost, O.T(s0), T)
+            ref.backward()
+            times.append(time.perf_counter() - c0)
+        out["cpu_baseline"] = {"value": 1.0 / min(times), "unit": "policy-gradient steps/sec", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "the same rollout + reverse pass through oracle/gp_oracle.py (torch-CPU float64), best of 3",
+                               "first_loss": float(ref.detach())}
+    return out
+
+
 def cpu_baseline_gp(N, Q, X, Y, reps=2):
     """The oracle's MAP step of the exact GP (Gram, potrf, trsm, autograd backward, Adam; float64, torch-CPU LAPACK/BLAS) at the full N."""
     from oracle import gp_oracle as O
@@ -335,8 +432,9 @@ def main():
     ap.add_argument('--M', type=int, default=1024)
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--lr', type=float, default=1e-3)
-    ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
+    ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp', 'pilco'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
+    ap.add_argument('--horizon', type=int, default=100, help='time steps of the PILCO rollout workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -357,6 +455,12 @@ def main():
     S_local = args.samples // world
     torch.manual_seed(1234 + rank)
 
+    if args.workload == 'pilco':       # GP-predict-in-a-loop latency (single GPU; the rollout is a serial chain)
+        out = bench_pilco(1000 if args.N == 65536 else args.N, 64 if args.samples == 32 else args.samples, args.horizon,
+                          'float64' if args.dtype == 'float64' else 'float32', args.steps, args.warmup, args.graph, not args.no_cpu_baseline)
+        if rank == 0:
+            print(json.dumps(out))
+        return
     if args.workload == 'gp':          # secondary workload: BASELINE.json configs[1] (exact GP, N=8192 D=8; does not shard: replicas only)
         N, Q = (8192 if args.N == 65536 else args.N), args.Q
         X, Y, _ = synth(N, Q, 1)

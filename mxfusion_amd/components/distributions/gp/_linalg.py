@@ -161,3 +161,25 @@ def coldot(A, B):
     if _needs_grad(A, B):
         return ColdotFn.apply(A, B)
     return ops.coldot(A, B)
+
+
+class _InverseCache(object):
+    """L^-1 (mxf_trtri) of a shared lower factor, kept while the factor tensor is unchanged (same storage, same version counter)."""
+
+    def __init__(self):
+        self._key, self._inv, self._held = None, None, None
+
+    def get(self, L):
+        key = (L.data_ptr(), L._version, tuple(L.shape), L.dtype)
+        if key != self._key:
+            with torch.no_grad():
+                self._inv = ops.trtri(L.detach())
+            self._key, self._held = key, L        # holding the factor keeps its storage from being recycled under the same address
+        return self._inv
+
+
+def solve_shared(L, B, cache):
+    """L^-1 B for a factor shared by all samples inside a differentiable loop (the PILCO rollout: hundreds of solves against the SAME
+    factor with one right-hand side per trajectory).  mxf_trsm is a chain of N / 64 dependent panel steps however few columns B has;
+    with the cached explicit inverse the solve -- and its reverse pass -- is one GEMM each."""
+    return gemm(cache.get(L), B)

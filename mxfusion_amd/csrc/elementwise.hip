@@ -111,6 +111,29 @@ __global__ void coldot_kernel(int64_t M, int64_t N, const T* __restrict__ A, int
     out[(int64_t)blockIdx.y * N + n] = acc;
 }
 
+// few columns (the rollout's one test point per trajectory: N = 64, M = 1000): a thread per column leaves the chip idle and walks the rows
+// serially (224 us at that shape); here a workgroup owns 16 columns and spreads the rows over 16 lanes each, combined through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void coldot_small_kernel(int64_t M, int64_t N, const T* __restrict__ A, int64_t lda, int64_t sA,
+                                                           const T* __restrict__ B, int64_t ldb, int64_t sB, T* __restrict__ out) {
+    __shared__ T part[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int64_t n = (int64_t)blockIdx.x * 16 + cx;
+    const T* a = A + (int64_t)blockIdx.y * sA;
+    const T* b = B + (int64_t)blockIdx.y * sB;
+    T acc = 0;
+    if (n < N)
+        for (int64_t m = ry; m < M; m += 16) acc = fma(a[m * lda + n], b[m * ldb + n], acc);
+    part[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && n < N) {
+        T t = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][cx];
+        out[(int64_t)blockIdx.y * N + n] = t;
+    }
+}
+
 inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -197,6 +220,12 @@ extern "C" int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, 
     if (S <= 0 || N <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 g((unsigned)((N + 255) / 256), (unsigned)S);
+    if ((int64_t)S * N < 16384 && M >= 64) {
+        dim3 gs((unsigned)((N + 15) / 16), (unsigned)S);
+        DISPATCH(h, dtype, "mxf_coldot",
+                 hipLaunchKernelGGL((coldot_small_kernel<float>), gs, dim3(256), 0, st, M, N, (const float*)A, lda, strideS_A, (const float*)B, ldb, strideS_B, (float*)out),
+                 hipLaunchKernelGGL((coldot_small_kernel<double>), gs, dim3(256), 0, st, M, N, (const double*)A, lda, strideS_A, (const double*)B, ldb, strideS_B, (double*)out));
+    }
     DISPATCH(h, dtype, "mxf_coldot",
              hipLaunchKernelGGL((coldot_kernel<float>), g, dim3(256), 0, st, M, N, (const float*)A, lda, strideS_A, (const float*)B, ldb, strideS_B, (float*)out),
              hipLaunchKernelGGL((coldot_kernel<double>), g, dim3(256), 0, st, M, N, (const double*)A, lda, strideS_A, (const double*)B, ldb, strideS_B, (double*)out));

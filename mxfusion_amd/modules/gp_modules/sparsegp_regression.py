@@ -73,14 +73,22 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             wv = variables[self.graphs[1].wv]
             kern = self.model.kernel
             kern_params = kern.fetch_parameters(variables)
+            fold = None             # S samples of the test inputs against one posterior: fold them into columns (gp_regression.py here)
+            if self.diagonal_variance and X.shape[0] > 1 and all(t.shape[0] == 1 for t in [Z, noise_var, L, LA, wv] + list(kern_params.values())):
+                fold = tuple(X.shape[:2])
+                X = X.reshape(1, fold[0] * fold[1], X.shape[-1])
             Kxt = kern.K(F, Z, X, **kern_params)
             mu = lin.gemm(Kxt, wv, transA=True)
+            if fold is not None:
+                mu = mu.reshape(fold + (mu.shape[-1],))
             if self.model.F.factor.has_mean:
                 mu = mu + variables[self.model.mean]
             LinvKxt = lin.trsm(L, Kxt)
             LAinvLinvKxt = lin.trsm(LA, LinvKxt)
             if self.diagonal_variance:
                 var = kern.Kdiag(F, X, **kern_params) - lin.coldot(LinvKxt, LinvKxt) + lin.coldot(LAinvLinvKxt, LAinvLinvKxt)
+                if fold is not None:
+                    var = var.reshape(fold)
                 if not self.noise_free:
                     var = var + noise_var
             elif torch.is_grad_enabled():

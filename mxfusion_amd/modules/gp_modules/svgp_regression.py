@@ -109,6 +109,10 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         M = Z.shape[-2]
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
+        fold = None                 # S samples of the test inputs against one posterior: fold them into columns (gp_regression.py here)
+        if self.diagonal_variance and X.shape[0] > 1 and all(t.shape[0] == 1 for t in [Z, noise_var, mu, S_W, S_diag] + list(kern_params.values())):
+            fold = tuple(X.shape[:2])
+            X = X.reshape(1, fold[0] * fold[1], X.shape[-1])
         with torch.no_grad():       # everything that does not depend on the test inputs
             S = ops.gemm(S_W, S_W, transB=True) + torch.diag_embed(S_diag)                  # :145
             Kuu = kern.K(F, Z, **kern_params).contiguous().clone()
@@ -122,13 +126,20 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             wv = ops.trsm_(L, Linvmu.clone(), transpose=True)
         Kxt = kern.K(F, Z, X, **kern_params)
         mu_t = lin.gemm(Kxt, wv, transA=True)
+        if fold is not None:
+            mu_t = mu_t.reshape(fold + (mu_t.shape[-1],))
         if self.model.F.factor.has_mean:
             mu_t = mu_t + variables[self.model.mean]
-        LinvKxt = lin.trsm(L, Kxt)
+        if torch.is_grad_enabled() and L.shape[0] == 1:
+            LinvKxt = lin.gemm(ops.trtri(L), Kxt)        # rollout: one GEMM (and one in the reverse pass) instead of a chain of panel solves
+        else:
+            LinvKxt = lin.trsm(L, Kxt)
         tmp = lin.gemm(LinvSLinvT, LinvKxt)
         if self.diagonal_variance:
             Ktt = kern.Kdiag(F, X, **kern_params)
             var = Ktt - lin.coldot(LinvKxt, LinvKxt) + lin.coldot(tmp, LinvKxt)
+            if fold is not None:
+                var = var.reshape(fold)
             var = var.unsqueeze(-1)
             if not self.noise_free:
                 var = var + noise_var

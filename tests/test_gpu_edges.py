@@ -94,3 +94,18 @@ def test_nan_input_is_reported_not_hidden():
     assert int(r['info'][0]) > 0
     with pytest.raises(_lib.MXFError):
         ops.check_info(r['info'])
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('S,M,N', [(1, 1000, 64), (3, 70, 5), (2, 64, 8192), (1, 40, 7), (2, 300, 20000)])
+def test_coldot_shapes(dtype, S, M, N):
+    """mxf_coldot (F.sum(A*B, axis=-2)): the few-column workgroup-per-16-columns kernel and the thread-per-column one, one operand shared
+    over the sample axis."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(S + M + N)
+    A, B = rng.randn(S, M, N), rng.randn(1, M, N)
+    got = ops.coldot(torch.as_tensor(A, dtype=dtype).cuda(), torch.as_tensor(B, dtype=dtype).cuda())
+    ref = (A * B).sum(-2)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    assert got.shape == (S, N)
+    assert np.allclose(got.double().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
