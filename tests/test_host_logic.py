@@ -120,3 +120,32 @@ def test_minibatch_rollover_indexing(monkeypatch):
     loop.run(executor, data, param_dict=None, ctx=None, max_iter=2)
     assert all(b.numel() == 4 for b in seen) and len(seen) == 5          # 10 + 10 samples -> 2 + 3 full batches, 0 left
     assert sorted(torch.cat(seen).tolist()) == sorted(list(range(10)) * 2)
+
+
+def test_grad_transfer_parameters_fixed_model_trainable_policy_on_cpu():
+    """GradTransferInference's parameter handling (grad_based_inference.py:124-140): inherited parameters are carried over and fixed;
+    the caller's `train_params` are re-homed into one flat buffer whose .grad is the flat gradient the optimiser / all-reduce see."""
+    from mxfusion_amd.inference import GradTransferInference, PILCOAlgorithm
+    m = _gp()
+    alg0 = MAP(model=m, observed=[m.X, m.Y])
+    trained = InferenceParameters(dtype='float64', context=torch.device('cpu'))
+    trained.initialize_params(alg0.graphs, alg0.observed_variable_UUIDs, seed=0)
+    trained[m.noise_var] = np.array([0.3])
+    policy = torch.nn.Linear(3, 1)                                            # float32 module: re-homed in the inference dtype
+    w0 = policy.weight.detach().clone().double()
+    alg = PILCOAlgorithm(model=m, observed=[m.X, m.Y], cost_function=None, policy=policy, n_time_steps=2,
+                         initial_state_generator=None, num_samples=3)
+    infr = GradTransferInference(alg, infr_params=trained, train_params=list(policy.parameters()), dtype='float64', context=torch.device('cpu'))
+    infr.initialize(X=(5, 3), Y=(5, 2))
+    p = infr.params
+    assert np.allclose(np.log1p(np.exp(p.raw(m.noise_var).numpy())), 0.3)                 # carried over (stored unconstrained) ...
+    assert not any(t.requires_grad for t in p.tensors().values())                          # ... and fixed
+    assert p.flat.numel() == 4 and p.flat.dtype == torch.float64 and policy.weight.dtype == torch.float64
+    assert torch.allclose(policy.weight.detach(), w0) and policy.weight.data_ptr() == p.flat.data_ptr()
+    (policy(torch.ones(2, 3, dtype=torch.float64)).sum() * 3).backward()
+    assert torch.allclose(p.flat.grad, torch.tensor([6., 6., 6., 6.], dtype=torch.float64))   # weight grads 3*2 each, bias grad 3*2
+    with torch.no_grad():
+        p.flat.detach().sub_(1.0)                                                          # an optimiser step on the flat buffer ...
+    assert torch.allclose(policy.weight.detach(), w0 - 1.0)                                # ... is a step on the module's tensors
+    p.zero_grad()
+    assert float(p.flat.grad.abs().sum()) == 0 and policy.weight.grad.data_ptr() == p.flat.grad.data_ptr()
