@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+# three HIP streams of the step (main + two side streams) plus torch's and RCCL's own: with the default of 4 hardware queues two of the
+# step's streams share one as soon as RCCL is initialised and the two Cholesky chains serialise (+1.2 ms per step at 4 samples per GPU).
+# Read when the HIP runtime initialises (first device call), so it must be in the environment before that.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -441,6 +446,16 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to the C stdout at start-up (seen after the JSON when stdout
+    # is a pipe), so file descriptor 1 is pointed at stderr for the rest of the run and the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    _json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        with os.fdopen(os.dup(_json_fd), 'w') as f:
+            f.write(json.dumps(obj) + '\n')
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -459,7 +474,7 @@ def main():
         out = bench_pilco(1000 if args.N == 65536 else args.N, 64 if args.samples == 32 else args.samples, args.horizon,
                           'float64' if args.dtype == 'float64' else 'float32', args.steps, args.warmup, args.graph, not args.no_cpu_baseline)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
     if args.workload == 'gp':          # secondary workload: BASELINE.json configs[1] (exact GP, N=8192 D=8; does not shard: replicas only)
         N, Q = (8192 if args.N == 65536 else args.N), args.Q
@@ -478,7 +493,7 @@ def main():
         if rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_gp(N, Q, X, Y)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if distributed:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -491,7 +506,7 @@ def main():
         data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]
         dt, last_loss = time_steps_multi(infr, loop, data, args.steps, args.warmup, args.lr, distributed)
         if rank == 0:
-            print(json.dumps({
+            emit(({
                 "metric": "ELBO-steps/sec, 2-layer SVGP deep GP (BASELINE.json configs[4])", "value": args.steps / dt, "unit": "ELBO-steps/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
@@ -554,7 +569,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, Q, M, args.samples, X, Y, Z)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
