@@ -77,7 +77,8 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
 static inline bool mxf_side_init(mxf_ctx* h) {
     if (h->side) return true;
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
-    // (a CU-masked side2 via hipExtStreamCreateWithCUMask was measured: 83 -> 114 ms per step; plain stream kept)
+    // (a CU-masked side2 via hipExtStreamCreateWithCUMask was measured: 83 -> 114 ms per step; stream priorities -- bulk stream lowest,
+    //  Su-chain stream highest -- were measured too: no change at 1, 4 or 32 samples; plain streams kept)
     if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) { h->side2 = nullptr; return false; }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
