@@ -33,14 +33,14 @@ struct GramArgs {
 
 template <typename T> __device__ __forceinline__ T fast_exp2_neg(T x);   // 2^(-x), x >= 0
 template <> __device__ __forceinline__ float fast_exp2_neg<float>(float x) { return __builtin_amdgcn_exp2f(-x); }
-template <> __device__ __forceinline__ double fast_exp2_neg<double>(double x) { return exp2(-x); }
+template <> __device__ __forceinline__ double fast_exp2_neg<double>(double x) { return mxf_exp2_neg_f64(x); }
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __builtin_sqrtf(x); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 template <typename T> __device__ __forceinline__ T t_exp(T x);
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return mxf_exp_nonpos_f64(x); }   // only called with x <= 0
 
 // coordinate pre-scale so that the RBF epilogue is a bare exp2:  exp(-r2/2) = 2^-(c^2 r2), c^2 = log2(e)/2
 template <typename T, int KIND> __device__ __forceinline__ T coord_scale() {

@@ -37,18 +37,21 @@ struct GramBwdArgs {
 __device__ __forceinline__ void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+__device__ __forceinline__ float expnp(float x) { return exp(x); }
+__device__ __forceinline__ double expnp(double x) { return mxf_exp_nonpos_f64(x); }      // arguments here are never positive
+
 // unit-variance covariance k and slope dk/d(r2) (r2 in lengthscale-scaled coordinates)
 template <typename T, int KIND>
 __device__ __forceinline__ void cov_and_slope(T r2, T& k, T& w) {
-    if (KIND == MXF_K_RBF) { k = exp((T)-0.5 * r2); w = (T)-0.5 * k; return; }
+    if (KIND == MXF_K_RBF) { k = expnp((T)-0.5 * r2); w = (T)-0.5 * k; return; }
     const bool clipped = r2 < (T)1e-14;
     const T r = sqrt(clipped ? (T)1e-14 : r2);
-    if (KIND == MXF_K_MATERN12) { k = exp(-r); w = clipped ? (T)0 : -k / ((T)2 * r); return; }
+    if (KIND == MXF_K_MATERN12) { k = expnp(-r); w = clipped ? (T)0 : -k / ((T)2 * r); return; }
     if (KIND == MXF_K_MATERN32) {
-        const T s3 = (T)1.7320508075688772, e = exp(-s3 * r);
+        const T s3 = (T)1.7320508075688772, e = expnp(-s3 * r);
         k = ((T)1 + s3 * r) * e; w = clipped ? (T)0 : (T)-1.5 * e; return;
     }
-    const T s5 = (T)2.23606797749979, e = exp(-s5 * r);   // MATERN52 (matern.py:85-87: un-clipped r2 in the 5/3 term)
+    const T s5 = (T)2.23606797749979, e = expnp(-s5 * r);   // MATERN52 (matern.py:85-87: un-clipped r2 in the 5/3 term)
     k = ((T)1 + s5 * r + (T)(5.0 / 3.0) * r2) * e;
     w = clipped ? (T)(5.0 / 3.0) * e : (T)(-5.0 / 6.0) * ((T)1 + s5 * r) * e;
 }
