@@ -14,7 +14,7 @@ struct mxf_ctx {
     size_t ws_bytes = 0;
     hipStream_t side = nullptr;   // internal side streams: independent chains of the SVGP step run concurrently
     hipStream_t side2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_su = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
     int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
@@ -84,6 +84,7 @@ static inline bool mxf_side_init(mxf_ctx* h) {
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_aux2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }

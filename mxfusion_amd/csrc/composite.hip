@@ -615,8 +615,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
                                       (int64_t)pl_big, gscr0, sd_);
         if (rc) return rc;
-        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));
-        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux, 0));
+        // ordering for bandwidth only (the Kfu planes are written next to Psi2 rather than next to the Kuf planes); skipped while the
+        // step is being captured into a hipGraph: a dependency between the two forked streams crashes hipStreamEndCapture (ROCm 7.0)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            MXF_HIP(h, hipEventRecord(h->ev_aux2, sd_));
+            MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
+        }
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
                                       (int64_t)pl_big, gscr1, s2_);
         if (rc) return rc;

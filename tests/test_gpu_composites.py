@@ -307,3 +307,36 @@ def test_svgp_logpdf_sampled_outputs_over_shared_inputs(dtype, tol, B, M, Q, P, 
     _close(rm['logL'], logL, tol, 'logL (mat)')
     for key in ('dY', 'dnoise', 'dmu', 'dW', 'dSdiag'):
         _close(rm[key].reshape(r[key].shape), r[key].double().cpu(), gtol, key + ' (mat)')
+
+
+def test_svgp_split_path_training_call_is_graph_capturable():
+    """The float32 training call on the split path (three HIP streams forked and joined by events) captured into a hipGraph and
+    replayed gives the eager result.  Regression: a dependency between the two forked streams crashed hipStreamEndCapture."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(5)
+    S, B, M, Q, P = 2, 512, 128, 8, 1
+    X = rng.uniform(-2, 2, (S, B, Q))
+    Y = np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P)
+    Z = rng.uniform(-2, 2, (M, Q))
+    dt = torch.float32
+    args = [_dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(np.array([0.05]), dt), _dev(rng.randn(M, P) * 0.3, dt), _dev(rng.randn(M, M) * 0.05, dt),
+            _dev(rng.rand(M) + 0.5, dt), _dev((rng.rand(Q) * 0.3 + 0.3) * np.sqrt(Q / 3.0), dt), _dev(np.array([1.3]), dt), True]
+    call = lambda: ops.svgp_logpdf('rbf', *args, jitter=1e-6, scaling=1.0, gscale=1.0 / S, want_grad=True)
+    ref = call()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):          # warm-up off the default stream (scratch growth, lazy initialisation)
+        call()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = call()
+    for _ in range(2):
+        args[0].add_(0.0)                  # same inputs: the replay must reproduce the eager values
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(out['info'].abs().sum()) == 0
+    for key in ('logL', 'dX', 'dZ', 'dW', 'dls', 'dmu', 'dnoise', 'dSdiag', 'dvar'):
+        a, b = ref[key].double().cpu().numpy(), out[key].double().cpu().numpy()
+        assert np.allclose(a, b, rtol=2e-4, atol=2e-5 * max(1e-30, np.abs(a).max())), key      # f32 atomics: summation order differs run to run
