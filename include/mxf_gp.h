@@ -97,6 +97,13 @@ int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t M, int64_t
 int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
                    double beta, void* C, int64_t ldc, int lower_only, void* stream);
 
+/* The same product from TWO scaled f16 terms per operand and THREE matrix-pipe products (hi hi' + hi lo' + lo hi'; each operand is
+ * scaled by the power of two that puts its largest magnitude at [2^13, 2^14), so the low term keeps its 11 bits over 2^18 of dynamic
+ * range): the f32 MFMA's product accuracy at 3/16 of its cost.  This is the form the SVGP training step uses for Psi2 = Kuf Kuf^T and
+ * T = H0 Kuf (MXF_SPLIT_MODE=bf16x3 selects the three-term form there).  Normwise f32 accuracy.                                      */
+int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
+                   double beta, void* C, int64_t ldc, int lower_only, void* stream);
+
 /* The two halves of mxf_gemm_f32x3 for callers that reuse split operands (the SVGP step splits Kuf once for two products):
  * mxf_f32x3_split writes the three bf16 planes of an (R x K) float32 matrix (k16-blocked, see gemm_split.hip) into `planes`
  * (3 * mxf_f32x3_plane_elems(R, K) 16-bit elements); mxf_gemm_f32x3_planes multiplies two split operands.                         */

@@ -300,9 +300,10 @@ __global__ __launch_bounds__(256) void wt_kuf_kernel(int64_t M, int64_t SB, int 
 
 // The same row block from the three-term bf16 planes of Kfu (operand (n, k = m), gemm_split.hip layout): U[p][n] = sum_m w[m][p] Kfu[n][m].
 // lane <-> column n (32 contiguous bytes per lane and plane per k block); HBM-read bound (6 bytes per element).
-template <int PT>
+// NP = 2: f16x2 planes holding k / variance * 2^14 (result scaled by variance * 2^-14).
+template <int PT, int NP>
 __global__ __launch_bounds__(256) void wt_planes_kernel(int64_t M, int64_t SB, int P, const unsigned short* __restrict__ pl, int64_t pstride,
-                                                        const float* __restrict__ w, float* __restrict__ U) {
+                                                        const float* __restrict__ w, float* __restrict__ U, const float* __restrict__ var) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= SB) return;
@@ -312,17 +313,21 @@ __global__ __launch_bounds__(256) void wt_planes_kernel(int64_t M, int64_t SB, i
     const int64_t K16 = (M + 15) / 16;
     for (int64_t kb = 0; kb < K16; ++kb) {
         const unsigned short* base = pl + (kb * SB + n) * 16;
-        u4 v[3][2];
+        u4 v[NP][2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { v[q][0] = *reinterpret_cast<const u4*>(base + q * pstride); v[q][1] = *reinterpret_cast<const u4*>(base + q * pstride + 8); }
+        for (int q = 0; q < NP; ++q) { v[q][0] = *reinterpret_cast<const u4*>(base + q * pstride); v[q][1] = *reinterpret_cast<const u4*>(base + q * pstride + 8); }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float x = 0.f;
 #pragma unroll
-            for (int q = 2; q >= 0; --q) {
+            for (int q = NP - 1; q >= 0; --q) {
                 const unsigned word = v[q][j >> 3][(j & 7) >> 1];
-                const unsigned bits = (j & 1) ? (word & 0xffff0000u) : (word << 16);
-                x += __builtin_bit_cast(float, bits);
+                if (NP == 2) {
+                    x += (float)__builtin_bit_cast(_Float16, (unsigned short)((j & 1) ? (word >> 16) : (word & 0xffffu)));
+                } else {
+                    const unsigned bits = (j & 1) ? (word & 0xffff0000u) : (word << 16);
+                    x += __builtin_bit_cast(float, bits);
+                }
             }
             const int64_t m = kb * 16 + j;
             if (m < M) {
@@ -331,8 +336,9 @@ __global__ __launch_bounds__(256) void wt_planes_kernel(int64_t M, int64_t SB, i
             }
         }
     }
+    const float sc = NP == 2 ? var[0] * (1.f / 16384.f) : 1.f;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) if (p < P) U[(int64_t)p * SB + n] = acc[p];
+    for (int p = 0; p < PT; ++p) if (p < P) U[(int64_t)p * SB + n] = acc[p] * sc;
 }
 
 // A_Ki = (G - T1 - T1^T) + 1/2 (Gw mu^T + mu Gw^T) - b (P/2 Su + 1/2 mu mu^T)
@@ -543,6 +549,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // float32 streaming: the two big GEMMs run on the bf16 matrix pipe from three-term split planes of their operands (gemm_split.hip)
     static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
+    // operand format of the split GEMMs: two scaled f16 terms / three products (default) or three bf16 terms / six products
+    static const int split_mode = (getenv("MXF_SPLIT_MODE") && !strcmp(getenv("MXF_SPLIT_MODE"), "bf16x3")) ? MXF_SPLIT_BF16X3 : MXF_SPLIT_F16X2;
+    const float split_ga = split_mode == MXF_SPLIT_F16X2 ? (1.f / 16384.f) : 1.f;     // Gram planes hold k / variance * 2^14 in the f16x2 format
+    const float* split_var = split_mode == MXF_SPLIT_F16X2 ? (const float*)var : nullptr;
     const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
     const size_t gp_scr = use_split ? mxf_gram_planes_scratch_bytes(SB, SB, Q) : 0;      // upper bound for either orientation
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
@@ -613,7 +623,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
         // (n, k = m): T GEMM and the w^T Kuf row) are then written (HBM bound) on the second side stream NEXT TO Psi2.
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
-                                      (int64_t)pl_big, gscr0, sd_);
+                                      (int64_t)pl_big, gscr0, sd_, split_mode);
         if (rc) return rc;
         // ordering for bandwidth only (the Kfu planes are written next to Psi2 rather than next to the Kuf planes); skipped while the
         // step is being captured into a hipGraph: a dependency between the two forked streams crashes hipStreamEndCapture (ROCm 7.0)
@@ -624,7 +634,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
         }
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
-                                      (int64_t)pl_big, gscr1, s2_);
+                                      (int64_t)pl_big, gscr1, s2_, split_mode);
         if (rc) return rc;
         MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes ready: the T GEMM waits for it
     } else {
@@ -644,14 +654,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (use_split) {
             if (KA > 0) {
                 // 3 workgroups of the split kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs
-                rc = mxf_gemm_split_internal(h, M, M, KA, 1.0, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                             psi2_ra_env ? psi2_ra : 184);
+                rc = mxf_gemm_split_internal(h, M, M, KA, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                             psi2_ra_env ? psi2_ra : 184, split_mode, split_var, 2, nullptr);
                 if (rc) return rc;
             }
             if (KA < SB) {
                 const unsigned short* pk = plKuf + (KA / 16) * M * 16;
-                rc = mxf_gemm_split_internal(h, M, M, SB - KA, 1.0, pk, (int64_t)pl_big, pk, (int64_t)pl_big, KA > 0 ? 1.0 : 0.0, (float*)Psi2, M, 1, sd_,
-                                             psi2_rb);
+                rc = mxf_gemm_split_internal(h, M, M, SB - KA, (double)split_ga * split_ga, pk, (int64_t)pl_big, pk, (int64_t)pl_big, KA > 0 ? 1.0 : 0.0, (float*)Psi2, M, 1, sd_,
+                                             psi2_rb, split_mode, split_var, 2, nullptr);
                 if (rc) return rc;
             }
         } else {
@@ -710,20 +720,32 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
     if (use_split) {
-        rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st);
+        unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
+        if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st); if (rc) return rc; }
+        rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st, split_mode, split_mode == MXF_SPLIT_F16X2 ? h0max : nullptr);
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     if (use_split)   // T = H0 Kuf = H0 Kfu^T on the bf16 pipe (f32-equivalent three-term splitting)
-        rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0);
+        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
+                                     split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr);
     else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
     if (use_split) {
         dim3 gu((unsigned)((SB + 255) / 256));
-        if (P == 1) hipLaunchKernelGGL((wt_planes_kernel<1>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, (const float*)wT, (float*)(Text + M * SB));
-        else hipLaunchKernelGGL((wt_planes_kernel<8>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, (const float*)wT, (float*)(Text + M * SB));
+#define WT_GO(PTV)                                                                                                                              \
+        do {                                                                                                                               \
+            if (split_mode == MXF_SPLIT_F16X2)                                                                                             \
+                hipLaunchKernelGGL((wt_planes_kernel<PTV, 2>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, \
+                                   (const float*)wT, (float*)(Text + M * SB), (const float*)var);                                         \
+            else                                                                                                                           \
+                hipLaunchKernelGGL((wt_planes_kernel<PTV, 3>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, \
+                                   (const float*)wT, (float*)(Text + M * SB), (const float*)var);                                         \
+        } while (0)
+        if (P == 1) WT_GO(1); else WT_GO(8);
+#undef WT_GO
     } else {
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));

@@ -15,6 +15,13 @@
 // copy per thread and the LDS image equals the global one (with an XOR swizzle of the two 16-byte halves of a row, which makes
 // the ds_read_b128 fragment reads conflict free).  A-fragment of v_mfma_f32_32x32x16_bf16: lane l -> A[i = l & 31][k = 8 (l >> 5) .. +7]
 // = one 16-byte unit; B likewise (both operands are k-contiguous: "NT" form only -- the SVGP step has both Kuf and Kfu).
+//
+// Second operand format ("f16x2", NP = 2): x * s = hi + lo with two f16 terms (11 + 11 significand bits), s a power of two that puts the
+// operand's largest magnitude at [2^13, 2^14] -- near the top of the f16 range, so that lo keeps its 11 bits down to 2^-18 of the
+// maximum and its absolute error never exceeds 2^-39 of it.  Three products (hi hi' + hi lo' + lo hi'; dropped lo lo' <= 2^-22 |x y|,
+// representation error <= 2^-23 |x|): the product accuracy of the f32 MFMA at 3/16 of its cost instead of 6/16 (peak 2.5 PF / 3).
+// The scale of a Gram operand is known in closed form (unit-variance covariances are <= 1: planes hold k / variance * 2^14); the scale
+// of a general operand comes from its max-abs word (mxf_maxabs_internal), read by the splitter and by the GEMM epilogue.
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
@@ -22,6 +29,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -29,8 +37,18 @@ constexpr int SBM = 128, SBN = 128, SNT = 256;   // one 16-wide k block per MFMA
 
 // ------------------------------------------------------------------------------------------------ f32 -> three bf16 planes
 // X (R x K, row stride ld) -> planes; K is padded with zeros to a multiple of 16 (Kp).  One block: 64 rows x 64 k.
+// power-of-two scale that puts |x| <= max at [2^13, 2^14]; max given as the bit pattern of a non-negative float
+__device__ __forceinline__ float scale_from_maxbits(unsigned bits) {
+    const int ex = (int)((bits >> 23) & 0xff);                 // biased exponent of the maximum: max in [2^(ex-127), 2^(ex-126))
+    if (ex == 0 || ex == 0xff) return 1.f;                      // zero / denormal / non-finite maximum: leave unscaled
+    int e = 14 - (ex - 126);                                    // max * 2^e in [2^13, 2^14)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
+template <int NP>
 __global__ __launch_bounds__(256) void split_planes_kernel(int64_t R, int64_t K, const float* __restrict__ X, int64_t ld,
-                                                           unsigned short* __restrict__ P, int64_t pstride) {
+                                                           unsigned short* __restrict__ P, int64_t pstride, const unsigned* __restrict__ maxbits) {
     __shared__ float tile[64][68];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * 64, k0 = (int64_t)blockIdx.x * 64;
@@ -56,9 +74,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int64_t R, int64_t K,
     const int64_t Kp16 = (K + 15) / 16;
     if (r >= R || kb >= Kp16) return;
     unsigned short h[16], m[16], l[16];
+    const float sc = (NP == 2 && maxbits) ? scale_from_maxbits(maxbits[0]) : 1.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float x = tile[row][kbl * 16 + j];
+        if (NP == 2) {
+            const float xs = x * sc;
+            const _Float16 fh = (_Float16)xs;
+            const _Float16 fl = (_Float16)(xs - (float)fh);
+            h[j] = __builtin_bit_cast(unsigned short, fh); m[j] = __builtin_bit_cast(unsigned short, fl); l[j] = 0;
+            continue;
+        }
         const __bf16 bh = (__bf16)x;
         const float r1 = x - (float)bh;
         const __bf16 bm = (__bf16)r1;
@@ -76,7 +102,18 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int64_t R, int64_t K,
     };
     put(P + off, h);
     put(P + pstride + off, m);
-    put(P + 2 * pstride + off, l);
+    if (NP == 3) put(P + 2 * pstride + off, l);
+}
+
+// bit pattern of max |x| (non-negative floats order like unsigned integers); out must be zeroed
+__global__ __launch_bounds__(256) void maxabs_kernel(int64_t n, int64_t K, int64_t ld, const float* __restrict__ x, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, x[(i / K) * ld + i % K]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // ------------------------------------------------------------------------------------------------ the GEMM
@@ -88,13 +125,16 @@ struct SplitArgs {
     int splitk, lower_only, atomic, nprod, use_dma;
     int64_t kchunk;             // k blocks per split
     int64_t tm, tn, ntiles, nwg;
+    const float* ad0; int pow0;          // alpha *= ad0[0]^pow0 (device scalar, e.g. the kernel variance of Gram planes)
+    const unsigned* maxbits;             // alpha /= scale_from_maxbits(maxbits[0]) (the power-of-two scale of an f16x2 operand)
+    const unsigned* maxbits2;            // the same for the other operand
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
 
-template <bool DMA>
+template <bool DMA, int NP>
 __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
-    __shared__ u32x4 smem[2][2][3][256];   // [buffer][A|B][plane][unit]  (48 KB)
+    __shared__ u32x4 smem[2][2][NP][256];   // [buffer][A|B][plane][unit]  (48 KB for three planes, 32 KB for two)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     int64_t wid = blockIdx.x;
@@ -131,18 +171,18 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     const unsigned short* pa = g.A + (m0 + lrow) * 16 + lkh * 8;
     const unsigned short* pb = g.B + (n0 + lrow) * 16 + lkh * 8;
     const int sunit = lds_unit(lrow, lkh);
-    u32x4 ra[3], rb[3];
+    u32x4 ra[NP], rb[NP];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 #define SLOAD(kb)                                                                                                                  \
     do {                                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                            \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                           \
             ra[p] = va ? *reinterpret_cast<const u32x4*>(pa + p * g.pA + (kb) * g.M * 16) : zero4;                                 \
             rb[p] = vb ? *reinterpret_cast<const u32x4*>(pb + p * g.pB + (kb) * g.N * 16) : zero4;                                 \
         }                                                                                                                          \
     } while (0)
 #define SSTORE(buf)                                                                                                                \
     do {                                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) { smem[buf][0][p][sunit] = ra[p]; smem[buf][1][p][sunit] = rb[p]; }          \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) { smem[buf][0][p][sunit] = ra[p]; smem[buf][1][p][sunit] = rb[p]; }         \
     } while (0)
     // interior tiles: LDS-DMA (global_load_lds_dwordx4) straight into the other LDS buffer -- no staging VGPRs, no ds_write pass.
     // The LDS destination of a wave is linear (base + lane * 16), so the XOR swizzle is applied to the SOURCE: the lane that fills
@@ -153,7 +193,7 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     const unsigned short* db = g.B + (n0 + drow) * 16 + dkh * 8;
 #define SDMA(kb, buf)                                                                                                              \
     do {                                                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                            \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                           \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + p * g.pA + (kb) * g.M * 16),     \
                                              (__attribute__((address_space(3))) void*)(&smem[buf][0][p][wave * 64]), 16, 0, 0);    \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + p * g.pB + (kb) * g.N * 16),     \
@@ -173,27 +213,37 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
     for (int64_t kb = kbeg; kb < kend; ++kb) {
         const bool more = kb + 1 < kend;
         if (more) { if constexpr (dma) SDMA(kb + 1, cur ^ 1); else SLOAD(kb + 1); }
-        bf16x8 a[2][3], b[2][3];
+        u32x4 a[2][NP], b[2][NP];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[x][p] = __builtin_bit_cast(bf16x8, smem[cur][0][p][ua[x]]);
-                b[x][p] = __builtin_bit_cast(bf16x8, smem[cur][1][p][ub[x]]);
+            for (int p = 0; p < NP; ++p) {
+                a[x][p] = smem[cur][0][p][ua[x]];
+                b[x][p] = smem[cur][1][p][ub[x]];
             }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 f32x16 acc = c[x][y];
-                if (g.nprod >= 6) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc, 0, 0, 0);   // m m'
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc, 0, 0, 0);   // h l'
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc, 0, 0, 0);   // l h'
+                if constexpr (NP == 3) {
+#define BF(v) __builtin_bit_cast(bf16x8, v)
+                    if (g.nprod >= 6) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][1]), BF(b[y][1]), acc, 0, 0, 0);   // m m'
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][0]), BF(b[y][2]), acc, 0, 0, 0);   // h l'
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][2]), BF(b[y][0]), acc, 0, 0, 0);   // l h'
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][0]), BF(b[y][1]), acc, 0, 0, 0);       // h m'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][1]), BF(b[y][0]), acc, 0, 0, 0);       // m h'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[x][0]), BF(b[y][0]), acc, 0, 0, 0);       // h h'
+#undef BF
+                } else {
+#define HF(v) __builtin_bit_cast(f16x8, v)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][0]), HF(b[y][1]), acc, 0, 0, 0);        // hi lo'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][1]), HF(b[y][0]), acc, 0, 0, 0);        // lo hi'
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][0]), HF(b[y][0]), acc, 0, 0, 0);        // hi hi'
+#undef HF
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc, 0, 0, 0);       // h m'
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc, 0, 0, 0);       // m h'
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc, 0, 0, 0);       // h h'
                 c[x][y] = acc;
             }
         if constexpr (!dma) { if (more) SSTORE(cur ^ 1); }
@@ -203,7 +253,11 @@ __global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
 #undef SLOAD
 #undef SSTORE
 #undef SDMA
-    const float alpha = g.alpha, beta = g.beta;
+    float alpha = g.alpha;
+    const float beta = g.beta;
+    if (g.ad0) { const float v = g.ad0[0]; for (int i = 0; i < g.pow0; ++i) alpha *= v; }
+    if (g.maxbits) alpha /= scale_from_maxbits(g.maxbits[0]);
+    if (g.maxbits2) alpha /= scale_from_maxbits(g.maxbits2[0]);
     const bool atomic = g.atomic != 0;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -234,12 +288,25 @@ __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, 
 
 size_t mxf_split_plane_elems(int64_t R, int64_t K) { return (size_t)((K + 15) / 16) * (size_t)R * 16; }
 
-int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st) {
+int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st) {
+    MXF_HIP(h, hipMemsetAsync(out, 0, sizeof(unsigned), st));
+    const int64_t n = R * K;
+    if (n <= 0) return 0;
+    int64_t nb = (n + 256 * 8 - 1) / (256 * 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(maxabs_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, K, ld, x, out);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
+int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st, int mode,
+                              const unsigned* maxbits) {
     if (R <= 0 || K <= 0) return 0;
     const int64_t pstride = (int64_t)mxf_split_plane_elems(R, K);
     dim3 grid((unsigned)((K + 63) / 64), (unsigned)((R + 63) / 64));
     if (grid.y > 65535u) MXF_FAIL(h, -3, "split planes: too many rows for one launch (%lld)", (long long)R);
-    hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, st, R, K, X, ld, planes, pstride);
+    if (mode == MXF_SPLIT_F16X2) hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, st, R, K, X, ld, planes, pstride, maxbits);
+    else hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, st, R, K, X, ld, planes, pstride, (const unsigned*)nullptr);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
@@ -248,9 +315,10 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 // [k0, k0+K) of a (R x Ktot) operand is the pointer planes + (k0 / 16) * R * 16 with the FULL operand's plane stride.
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
-                            int reserve_cus) {
+                            int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
+    g.ad0 = ad0; g.pow0 = pow0; g.maxbits = maxbits; g.maxbits2 = maxbits2;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
     g.pA = pA; g.pB = pB; g.ldc = ldc;
     g.alpha = (float)alpha; g.beta = (float)beta; g.lower_only = lower_only;
@@ -283,8 +351,14 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M);
         hipLaunchKernelGGL(split_scale_kernel, gs, dim3(256), 0, st, C, M, N, ldc, (float)beta, lower_only);
     }
-    if (g.use_dma && (M % SBM) == 0 && (N % SBN) == 0) hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
-    else hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    const bool dma = g.use_dma && (M % SBM) == 0 && (N % SBN) == 0;
+    if (mode == MXF_SPLIT_F16X2) {
+        if (dma) hipLaunchKernelGGL((gemm_split_kernel<true, 2>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<false, 2>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    } else {
+        if (dma) hipLaunchKernelGGL((gemm_split_kernel<true, 3>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<false, 3>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
+    }
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
@@ -307,6 +381,34 @@ extern "C" int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, dou
     rc = mxf_split_planes_internal(h, N, K, (const float*)B, ldb, pb, st);
     if (rc) return rc;
     return mxf_gemm_split_internal(h, M, N, K, alpha, pa, (int64_t)ea, pb, (int64_t)eb, beta, (float*)C, ldc, lower_only, st, 0);
+}
+
+// The same product from two scaled f16 terms per operand and three MFMA products (see the header of this file): each operand is scaled
+// by the power of two that puts its largest magnitude at [2^13, 2^14).  Normwise f32 accuracy; an element more than 2^18 below its
+// operand's maximum keeps fewer than 22 bits (absolute error <= 2^-39 of the maximum).
+extern "C" int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, double beta, void* C, int64_t ldc, int lower_only, void* stream) {
+    if (!h) return -1;
+    if (M <= 0 || N <= 0 || K <= 0) MXF_FAIL(h, -2, "mxf_gemm_f16x2: bad shape");
+    if (!A || !B || !C) MXF_FAIL(h, -2, "mxf_gemm_f16x2: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ea = mxf_split_plane_elems(M, K), eb = mxf_split_plane_elems(N, K);
+    const size_t need = mxf_align(2 * ea * 2) + mxf_align(2 * eb * 2) + mxf_align(2 * sizeof(unsigned));
+    char* ws = (char*)mxf_ws(h, need);
+    if (!ws) MXF_FAIL(h, -4, "mxf_gemm_f16x2: cannot allocate %zu bytes of scratch", need);
+    unsigned short* pa = (unsigned short*)ws;
+    unsigned short* pb = (unsigned short*)(ws + mxf_align(2 * ea * 2));
+    unsigned* mx = (unsigned*)(ws + mxf_align(2 * ea * 2) + mxf_align(2 * eb * 2));
+    int rc = mxf_maxabs_internal(h, M, K, (const float*)A, lda, mx, st);
+    if (rc) return rc;
+    rc = mxf_maxabs_internal(h, N, K, (const float*)B, ldb, mx + 1, st);
+    if (rc) return rc;
+    rc = mxf_split_planes_internal(h, M, K, (const float*)A, lda, pa, st, MXF_SPLIT_F16X2, mx);
+    if (rc) return rc;
+    rc = mxf_split_planes_internal(h, N, K, (const float*)B, ldb, pb, st, MXF_SPLIT_F16X2, mx + 1);
+    if (rc) return rc;
+    return mxf_gemm_split_internal(h, M, N, K, alpha, pa, (int64_t)ea, pb, (int64_t)eb, beta, (float*)C, ldc, lower_only, st, 0, MXF_SPLIT_F16X2,
+                                   nullptr, 0, mx, mx + 1);
 }
 
 // the two halves of mxf_gemm_f32x3 for callers that reuse split operands: planes = 3 * mxf_f32x3_plane_elems(R, K) bf16 (uint16) elements

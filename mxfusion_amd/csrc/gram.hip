@@ -13,6 +13,7 @@
 //     1 KiB of one output row per instruction (full-line, fully coalesced), non-temporal (written once,
 //     never re-read by this kernel).
 #include "common.h"
+#include "internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -283,7 +284,9 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
 // h + m + l (bf16 each) and writes ONE 16-byte unit per plane; a wave writes 1 KB contiguous per plane per k block.
 // HBM-write bound: 6 bytes per element (12.9 GB at M = 1024 x 2.1 M columns).
 typedef unsigned int gp_u32x4 __attribute__((ext_vector_type(4)));
-template <int QT, int KIND>
+// NP = 2 (f16x2 format of gemm_split.hip): the planes hold cov / variance * 2^14 as hi + lo (f16 each); the consumer multiplies by
+// variance * 2^-14 (unit-variance covariances are <= 1, so the format's power-of-two scale is known without a reduction).
+template <int QT, int KIND, int NP>
 __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                           const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
                                                           int chunks_per_block) {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
     const int tid = threadIdx.x, rl = tid >> 1, half = tid & 1;
     const int64_t r = (int64_t)blockIdx.x * 128 + rl;
     const bool rvalid = r < R;
-    const float variance = var[0];
+    const float variance = NP == 2 ? 16384.f : var[0];
     float z[QT];
 #pragma unroll
     for (int q = 0; q < QT; q += 4) *reinterpret_cast<f32x4_t*>(&z[q]) = *reinterpret_cast<const f32x4_t*>(Xmin_s + r * QT + q);   // padded
@@ -328,6 +331,13 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
                 unsigned hh = 0, mm = 0, ll = 0;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
+                    if (NP == 2) {
+                        const _Float16 fh = (_Float16)kv[e];
+                        const _Float16 fl = (_Float16)(kv[e] - (float)fh);
+                        hh |= (unsigned)__builtin_bit_cast(unsigned short, fh) << (16 * e);
+                        mm |= (unsigned)__builtin_bit_cast(unsigned short, fl) << (16 * e);
+                        continue;
+                    }
                     const __bf16 bh = (__bf16)kv[e];
                     const float r1 = kv[e] - (float)bh;
                     const __bf16 bm = (__bf16)r1;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
                 unsigned short* dst = P + ((kb0 + kbl) * R + r) * 16 + half * 8;
                 __builtin_nontemporal_store(uh, reinterpret_cast<gp_u32x4*>(dst));
                 __builtin_nontemporal_store(um, reinterpret_cast<gp_u32x4*>(dst + pstride));
-                __builtin_nontemporal_store(ul, reinterpret_cast<gp_u32x4*>(dst + 2 * pstride));
+                if (NP == 3) __builtin_nontemporal_store(ul, reinterpret_cast<gp_u32x4*>(dst + 2 * pstride));
             }
         }
     }
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
 
 template <int KIND>
 int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
-                     const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st) {
+                     const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode) {
     const int QT = Q <= 8 ? 8 : 16;
     const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
     float* buf = scratch;     // (padr + padk) * QT floats, caller-owned: two of these run concurrently on different streams
@@ -367,7 +377,10 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
                            (int64_t)0, ard, R, Q, padr, buf);                                                                         \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
                            (int64_t)0, ard, Kn, Q, padk, bmaj);                                                                       \
-        hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
+        if (mode == MXF_SPLIT_F16X2)                                                                                                  \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 3>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
     } while (0)
     if (QT == 8) GO(8); else GO(16);
 #undef GO
@@ -435,15 +448,15 @@ size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q) {
 }
 
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
-                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st) {
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode) {
     if (R <= 0 || Kn <= 0) return 0;
     if (!scratch) MXF_FAIL(h, -2, "gram planes: scratch of mxf_gram_planes_scratch_bytes() bytes required");
     if (Q > 16) MXF_FAIL(h, -3, "gram planes: Q > 16 not supported");
     switch (kind) {
-        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
-        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
-        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
-        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st);
+        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
+        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
+        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
+        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
     }
     MXF_FAIL(h, -2, "gram planes: stationary kernels only (kind %d)", kind);
 }

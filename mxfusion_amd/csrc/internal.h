@@ -27,10 +27,17 @@ int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int6
 
 // f32-accurate GEMM on the bf16 matrix pipe (three-term bf16 splitting, gemm_split.hip)
 size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE plane of an (R x K) operand
-int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st);
+// operand formats of the split GEMM (gemm_split.hip): three bf16 terms / two scaled f16 terms
+#define MXF_SPLIT_BF16X3 0
+#define MXF_SPLIT_F16X2 1
+int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st);   // out[0] = bit pattern of max |x|
+int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st,
+                              int mode = MXF_SPLIT_BF16X3, const unsigned* maxbits = nullptr);
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
-                            int reserve_cus = 0);
+                            int reserve_cus = 0, int mode = MXF_SPLIT_BF16X3, const float* ad0 = nullptr, int pow0 = 0,
+                            const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr);
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
-                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st);
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st,
+                             int mode = 0 /* MXF_SPLIT_BF16X3 */);

@@ -97,6 +97,21 @@ def gemm_f32x3(A, B, alpha=1.0, beta=0.0, out=None, lower_only=False):
     return out
 
 
+def gemm_f16x2(A, B, alpha=1.0, beta=0.0, out=None, lower_only=False):
+    """C = alpha A B^T + beta C for float32 A (M,K), B (N,K) on the f16 matrix pipe: two scaled f16 terms per operand, three products
+    (f32-equivalent normwise; half the matrix-pipe work of gemm_f32x3)."""
+    A, B = _c(A), _c(B)
+    if A.dtype != torch.float32 or B.dtype != torch.float32 or A.dim() != 2 or B.dim() != 2:
+        raise ValueError('gemm_f16x2: 2-D float32 operands')
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.zeros((M, N), dtype=A.dtype, device=A.device) if lower_only else torch.empty((M, N), dtype=A.dtype, device=A.device)
+    _lib.call('mxf_gemm_f16x2', _h(A), M, N, K, float(alpha), _p(A), A.stride(0), _p(B), B.stride(0), float(beta), _p(out), out.stride(0),
+              int(bool(lower_only)), _stream())
+    return out
+
+
 def f32x3_split(X):
     """Three-term bf16 split planes of a 2-D float32 matrix (operand format of gemm_f32x3_planes); returns an int16 tensor."""
     X = _c(X)

@@ -50,3 +50,39 @@ def test_gemm_f32x3_is_f32_accurate(M, N, K, lower):
     out = torch.full((M, N), 2.0, device='cuda')
     ops.gemm_f32x3_planes(ops.f32x3_split(A), ops.f32x3_split(B), M, N, K, alpha=0.5, beta=1.0, out=out)
     assert float(((out.double() - (0.5 * ref + 2.0)).abs() / (scale + 1.0)).max()) < 4e-7
+
+
+@pytest.mark.parametrize('M,N,K,lower', [(128, 128, 16, False), (256, 384, 1024, False), (130, 70, 50, False), (1, 5, 7, False),
+                                          (1024, 1024, 4096, True), (300, 300, 333, True), (512, 8192, 512, False)])
+@pytest.mark.parametrize('mag', [1.0, 3e-6, 7e5])
+def test_gemm_f16x2_is_f32_accurate(M, N, K, lower, mag):
+    """mxf_gemm_f16x2 (two power-of-two-scaled f16 terms per operand, three f16 MFMA products, f32 accumulate): error against float64
+    at the level of the f32-MFMA kernel for aligned, ragged, tiny, split-K and lower-only shapes, operands of both signs with a wide
+    dynamic range, and operand magnitudes far outside the f16 range (the per-operand scale comes from its max-abs word)."""
+    from mxfusion_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K)
+    A = (torch.rand(M, K, device='cuda', generator=g) * 2 - 0.7) * torch.exp(torch.randn(M, 1, device='cuda', generator=g)) * mag
+    B = torch.exp(-torch.rand(N, K, device='cuda', generator=g) * 8) * (torch.rand(N, K, device='cuda', generator=g) - 0.3) / mag ** 0.5
+    ref = A.double() @ B.double().T
+    C2 = ops.gemm_f16x2(A, B, lower_only=lower)
+    C1 = ops.gemm(A[None], B[None], transB=True)[0]
+    msk = torch.tril(torch.ones(M, N, device='cuda')) if lower else torch.ones(M, N, device='cuda')
+    scale = (A.double().abs() @ B.double().abs().T)
+    e2 = float((((C2.double() - ref).abs() / scale) * msk).max())
+    e1 = float((((C1.double() - ref).abs() / scale) * msk).max())
+    assert e2 < 6e-7, (e2, e1)                                              # 2^-22 per product at worst, a few f32 ulps of sum|a||b| in practice
+    assert e2 < 2.5 * e1 + 2e-7, (e2, e1)
+    if lower:
+        assert float((C2 * (1 - msk)).abs().max()) == 0.0
+    out = torch.full((M, N), 2.0, device='cuda') * float(scale.max())
+    out0 = out.clone()
+    ops.gemm_f16x2(A, B, alpha=0.5, beta=1.0, out=out, lower_only=lower)
+    # (split-K partial sums are added to the large beta * C term one by one: a few more f32 roundings of that term)
+    assert float((((out.double() - (0.5 * ref + out0.double())).abs() / (scale + out0.double().abs())) * msk).max()) < 2e-6
+
+
+def test_gemm_f16x2_zero_operand():
+    from mxfusion_amd import ops
+    A = torch.zeros(128, 64, device='cuda')
+    B = torch.randn(128, 64, device='cuda')
+    assert float(ops.gemm_f16x2(A, B).abs().max()) == 0.0
