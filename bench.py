@@ -346,8 +346,8 @@ def gram_roofline(N, Q, dtype, reps=10):
 
 
 def mfma_roofline(M, SB, dtype, reps=3):
-    """The dominant MFMA kernel of the step: T = H0 Kuf_all  (M x M x SB).  float32: gemm_split_kernel -- f32 operands split exactly
-    into three bf16 terms, six bf16 MFMA products, f32 accumulate (f32-equivalent accuracy); its peak is the dense bf16 MFMA peak / 6.
+    """The dominant MFMA kernel of the step: T = H0 Kuf_all  (M x M x SB).  float32: gemm_split_kernel -- f32 operands as two scaled f16
+    terms, three f16 MFMA products, f32 accumulate (f32-equivalent accuracy); its peak is the dense f16 MFMA peak / 3.
     float64: gemm_kernel on v_mfma_f64_16x16x4_f64."""
     from mxfusion_amd import ops
     fl = 2.0 * M * M * SB
@@ -355,12 +355,12 @@ def mfma_roofline(M, SB, dtype, reps=3):
     if dtype == 'float32':
         A = torch.randn(M, M, device='cuda')
         B = torch.rand(SB, M, device='cuda')
-        pa, pb = ops.f32x3_split(A), ops.f32x3_split(B)
+        pa, pb = ops.f16x2_split(A), ops.f16x2_split(B)
         del B
         out = torch.empty(M, SB, device='cuda')
-        run = lambda: ops.gemm_f32x3_planes(pa, pb, M, SB, M, out=out)
-        name, peak, extra = "gemm_split_kernel (f32 = 3 bf16 terms, 6 MFMA products) %dx%dx%d" % (M, SB, M), 2500.0 / 6.0, \
-            {"peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 products; the f32 MFMA peak is 157.3", "f32_mfma_peak": 157.3}
+        run = lambda: ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out)
+        name, peak, extra = "gemm_split_kernel<.., 2> (f32 = 2 scaled f16 terms, 3 MFMA products) %dx%dx%d" % (M, SB, M), 2500.0 / 3.0, \
+            {"peak_note": "dense f16 MFMA peak 2500 TFLOP/s / 3 products; the f32 MFMA peak is 157.3", "f32_mfma_peak": 157.3}
     else:
         A = torch.randn(1, M, M, device='cuda', dtype=torch.float64)
         B = torch.randn(1, M, SB, device='cuda', dtype=torch.float64)

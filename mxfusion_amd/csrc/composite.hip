@@ -653,9 +653,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         if (use_split) {
             if (KA > 0) {
-                // 3 workgroups of the split kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs
+                // 3 workgroups of the three-term kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs; the two-term
+                // kernel fits 4: (256 - 202) * 4 = 216
                 rc = mxf_gemm_split_internal(h, M, M, KA, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                             psi2_ra_env ? psi2_ra : 184, split_mode, split_var, 2, nullptr);
+                                             psi2_ra_env ? psi2_ra : (split_mode == MXF_SPLIT_F16X2 ? 202 : 184), split_mode, split_var, 2, nullptr);
                 if (rc) return rc;
             }
             if (KA < SB) {

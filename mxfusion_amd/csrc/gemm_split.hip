@@ -133,7 +133,7 @@ struct SplitArgs {
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
 
 template <bool DMA, int NP>
-__global__ __launch_bounds__(SNT, 3) void gemm_split_kernel(SplitArgs g) {
+__global__ __launch_bounds__(SNT, NP == 2 ? 4 : 3) void gemm_split_kernel(SplitArgs g) {
     __shared__ u32x4 smem[2][2][NP][256];   // [buffer][A|B][plane][unit]  (48 KB for three planes, 32 KB for two)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -330,7 +330,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
     const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     int splitk = 1;
-    const int64_t slots = (int64_t)(256 - reserve_cus) * 3;
+    const int64_t slots = (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
     if (tiles < slots && g.K16 >= 16) {
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
@@ -409,6 +409,25 @@ extern "C" int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, dou
     if (rc) return rc;
     return mxf_gemm_split_internal(h, M, N, K, alpha, pa, (int64_t)ea, pb, (int64_t)eb, beta, (float*)C, ldc, lower_only, st, 0, MXF_SPLIT_F16X2,
                                    nullptr, 0, mx, mx + 1);
+}
+
+// the two halves of mxf_gemm_f16x2 for callers that reuse split operands: planes = 2 * mxf_f32x3_plane_elems(R, K) 16-bit elements,
+// maxword = one 32-bit device word (bit pattern of max |X|, from which the operand's power-of-two scale is derived)
+extern "C" int mxf_f16x2_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* maxword, void* stream) {
+    if (!h) return -1;
+    if (R <= 0 || K <= 0 || !X || !planes || !maxword) MXF_FAIL(h, -2, "mxf_f16x2_split: bad argument");
+    int rc = mxf_maxabs_internal(h, R, K, (const float*)X, ld, (unsigned*)maxword, (hipStream_t)stream);
+    if (rc) return rc;
+    return mxf_split_planes_internal(h, R, K, (const float*)X, ld, (unsigned short*)planes, (hipStream_t)stream, MXF_SPLIT_F16X2, (const unsigned*)maxword);
+}
+
+extern "C" int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
+                                     const void* B_planes, const void* B_maxword, double beta, void* C, int64_t ldc, int lower_only, void* stream) {
+    if (!h) return -1;
+    if (M <= 0 || N <= 0 || K <= 0 || !A_planes || !B_planes || !A_maxword || !B_maxword || !C) MXF_FAIL(h, -2, "mxf_gemm_f16x2_planes: bad argument");
+    return mxf_gemm_split_internal(h, M, N, K, alpha, (const unsigned short*)A_planes, (int64_t)mxf_split_plane_elems(M, K),
+                                   (const unsigned short*)B_planes, (int64_t)mxf_split_plane_elems(N, K), beta, (float*)C, ldc, lower_only,
+                                   (hipStream_t)stream, 0, MXF_SPLIT_F16X2, nullptr, 0, (const unsigned*)A_maxword, (const unsigned*)B_maxword);
 }
 
 // the two halves of mxf_gemm_f32x3 for callers that reuse split operands: planes = 3 * mxf_f32x3_plane_elems(R, K) bf16 (uint16) elements

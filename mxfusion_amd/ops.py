@@ -112,6 +112,29 @@ def gemm_f16x2(A, B, alpha=1.0, beta=0.0, out=None, lower_only=False):
     return out
 
 
+def f16x2_split(X):
+    """The two scaled f16 planes of a 2-D float32 operand and its max-abs word (see gemm_f16x2_planes)."""
+    X = _c(X)
+    R, K = X.shape
+    if X.dtype != torch.float32 or X.dim() != 2:
+        raise ValueError('f16x2_split: 2-D float32 operand')
+    n = _lib.load().mxf_f32x3_plane_elems(R, K)
+    planes = torch.empty(2 * n, dtype=torch.int16, device=X.device)
+    word = torch.zeros(1, dtype=torch.int32, device=X.device)
+    _lib.call('mxf_f16x2_split', _h(X), R, K, _p(X), X.stride(0), _p(planes), _p(word), _stream())
+    return planes, word
+
+
+def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, lower_only=False):
+    """C = alpha A B^T + beta C from operands already split by f16x2_split (reuse across products)."""
+    (pa, wa), (pb, wb) = A_split, B_split
+    if out is None:
+        out = torch.zeros((M, N), dtype=torch.float32, device=pa.device) if lower_only else torch.empty((M, N), dtype=torch.float32, device=pa.device)
+    _lib.call('mxf_gemm_f16x2_planes', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), float(beta), _p(out), out.stride(0),
+              int(bool(lower_only)), _stream())
+    return out
+
+
 def f32x3_split(X):
     """Three-term bf16 split planes of a 2-D float32 matrix (operand format of gemm_f32x3_planes); returns an int16 tensor."""
     X = _c(X)

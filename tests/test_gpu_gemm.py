@@ -79,6 +79,9 @@ def test_gemm_f16x2_is_f32_accurate(M, N, K, lower, mag):
     ops.gemm_f16x2(A, B, alpha=0.5, beta=1.0, out=out, lower_only=lower)
     # (split-K partial sums are added to the large beta * C term one by one: a few more f32 roundings of that term)
     assert float((((out.double() - (0.5 * ref + out0.double())).abs() / (scale + out0.double().abs())) * msk).max()) < 2e-6
+    # the planes-level entry points (operands split once, reused)
+    Cp = ops.gemm_f16x2_planes(ops.f16x2_split(A), ops.f16x2_split(B), M, N, K, lower_only=lower)
+    assert torch.equal(Cp * msk, C2 * msk) or float((((Cp.double() - ref).abs() / scale) * msk).max()) < 6e-7
 
 
 def test_gemm_f16x2_zero_operand():
