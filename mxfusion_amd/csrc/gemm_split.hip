@@ -133,8 +133,12 @@ struct SplitArgs {
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
 
 template <bool DMA, int NP>
-__global__ __launch_bounds__(SNT, NP == 2 ? 4 : 3) void gemm_split_kernel(SplitArgs g) {
-    __shared__ u32x4 smem[2][2][NP][256];   // [buffer][A|B][plane][unit]  (48 KB for three planes, 32 KB for two)
+__global__ __launch_bounds__(SNT, (NP == 2 && !DMA) ? 4 : 3) void gemm_split_kernel(SplitArgs g) {
+    // [stage][A|B][plane][unit]: two stages of 24 KB for three planes; THREE stages of 16 KB for the two-plane LDS-DMA kernel, whose
+    // loads run two k blocks ahead of the MFMAs (one block ahead left the matrix pipe waiting for L2: 14.5 ms at the T shape, of which
+    // only 7 ms scale with the number of products)
+    constexpr int NST = (DMA && NP == 2) ? 3 : 2;
+    __shared__ u32x4 smem[NST][2][NP][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     int64_t wid = blockIdx.x;
@@ -204,7 +208,17 @@ __global__ __launch_bounds__(SNT, NP == 2 ? 4 : 3) void gemm_split_kernel(SplitA
         if constexpr (dma) SDMA(kbeg, 0);
         else { SLOAD(kbeg); SSTORE(0); }
     }
-    __syncthreads();
+    if constexpr (NST == 3) {
+        if (kbeg + 1 < kend) {
+            SDMA(kbeg + 1, 1);
+            __builtin_amdgcn_s_waitcnt(0xF70 | (2 * NP));       // vmcnt(2 NP): everything but the stage just issued has landed
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xF70);                  // vmcnt(0)
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
     const int li = lane & 31, lk = lane >> 5;
     int ua[2], ub[2];
 #pragma unroll
@@ -212,7 +226,11 @@ __global__ __launch_bounds__(SNT, NP == 2 ? 4 : 3) void gemm_split_kernel(SplitA
     int cur = 0;
     for (int64_t kb = kbeg; kb < kend; ++kb) {
         const bool more = kb + 1 < kend;
-        if (more) { if constexpr (dma) SDMA(kb + 1, cur ^ 1); else SLOAD(kb + 1); }
+        if constexpr (NST == 3) {
+            if (kb + 2 < kend) SDMA(kb + 2, (cur + 2) % 3);
+        } else {
+            if (more) { if constexpr (dma) SDMA(kb + 1, cur ^ 1); else SLOAD(kb + 1); }
+        }
         u32x4 a[2][NP], b[2][NP];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -239,16 +257,29 @@ __global__ __launch_bounds__(SNT, NP == 2 ? 4 : 3) void gemm_split_kernel(SplitA
 #undef BF
                 } else {
 #define HF(v) __builtin_bit_cast(f16x8, v)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][0]), HF(b[y][1]), acc, 0, 0, 0);        // hi lo'
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][1]), HF(b[y][0]), acc, 0, 0, 0);        // lo hi'
+                    if (g.nprod >= 3) {      // (MXF_SPLIT_NPROD=1: diagnostic only -- the kernel's time without the cross products)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][0]), HF(b[y][1]), acc, 0, 0, 0);    // hi lo'
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][1]), HF(b[y][0]), acc, 0, 0, 0);    // lo hi'
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a[x][0]), HF(b[y][0]), acc, 0, 0, 0);        // hi hi'
 #undef HF
                 }
                 c[x][y] = acc;
             }
-        if constexpr (!dma) { if (more) SSTORE(cur ^ 1); }
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NST == 3) {
+            // the next block's stage must have landed (this wave's share; the barrier extends that to the workgroup); the stage issued
+            // in this iteration (2 NP loads per lane) may stay in flight.  A bare s_barrier: __syncthreads() would wait for vmcnt(0).
+            asm volatile("" ::: "memory");
+            if (kb + 2 < kend) __builtin_amdgcn_s_waitcnt(0xF70 | (2 * NP));
+            else __builtin_amdgcn_s_waitcnt(0xF70);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur = cur == 2 ? 0 : cur + 1;
+        } else {
+            if constexpr (!dma) { if (more) SSTORE(cur ^ 1); }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 #undef SLOAD
 #undef SSTORE
