@@ -340,3 +340,29 @@ def test_svgp_split_path_training_call_is_graph_capturable():
     for key in ('logL', 'dX', 'dZ', 'dW', 'dls', 'dmu', 'dnoise', 'dSdiag', 'dvar'):
         a, b = ref[key].double().cpu().numpy(), out[key].double().cpu().numpy()
         assert np.allclose(a, b, rtol=2e-4, atol=2e-5 * max(1e-30, np.abs(a).max())), key      # f32 atomics: summation order differs run to run
+
+
+@pytest.mark.parametrize('var,noise,yscale', [(1e-3, 1e-4, 0.03), (60.0, 3.0, 8.0), (1.0, 0.05, 1.0)])
+def test_svgp_split_path_is_insensitive_to_the_problem_scale(var, noise, yscale):
+    """The f16x2 operand format of the float32 training step carries power-of-two scales (Gram planes hold k / variance * 2^14, H0's scale
+    comes from its max-abs word): kernel variances / noise levels / output scales far from 1 must give the same agreement with the
+    float64 step as the unit-scale problem."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(11)
+    S, B, M, Q, P = 2, 1024, 128, 4, 1
+    X = rng.uniform(-2, 2, (S, B, Q))
+    Y = yscale * (np.sin(X[0] @ rng.randn(Q, P)) + 0.1 * rng.randn(B, P))
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm, qW, qd = yscale * rng.randn(M, P) * 0.3, np.sqrt(var) * rng.randn(M, M) * 0.05, var * (rng.rand(M) + 0.5)
+    ls = (rng.rand(Q) * 0.3 + 0.5)
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        out[dt] = ops.svgp_logpdf('rbf', _dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(np.array([noise]), dt), _dev(qm, dt), _dev(qW, dt),
+                                  _dev(qd, dt), _dev(ls, dt), _dev(np.array([var]), dt), True, jitter=1e-6 * var, scaling=1.0, gscale=1.0 / S,
+                                  want_grad=True)
+        assert int(out[dt]['info'].abs().sum()) == 0
+    ref, got = out[torch.float64], out[torch.float32]
+    assert abs(float(got['logL'].double().mean() - ref['logL'].mean())) <= 1e-5 * abs(float(ref['logL'].mean()))
+    for key in ('dX', 'dZ', 'dW', 'dSdiag', 'dmu', 'dls', 'dvar', 'dnoise', 'dY'):
+        a, b = ref[key].double().cpu().numpy(), got[key].double().cpu().numpy()
+        assert np.linalg.norm(a - b) <= 5e-4 * np.linalg.norm(a), (key, np.linalg.norm(a - b) / np.linalg.norm(a))
