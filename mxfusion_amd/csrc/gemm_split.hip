@@ -107,13 +107,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int64_t R, int64_t K,
 
 // bit pattern of max |x| (non-negative floats order like unsigned integers); out must be zeroed
 __global__ __launch_bounds__(256) void maxabs_kernel(int64_t n, int64_t K, int64_t ld, const float* __restrict__ x, unsigned* __restrict__ out) {
+    __shared__ unsigned wm[4];
     unsigned m = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const unsigned b = __builtin_bit_cast(unsigned, x[(i / K) * ld + i % K]) & 0x7fffffffu;
         m = b > m ? b : m;
     }
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // one atomic per workgroup (same-address atomics serialise: 2048 of them took 27 us)
+        for (int w = 1; w < 4; ++w) m = wm[w] > m ? wm[w] : m;
+        atomicMax(out, m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the GEMM
@@ -323,8 +329,8 @@ int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_
     MXF_HIP(h, hipMemsetAsync(out, 0, sizeof(unsigned), st));
     const int64_t n = R * K;
     if (n <= 0) return 0;
-    int64_t nb = (n + 256 * 8 - 1) / (256 * 8);
-    if (nb > 1024) nb = 1024;
+    int64_t nb = (n + 256 * 16 - 1) / (256 * 16);
+    if (nb > 256) nb = 256;
     hipLaunchKernelGGL(maxabs_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, K, ld, x, out);
     MXF_LAUNCH_CHECK(h);
     return 0;
