@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void wt_kuf_kernel(int64_t M, int64_t SB, int 
             for (int v = 0; v < VEC; ++v) if (n0 + v < SB) U[(int64_t)p * SB + n0 + v] = acc[p][v];
 }
 
-// The same row block from the three-term bf16 planes of Kfu (operand (n, k = m), gemm_split.hip layout): U[p][n] = sum_m w[m][p] Kfu[n][m].
-// lane <-> column n (32 contiguous bytes per lane and plane per k block); HBM-read bound (6 bytes per element).
+// The same row block from the split planes of Kfu (operand (n, k = m), gemm_split.hip layout): U[p][n] = sum_m w[m][p] Kfu[n][m].
+// lane <-> column n (32 contiguous bytes per lane and plane per k block); HBM-read bound (4 bytes per element in the f16x2 format, 6 in bf16x3).
 // NP = 2: f16x2 planes holding k / variance * 2^14 (result scaled by variance * 2^-14).
 template <int PT, int NP>
 __global__ __launch_bounds__(256) void wt_planes_kernel(int64_t M, int64_t SB, int P, const unsigned short* __restrict__ pl, int64_t pstride,
@@ -546,7 +546,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB, sizeof(T));
-    // float32 streaming: the two big GEMMs run on the bf16 matrix pipe from three-term split planes of their operands (gemm_split.hip)
+    // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
     static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
     // operand format of the split GEMMs: two scaled f16 terms / three products (default) or three bf16 terms / six products
@@ -619,7 +619,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (use_mat) {
         MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
     } else if (use_split) {
-        // float32 training step: the Grams are written directly as three-term bf16 planes (6 bytes per element, never as f32):
+        // float32 training step: the Grams are written directly as split planes (two scaled f16 terms = 4 bytes per element, never as f32):
         // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
         // (n, k = m): T GEMM and the w^T Kuf row) are then written (HBM bound) on the second side stream NEXT TO Psi2.
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
@@ -644,7 +644,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (!use_split) MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf ready: the T GEMM waits for it
     if (want_grad && !het) {
         // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream,
-        // lower blocks only, split-K.  float32: from the bf16 planes of Kuf (gemm_split.hip); float64 / fallback: from the TRANSPOSED
+        // lower blocks only, split-K.  float32: from the split planes of Kuf (gemm_split.hip); float64 / fallback: from the TRANSPOSED
         // Gram Kfu (S*B x M, rows = contiguous lines) as a TN GEMM (the NT form on Kuf reads 256 K-strided streams per workgroup).
         // Two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
         // ~216 CUs, so that the core chains' f64 workgroups (a whole CU's LDS / registers each) still find free CUs; phase B (the rest)
@@ -728,7 +728,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
-    if (use_split)   // T = H0 Kuf = H0 Kfu^T on the bf16 pipe (f32-equivalent three-term splitting)
+    if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr);
     else

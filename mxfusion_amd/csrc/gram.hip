@@ -278,11 +278,11 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     return 0;
 }
 
-// ---- Gram matrix written as three-term bf16 split planes (the operand format of gemm_split.hip) ------------------------------------
+// ---- Gram matrix written as split planes (the operand formats of gemm_split.hip: NP = 3 bf16 terms, NP = 2 scaled f16 terms) ----------
 // operand element (r, k) = cov(xmin[r], xmaj[k]); plane p element (r, k) at ((k / 16) * R + r) * 16 + k % 16.
 // Thread <-> (minor index r, k half): per 16-wide k block a thread evaluates 8 covariances, splits each f32 value exactly into
 // h + m + l (bf16 each) and writes ONE 16-byte unit per plane; a wave writes 1 KB contiguous per plane per k block.
-// HBM-write bound: 6 bytes per element (12.9 GB at M = 1024 x 2.1 M columns).
+// HBM-write bound: 2 NP bytes per element (8.6 GB at M = 1024 x 2.1 M columns for NP = 2).
 typedef unsigned int gp_u32x4 __attribute__((ext_vector_type(4)));
 // NP = 2 (f16x2 format of gemm_split.hip): the planes hold cov / variance * 2^14 as hi + lo (f16 each); the consumer multiplies by
 // variance * 2^-14 (unit-variance covariances are <= 1, so the format's power-of-two scale is known without a reduction).
@@ -439,7 +439,7 @@ extern "C" int mxf_gram(mxf_handle h, int kind, int dtype, int S, int64_t N, int
     MXF_FAIL(h, -2, "mxf_gram: bad dtype %d", dtype);
 }
 
-// Gram matrix cov(xmin[r], xmaj[k]) (r < R, k < Kn) as three-term bf16 split planes (float32 inputs, stationary kernels); see
+// Gram matrix cov(xmin[r], xmaj[k]) (r < R, k < Kn) as split planes in either format (float32 inputs, stationary kernels); see
 // gram_planes_kernel.  planes: 3 * pstride elements, pstride = mxf_split_plane_elems(R, Kn).
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q) {
     const int QT = Q <= 8 ? 8 : 16;
