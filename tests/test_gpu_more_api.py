@@ -539,3 +539,26 @@ def test_with_samples_gp_and_sparse_gp(module, golden_dir):
     for v, ref in checks:
         o, n, _ = P._slices[v.uuid]
         assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), v
+
+
+def test_forward_sampling_wrapper_and_expectation_algorithm(golden_dir):
+    """ForwardSampling (forward_sampling.py:40-79) == TransferInference over ForwardSamplingAlgorithm; ExpectationAlgorithm
+    (expectation.py:24-60) == the mean over the sample axis of the same forward samples (injected noise)."""
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.inference import Inference, MAP, ForwardSampling, ExpectationAlgorithm, TransferInference
+    g = np.load(os.path.join(golden_dir, 'kat_gp.npz'))
+    rng = np.random.RandomState(3)
+    eps = rng.randn(4, 10, 2)
+    m = _gp_model(g, rand_gen=MockRandomGenerator(_t(eps)))
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(g['X']), Y=_t(g['Y']))
+    fs = ForwardSampling(num_samples=4, model=m, observed=[m.X], var_tie={}, infr_params=infr.params, target_variables=[m.Y], dtype=DT)
+    samples = fs.run(X=_t(g['X']))[0]
+    k = O.RBF(3, ARD=True)
+    kp = {'rbf_lengthscale': O.T(g['ls'])[None], 'rbf_variance': O.T(g['var'])[None]}
+    ref = O.gp_sample_prior(k, O.T(g['X'])[None], O.T(g['noise'])[None], kp, O.T(eps))
+    assert np.allclose(samples.cpu().numpy(), ref.numpy(), atol=1e-10)
+    m.Y.factor._rand_gen = MockRandomGenerator(_t(eps))
+    ex = TransferInference(ExpectationAlgorithm(model=m, observed=[m.X], num_samples=4, target_variables=[m.Y]), infr_params=infr.params, dtype=DT)
+    mean = ex.run(X=_t(g['X']))[0]
+    assert np.allclose(mean.cpu().numpy(), ref.numpy().mean(0), atol=1e-10)
