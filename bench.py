@@ -561,8 +561,9 @@ def main():
             mm, qq, ii, ll, qx = build(N, Q, M, 4, dname, X, Y, Z, False)
             qx._rand_gen = MockRandomGenerator(eps64.to(tdd))     # identical injected noise in both precisions
             ex = ii.create_executor()
-            with torch.no_grad():
-                vals[dname] = float(ex(torch.as_tensor(Y, dtype=tdd).cuda())[0])
+            # evaluated WITH the reverse mode requested: that is the call the timed step makes (float32: Grams as split planes, both big
+            # GEMMs on the f16 matrix pipe); the forward-only call would run the plain f32-MFMA kernels instead
+            vals[dname] = float(ex(torch.as_tensor(Y, dtype=tdd).cuda())[0].detach())
             del mm, qq, ii, ex
             torch.cuda.empty_cache()
         out["elbo_f32_vs_f64_rel"] = abs(vals['float32'] - vals['float64']) / abs(vals['float64'])
