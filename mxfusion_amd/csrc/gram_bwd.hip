@@ -37,7 +37,9 @@ struct GramBwdArgs {
 __device__ __forceinline__ void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__device__ __forceinline__ float expnp(float x) { return exp(x); }
+// e^x for x <= 0 as the hardware exp2 of x log2(e) (1 ulp of exp2 + the rounding of the product: relative error ~|x| 2^-24, the same
+// formulation -- and error level -- as the forward Gram kernels' exp2 of pre-scaled coordinates; the library exp costs ~15 instructions)
+__device__ __forceinline__ float expnp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ double expnp(double x) { return mxf_exp_nonpos_f64(x); }      // arguments here are never positive
 
 // unit-variance covariance k and slope dk/d(r2) (r2 in lengthscale-scaled coordinates)
