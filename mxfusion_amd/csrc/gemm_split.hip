@@ -367,8 +367,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
     const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     int splitk = 1;
-    // split-K target: 3 workgroups fit a CU; the two-plane kernels are split for 4/3 of that (shorter workgroups balance better against
-    // the Cholesky chains that share the chip with Psi2: 32.1 vs 32.4 ms per step than with exactly one wave of workgroups)
+    // split-K target: ~one wave of workgroups (3 fit a CU; 3 or 4 per CU measure the same per step, 6 and more are slower)
     const int64_t slots = (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
     if (tiles < slots && g.K16 >= 16) {
         int64_t sk = slots / tiles;
