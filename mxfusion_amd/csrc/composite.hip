@@ -584,10 +584,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
-    if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); } if (!het) CONV(1, noise, noised); CONV(MP, mu, mud); CONV(MM, W, Wd); CONV(M, sdiag, sd);
+    // (W and diag(s) are converted on the second side stream, where Su is formed: two launches less in front of the Kuu chain)
+    // (everything the Kuu chain does not need itself -- noise, mu, W, diag(s), the scalar accumulators -- is prepared on the second side
+    //  stream, where Su is formed; the main stream waits for that stream's ev_su before it first touches them)
+    if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
-    MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
-    MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), st));
     int rc;
     static const int64_t psi2_ka = getenv("MXF_SVGP_PSI2_KA") ? atoll(getenv("MXF_SVGP_PSI2_KA")) : -1;
     static const bool psi2_ra_env = getenv("MXF_SVGP_PSI2_RA") != nullptr;
@@ -609,6 +610,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));
     MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_fork, 0));
     // second side stream, first thing: Su (H0 on the critical path needs it; its Cholesky comes later and is off the critical path)
+    MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), s2_));
+    MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), s2_));
+    if (!het) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(1), dim3(256), 0, s2_, (int64_t)1, (int64_t)1, noise, (int64_t)1, noised, (int64_t)1);
+    hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MP)), dim3(256), 0, s2_, (int64_t)1, (int64_t)MP, mu, (int64_t)MP, mud, (int64_t)MP);
+    hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MM)), dim3(256), 0, s2_, (int64_t)1, (int64_t)MM, W, (int64_t)MM, Wd, (int64_t)MM);
+    hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(M)), dim3(256), 0, s2_, (int64_t)1, (int64_t)M, sdiag, (int64_t)M, sd, (int64_t)M);
     hipLaunchKernelGGL((diag_embed_kernel<D>), dim3(gridn(MM)), dim3(256), 0, s2_, M, (const D*)sd, Su);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
     if (rc) return rc;
@@ -688,6 +695,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
+    MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
