@@ -132,6 +132,12 @@ int mxf_trsm(mxf_handle h, int dtype, int transpose, int S, int64_t n, int64_t n
 int mxf_trtri(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t strideS_L,
               void* Linv, int64_t ldi, int64_t strideS_I, void* stream);
 
+/* make_diagonal custom operator (mxfusion/util/customop.py:22-81): out (batch, n, n) = diag-embed of a (batch, n); mxf_diag_of is its
+ * reverse mode, out (batch, n) = diagonal of g (batch, n, n) (customop.py:49-61).  Used for S = W W^T + make_diagonal(s)
+ * (svgp_regression.py:76, :145).                                                                                                    */
+int mxf_make_diagonal(mxf_handle h, int dtype, int64_t batch, int64_t n, const void* a, void* out, void* stream);
+int mxf_diag_of(mxf_handle h, int dtype, int64_t batch, int64_t n, const void* g, void* out, void* stream);
+
 /* out[s] = sum_i log|L_ii| -- linalg.sumlogdiag(abs(L)) (gp_regression.py:67)                       */
 int mxf_sumlogdiag(mxf_handle h, int dtype, int S, int64_t n, const void* L, int64_t ldl, int64_t strideS_L,
                    void* out, void* stream);

@@ -39,6 +39,8 @@ SIGNATURES = {
     'mxf_f32x3_split': [_i64, _i64, _vp, _i64, _vp, _vp],
     'mxf_gemm_f32x3_planes': [_i64, _i64, _i64, _d, _vp, _vp, _d, _vp, _i64, _i, _vp],
     'mxf_gemm_f32x3': [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i, _vp],
+    'mxf_make_diagonal': [_i, _i64, _i64, _vp, _vp, _vp],
+    'mxf_diag_of': [_i, _i64, _i64, _vp, _vp, _vp],
     'mxf_gemm_f16x2': [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i, _vp],
     'mxf_f16x2_split': [_i64, _i64, _vp, _i64, _vp, _vp, _vp],
     'mxf_gemm_f16x2_planes': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _d, _vp, _i64, _i, _vp],

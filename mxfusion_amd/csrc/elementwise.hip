@@ -134,6 +134,22 @@ __global__ __launch_bounds__(256) void coldot_small_kernel(int64_t M, int64_t N,
     }
 }
 
+// make_diagonal (util/customop.py:22-81): out[b][i][j] = (i == j) ? a[b][i] : 0; its reverse mode extracts the diagonal of the cotangent
+template <typename T>
+__global__ void make_diagonal_kernel(int64_t total, int64_t n, const T* __restrict__ a, T* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = e % n, i = (e / n) % n, b = e / (n * n);
+        out[e] = (i == j) ? a[b * n + i] : (T)0;
+    }
+}
+template <typename T>
+__global__ void diag_of_kernel(int64_t total, int64_t n, const T* __restrict__ g, T* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % n, b = e / n;
+        out[e] = g[(b * n + i) * n + i];
+    }
+}
+
 inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -229,4 +245,24 @@ extern "C" int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, 
     DISPATCH(h, dtype, "mxf_coldot",
              hipLaunchKernelGGL((coldot_kernel<float>), g, dim3(256), 0, st, M, N, (const float*)A, lda, strideS_A, (const float*)B, ldb, strideS_B, (float*)out),
              hipLaunchKernelGGL((coldot_kernel<double>), g, dim3(256), 0, st, M, N, (const double*)A, lda, strideS_A, (const double*)B, ldb, strideS_B, (double*)out));
+}
+
+extern "C" int mxf_make_diagonal(mxf_handle h, int dtype, int64_t batch, int64_t n, const void* a, void* out, void* stream) {
+    if (!h) return -1;
+    if (batch <= 0 || n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = batch * n * n;
+    DISPATCH(h, dtype, "mxf_make_diagonal",
+             hipLaunchKernelGGL((make_diagonal_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, total, n, (const float*)a, (float*)out),
+             hipLaunchKernelGGL((make_diagonal_kernel<double>), dim3(grid_for(total)), dim3(256), 0, st, total, n, (const double*)a, (double*)out));
+}
+
+extern "C" int mxf_diag_of(mxf_handle h, int dtype, int64_t batch, int64_t n, const void* g, void* out, void* stream) {
+    if (!h) return -1;
+    if (batch <= 0 || n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = batch * n;
+    DISPATCH(h, dtype, "mxf_diag_of",
+             hipLaunchKernelGGL((diag_of_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, total, n, (const float*)g, (float*)out),
+             hipLaunchKernelGGL((diag_of_kernel<double>), dim3(grid_for(total)), dim3(256), 0, st, total, n, (const double*)g, (double*)out));
 }

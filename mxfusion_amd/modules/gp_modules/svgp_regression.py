@@ -114,7 +114,7 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             fold = tuple(X.shape[:2])
             X = X.reshape(1, fold[0] * fold[1], X.shape[-1])
         with torch.no_grad():       # everything that does not depend on the test inputs
-            S = ops.gemm(S_W, S_W, transB=True) + torch.diag_embed(S_diag)                  # :145
+            S = ops.gemm(S_W, S_W, transB=True) + ops.make_diagonal(S_diag)                 # :145 make_diagonal
             Kuu = kern.K(F, Z, **kern_params).contiguous().clone()
             if self.jitter > 0.:
                 Kuu = Kuu + torch.eye(M, dtype=Z.dtype, device=Z.device) * self.jitter

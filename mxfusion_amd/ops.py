@@ -216,6 +216,26 @@ def sumlogdiag(L):
     return out
 
 
+def make_diagonal(a):
+    """(..., n) -> (..., n, n) diagonal embed (mxf_make_diagonal)."""
+    a = _c(a)
+    n = a.shape[-1]
+    batch = a.numel() // n if n else 0
+    out = torch.empty(tuple(a.shape) + (n,), dtype=a.dtype, device=a.device)
+    _lib.call('mxf_make_diagonal', _h(a), _dt(a), batch, n, _p(a), _p(out), _stream())
+    return out
+
+
+def diag_of(g):
+    """(..., n, n) -> (..., n) diagonal (mxf_diag_of)."""
+    g = _c(g)
+    n = g.shape[-1]
+    batch = g.numel() // (n * n) if n else 0
+    out = torch.empty(tuple(g.shape[:-1]), dtype=g.dtype, device=g.device)
+    _lib.call('mxf_diag_of', _h(g), _dt(g), batch, n, _p(g), _p(out), _stream())
+    return out
+
+
 def softplus(x):
     x = _c(x)
     y = torch.empty_like(x)
