@@ -376,6 +376,15 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 template <typename T>
 int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st) {
     if (info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
+    // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
+    // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
+    // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
+    static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
+    hipStream_t ax = look ? h->potrf_aux : st;
+    bool pending_b = false;
     for (int64_t c0 = 0; c0 < n; c0 += NBO) {
         const int64_t pe = (c0 + NBO < n) ? c0 + NBO : n;   // panel end
         for (int64_t j0 = c0; j0 < pe; j0 += NB) {
@@ -392,11 +401,32 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                                arrived);
         }
         if (pe < n) {   // trailing update, lower blocks only: A22 -= L21 L21^T with K = panel width
-            int rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe, n - pe, pe - c0, -1.0, A + pe * lda + c0, lda, sA,
-                                       A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
-            if (rc) return rc;
+            const int64_t pe2 = (pe + NBO < n) ? pe + NBO : n, K = pe - c0;
+            if (pending_b) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0)); pending_b = false; }   // the previous rest-update touched these columns
+            if (!look || pe2 >= n) {
+                int rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe, n - pe, K, -1.0, A + pe * lda + c0, lda, sA,
+                                           A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
+                if (rc) return rc;
+            } else {
+                MXF_HIP(h, hipEventRecord(h->ev_pa, st));                     // the panel's columns (L21) are final
+                // next outer panel's columns on the caller's stream: its diagonal block (lower) and the rows below it
+                int rc = mxf_gemm_internal(h, dtype, 0, 1, pe2 - pe, pe2 - pe, K, -1.0, A + pe * lda + c0, lda, sA,
+                                           A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
+                if (rc) return rc;
+                rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
+                                       A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, st);
+                if (rc) return rc;
+                // the rest on the auxiliary stream, next to the next panel's factorisation
+                MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_pa, 0));
+                rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, n - pe2, K, -1.0, A + pe2 * lda + c0, lda, sA,
+                                       A + pe2 * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe2, lda, sA, S, 1, ax);
+                if (rc) return rc;
+                MXF_HIP(h, hipEventRecord(h->ev_pb, ax));
+                pending_b = true;
+            }
         }
     }
+    if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
     if (n > 1) {
         if (n > 65535) MXF_FAIL(h, -3, "mxf_potrf: n too large");
         hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);

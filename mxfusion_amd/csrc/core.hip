@@ -28,6 +28,9 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ev_su) (void)hipEventDestroy(h->ev_su);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->potrf_aux) (void)hipStreamDestroy(h->potrf_aux);
+    if (h->ev_pa) (void)hipEventDestroy(h->ev_pa);
+    if (h->ev_pb) (void)hipEventDestroy(h->ev_pb);
     delete h;
     return 0;
 }
