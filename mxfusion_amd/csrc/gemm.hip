@@ -45,7 +45,8 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
     T alpha, beta;
     int splitk, lower_only, atomic, vecA, vecB;
-    int k_from_m;     // TN product of LOWER-TRIANGULAR operands (L^T L): output tile (m0, n0 <= m0) only needs k >= m0
+    int k_from_m;     // triangular op(A): 1 = op(A) upper triangular (A^T of a lower-triangular A): tile rows m0.. only need k >= m0;
+                      //                 2 = op(A) lower triangular (A itself, not transposed): they only need k < m0 + tile rows
     int64_t kchunk;
     int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
 };
@@ -255,8 +256,9 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
     T* __restrict__ C = g.C + (int64_t)batch * g.sC;
 
     int64_t kbeg = (int64_t)split * g.kchunk;
-    const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-    if (g.k_from_m) { const int64_t kf = m0 / BK * BK; if (kf > kbeg) kbeg = kf; }
+    int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m == 1) { const int64_t kf = m0 / BK * BK; if (kf > kbeg) kbeg = kf; }
+    if (g.k_from_m == 2) { const int64_t kl = m0 + BM; if (kl < kend) kend = kl; }
 
     Acc<T> acc;
     acc.zero();
@@ -338,8 +340,9 @@ __global__ __launch_bounds__(256) void gemm_small_f64_kernel(GemmArgs<double> g)
     const double* __restrict__ B = g.B + (int64_t)batch * g.sB;
     double* __restrict__ C = g.C + (int64_t)batch * g.sC;
     int64_t kbeg = (int64_t)split * g.kchunk;
-    const int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-    if (g.k_from_m) { const int64_t kf = m0 / SBK_ * SBK_; if (kf > kbeg) kbeg = kf; }
+    int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m == 1) { const int64_t kf = m0 / SBK_ * SBK_; if (kf > kbeg) kbeg = kf; }
+    if (g.k_from_m == 2) { const int64_t kl = m0 + 64; if (kl < kend) kend = kl; }
     f64x4 c[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -440,7 +443,7 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
                int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta, void* C, int64_t ldc, int64_t sC,
                int batch, int lower_only, hipStream_t st, int reserve_cus, int k_from_m) {
     GemmArgs<T> g;
-    g.k_from_m = (k_from_m && lower_only && ta && !tb) ? 1 : 0;
+    g.k_from_m = (k_from_m == 1 && ta) ? 1 : ((k_from_m == 2 && !ta) ? 2 : 0);     // the caller vouches for the triangular operand
     g.A = (const T*)A; g.B = (const T*)B; g.C = (T*)C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
     g.alpha = (T)alpha; g.beta = (T)beta; g.lower_only = lower_only;
