@@ -46,12 +46,19 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     const int tid = threadIdx.x, b = blockIdx.y;
     T* Ab = A + (int64_t)b * sA;
     T* D = Ab + k0 * lda + k0;
-    for (int e = tid; e < NB * NB; e += 128) {
-        const int i = e / NB, c = e % NB;
-        T v = (T)0;
-        if (i < nb && c < nb) { if (c <= i) v = D[(int64_t)i * lda + c]; }
-        else if (i == c) v = (T)1;          // identity padding of a ragged last block
-        a[i][c] = v;
+    {   // all 32 loads of a thread are issued before the first LDS store: one memory round trip instead of one per unrolled batch
+        // (timestamps: 11.5 us for this 32 KB block and 19 us for the 64 KB row tile below, of a 64 us panel step, before)
+        T va[NB * NB / 128];
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {
+            const int e = tid + it * 128, i = e / NB, c = e % NB;
+            T v = (T)0;
+            if (i < nb && c < nb) { if (c <= i) v = D[(int64_t)i * lda + c]; }
+            else if (i == c) v = (T)1;          // identity padding of a ragged last block
+            va[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) { const int e = tid + it * 128; a[e / NB][e % NB] = va[it]; }
     }
     __syncthreads();
     // Every workgroup re-factors the diagonal block from the UNFACTORED values in global memory, and workgroup 0 writes the factor back
@@ -152,9 +159,16 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     // rows below: X L11^T = A21, one row per lane
     const int64_t r0 = k0 + nb, nrows = n - r0;
     const int64_t rb = r0 + (int64_t)(blockIdx.x - 1) * 128;
-    for (int e = tid; e < 128 * NB; e += 128) {
-        const int r = e / NB, c = e % NB;
-        t[r][c] = (rb + r < r0 + nrows && c < nb) ? Ab[(rb + r) * lda + k0 + c] : (T)0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // two batches of 32 loads per thread, each issued back to back
+        T vt[NB / 2];
+#pragma unroll
+        for (int it = 0; it < NB / 2; ++it) {
+            const int e = tid + (half * (NB / 2) + it) * 128, r = e / NB, c = e % NB;
+            vt[it] = (rb + r < r0 + nrows && c < nb) ? Ab[(rb + r) * lda + k0 + c] : (T)0;
+        }
+#pragma unroll
+        for (int it = 0; it < NB / 2; ++it) { const int e = tid + (half * (NB / 2) + it) * 128; t[e / NB][e % NB] = vt[it]; }
     }
     __syncthreads();
     // Blocked substitution: 16 columns at a time by plain substitution (one row per lane, x[16] in registers), then the remaining columns of
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
             }
         }
     }
+#pragma unroll 8
     for (int e = tid; e < 128 * NB; e += 128) {
         const int r = e / NB, c = e % NB;
         if (rb + r < r0 + nrows && c < nb) Ab[(rb + r) * lda + k0 + c] = t[r][c];
