@@ -237,13 +237,19 @@ __global__ __launch_bounds__(256) void solve_cols_kernel(const T* __restrict__ L
     const int tid = threadIdx.x, b = blockIdx.y;
     const T* Lkk = L + (int64_t)b * sL + k0 * ldl + k0;
     T* Bk = B + (int64_t)b * sB + k0 * ldb;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, m = e % NB;
-        T v = (T)0;
-        if (i < nb && m < nb) {
-            if (m <= i) v = TRANS ? Lkk[(int64_t)(nb - 1 - m) * ldl + (nb - 1 - i)] : Lkk[(int64_t)i * ldl + m];
-        } else if (i == m) v = (T)1;
-        l[i][m] = v;
+    {   // 16 loads per thread, issued back to back before the LDS stores (see potrf_panel_kernel)
+        T vl[NB * NB / 256];
+#pragma unroll
+        for (int it = 0; it < NB * NB / 256; ++it) {
+            const int e = tid + it * 256, i = e / NB, m = e % NB;
+            T v = (T)0;
+            if (i < nb && m < nb) {
+                if (m <= i) v = TRANS ? Lkk[(int64_t)(nb - 1 - m) * ldl + (nb - 1 - i)] : Lkk[(int64_t)i * ldl + m];
+            } else if (i == m) v = (T)1;
+            vl[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NB * NB / 256; ++it) { const int e = tid + it * 256; l[e / NB][e % NB] = vl[it]; }
     }
     __syncthreads();
     const int64_t c = c0 + (int64_t)blockIdx.x * 256 + tid;
@@ -318,13 +324,23 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L,
     const int nb = (int)((k0 + NB < n) ? NB : n - k0);
     const T* Lkk = L + (int64_t)b * sL + k0 * ldl + k0;
     T* Ikk = Li + (int64_t)b * sI + k0 * ldi + k0;
-    for (int e = tid; e < NB * NB; e += 64) {
-        const int i = e / NB, m = e % NB;
-        T v = (T)0;
-        if (i < nb && m < nb) { if (m <= i) v = Lkk[(int64_t)i * ldl + m]; }
-        else if (i == m) v = (T)1;          // identity padding of a ragged last block
-        l[i][m] = v;
-        x[i][m] = (T)0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // 2 x 32 loads per lane, each batch issued back to back (see potrf_panel_kernel)
+        T vl[NB / 2];
+#pragma unroll
+        for (int it = 0; it < NB / 2; ++it) {
+            const int e = tid + (half * (NB / 2) + it) * 64, i = e / NB, m = e % NB;
+            T v = (T)0;
+            if (i < nb && m < nb) { if (m <= i) v = Lkk[(int64_t)i * ldl + m]; }
+            else if (i == m) v = (T)1;          // identity padding of a ragged last block
+            vl[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NB / 2; ++it) {
+            const int e = tid + (half * (NB / 2) + it) * 64;
+            l[e / NB][e % NB] = vl[it];
+            x[e / NB][e % NB] = (T)0;
+        }
     }
     __syncthreads();
     {   // 16 x 16 diagonal sub-blocks: lane group g = tid / 16 owns sub-block g, lane c = tid % 16 column c of its inverse
