@@ -350,20 +350,28 @@ __global__ __launch_bounds__(256) void gemm_small_f64_kernel(GemmArgs<double> g)
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[x][y][r] = 0.0;
-    // loaders: 64 x 16 elements per operand per k tile = 4 per thread; element (mn = tid & 63, k = (tid >> 6) + 4 j)
-    const int lmn = tid & 63, lk0 = tid >> 6;
+    // loaders: 64 x 16 elements per operand per k tile = 4 per thread.  An operand whose k index is the contiguous one in memory (A not
+    // transposed, B transposed) is read as 4 CONSECUTIVE k of one row per thread (mn = tid >> 2, k = 4 (tid & 3) + j): a wave instruction
+    // then touches 16 rows x 32 contiguous bytes instead of 64 rows x 8 bytes (the rows are lda apart: every lane its own cache line);
+    // the other layout (mn contiguous) keeps element (mn = tid & 63, k = (tid >> 6) + 4 j): 64 consecutive doubles per k.
+    const int lmn = tid & 63, lk0 = tid >> 6;          // mn-contiguous operands
+    const int qmn = tid >> 2, qk0 = (tid & 3) * 4;     // k-contiguous operands
     double ra[4], rb[4];
     auto load = [&](int64_t k0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t kk = k0 + lk0 + 4 * j, ia = m0 + lmn, ib = n0 + lmn;
-            ra[j] = (ia < g.M && kk < kend) ? (TA ? A[kk * g.lda + ia] : A[ia * g.lda + kk]) : 0.0;
-            rb[j] = (ib < g.N && kk < kend) ? (TB ? B[ib * g.ldb + kk] : B[kk * g.ldb + ib]) : 0.0;
+            if (TA) { const int64_t kk = k0 + lk0 + 4 * j, ia = m0 + lmn; ra[j] = (ia < g.M && kk < kend) ? A[kk * g.lda + ia] : 0.0; }
+            else { const int64_t kk = k0 + qk0 + j, ia = m0 + qmn; ra[j] = (ia < g.M && kk < kend) ? A[ia * g.lda + kk] : 0.0; }
+            if (TB) { const int64_t kk = k0 + qk0 + j, ib = n0 + qmn; rb[j] = (ib < g.N && kk < kend) ? B[ib * g.ldb + kk] : 0.0; }
+            else { const int64_t kk = k0 + lk0 + 4 * j, ib = n0 + lmn; rb[j] = (ib < g.N && kk < kend) ? B[kk * g.ldb + ib] : 0.0; }
         }
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sm[buf][0][(lk0 + 4 * j) * SLD_ + lmn] = ra[j]; sm[buf][1][(lk0 + 4 * j) * SLD_ + lmn] = rb[j]; }
+        for (int j = 0; j < 4; ++j) {
+            if (TA) sm[buf][0][(lk0 + 4 * j) * SLD_ + lmn] = ra[j]; else sm[buf][0][(qk0 + j) * SLD_ + qmn] = ra[j];
+            if (TB) sm[buf][1][(qk0 + j) * SLD_ + qmn] = rb[j]; else sm[buf][1][(lk0 + 4 * j) * SLD_ + lmn] = rb[j];
+        }
     };
     if (kbeg < kend) { load(kbeg); store(0); }
     __syncthreads();
