@@ -12,6 +12,7 @@
 // (dX / dZ, R) are wavefront-shuffle reduced per row and accumulated in an LDS band racc[RB][.] across all
 // the block's column tiles, so global atomics are RB*(Q+P) per block instead of per wave-row.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -300,7 +301,9 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     constexpr bool FUSED = PT > 0;
     constexpr int QA = QT + PT;
     const size_t fixed = (size_t)(TRB * QT + TRB * PT + 16) * sizeof(T) + 16 * sizeof(double) + 64;
-    const size_t budget = 80 * 1024;
+    // LDS per block (the row accumulators): 30 KB = five blocks per CU; 80 KB (two blocks, fewer row flushes) measured 1 % slower per step
+    static const int bud_env = getenv("MXF_BWD_LDS_KB") ? atoi(getenv("MXF_BWD_LDS_KB")) : 30;
+    const size_t budget = (size_t)bud_env * 1024;
     int64_t rb = (int64_t)((budget - fixed) / (QA * sizeof(T)));
     rb = rb / TRB * TRB;
     if (rb < TRB) rb = TRB;
