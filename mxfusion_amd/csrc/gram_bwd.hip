@@ -316,8 +316,9 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     a.RB = rb;
     const int64_t rblocks = (a.N + rb - 1) / rb;
     const int64_t tiles = (a.N2 + 255) / 256;
-    // enough blocks to fill the chip (~8 per CU) while keeping the per-block row flush amortised
-    int64_t ct = (tiles * rblocks * S + 2047) / 2048;
+    // enough blocks to fill the chip (~16 per CU at five resident blocks each) while keeping the per-block row flush amortised
+    static const int64_t gt_env = getenv("MXF_BWD_GRID") ? atoll(getenv("MXF_BWD_GRID")) : 4096;
+    int64_t ct = (tiles * rblocks * S + gt_env - 1) / gt_env;
     if (ct < 1) ct = 1;
     if (ct > 64) ct = 64;
     a.CT = (int)ct;
