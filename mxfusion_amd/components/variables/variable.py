@@ -65,6 +65,16 @@ class Variable(object):
             return VariableType.RANDVAR
         return VariableType.FUNCVAR
 
+    def replicate_self(self):
+        """variable.py:100-115: a copy that KEEPS the UUID (so the runtime `variables` dict entry is shared) but has no factor and no
+        graph -- how a module's internal graph refers to the outer model's variables."""
+        rep = Variable(shape=self.shape, transformation=self._transformation, isInherited=True, initial_value=self._initial_value)
+        rep.uuid = self.uuid
+        rep.name = self.name
+        rep.isConstant = self.isConstant
+        rep._value = self._value
+        return rep
+
     def assign_factor(self, factor):
         """q[v].assign_factor(PointMass / Normal ...) (map.py:56-59, meanfield.py:40-43)."""
         factor.set_single_output(self)

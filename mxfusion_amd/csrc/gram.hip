@@ -7,14 +7,15 @@
 // Layout / mapping (wave64):
 //   * a wave owns a strip of 64*VEC consecutive columns (VEC = 16 B / sizeof(T)): lane l keeps the
 //     VEC pre-scaled z-vectors of its columns in VGPRs for the whole row loop;
-//   * the block (4 waves side by side = 1024 f32 / 512 f64 columns) stages TR pre-scaled rows of X in LDS;
-//     every lane reads a row with broadcast ds_read_b128 (same address in all lanes: conflict free);
+//   * a workgroup is ONE wave (64 threads) covering 16 rows of its strip; the pre-scaled x row is the same for all lanes and comes
+//     through scalar loads (s_load_dwordx8/x16 into SGPRs, used directly as VOP3P sources): no LDS, no barrier;
 //   * each lane produces VEC outputs per row and stores them with ONE 16-byte store, so a wave writes
 //     1 KiB of one output row per instruction (full-line, fully coalesced), non-temporal (written once,
 //     never re-read by this kernel).
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -63,56 +64,69 @@ template <typename T, int KIND> __device__ __forceinline__ T cov_from(T red, T v
     return red;   // LINEAR: the dot product itself
 }
 
-template <typename T, int QT, int KIND>
-__global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
-    const int MODE = a.mode;
-    const bool VECST = a.vecst;
+// NW = waves per workgroup.  The x rows are read through wave-uniform (scalar) loads straight from the pre-scaled copy: no LDS, no
+// barrier, and with NW = 1 every wave is its own workgroup, dispatched and retired independently (measured on MI355X, f32 RBF N=65536:
+// 4-wave blocks with an LDS x tile 5.67 TB/s, 4-wave blocks with scalar x 5.86, single-wave blocks with scalar x 6.52 TB/s --
+// tests/probes/gram_variants.hip).
+// FAST: plain overwrite (MXF_WRITE), 16-byte-aligned rows and N2 a multiple of VEC -- every store is one full 16-byte store and the
+// accumulate / ragged-edge code (and its registers: 86 -> <= 64 VGPRs, i.e. 8 waves per SIMD) is compiled out.
+template <typename T, int QT, int KIND, int NW, bool FAST>
+__global__ __launch_bounds__(NW * 64) void gram_kernel(GramArgs<T> a, const T* __restrict__ Xs_all, const T* __restrict__ Zs_all,
+                                                       T* __restrict__ K_all) {
+    // (the three array pointers are separate __restrict__ kernel arguments: only then may the compiler read the x rows with SCALAR
+    //  loads -- a pointer inside the by-value struct could alias the output and would be fetched with per-lane vector loads)
+    const int MODE = FAST ? (int)MXF_WRITE : a.mode;
+    const bool VECST = FAST ? true : (bool)a.vecst;
     constexpr int VEC = Vec16<T>::n;
     typedef typename Vec16<T>::type V;
-    __shared__ __attribute__((aligned(16))) T xs[TR * QT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = NW == 1 ? 0 : tid >> 6;
     const int s = blockIdx.z;
     const int TRr = a.tr;                       // rows per block (<= TR)
     const int64_t row0 = (int64_t)(blockIdx.x / a.ncb) * TRr;
-    const int64_t col0 = ((int64_t)(blockIdx.x % a.ncb) * 4 + wave) * (64 * VEC) + (int64_t)lane * VEC;
+    const int64_t col0 = ((int64_t)(blockIdx.x % a.ncb) * NW + wave) * (64 * VEC) + (int64_t)lane * VEC;
+    if (col0 >= a.N2 || row0 >= a.N) return;
 
     const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : a.var[(int64_t)s * a.svar];
-    T* __restrict__ K = a.K + (int64_t)s * a.sK;
+    T* __restrict__ K = K_all + (int64_t)s * a.sK;
 
-    // prologue: unguarded 16-byte copies of the PRE-SCALED, zero-padded coordinates (prescale_kernel): the x tile of this
-    // block's rows into LDS, the VEC z-vectors of this lane's columns into VGPRs.
+    // prologue: unguarded 16-byte copies of the PRE-SCALED, zero-padded coordinates (prescale_kernel): the VEC z-vectors of this
+    // lane's columns into VGPRs.
     T z[VEC][QT];
+    const T* __restrict__ Xrows = nullptr;
     if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {
-        const T* __restrict__ Xs = a.Xs + (int64_t)s * a.sXs + row0 * QT;
-        for (int i = tid * VEC; i < TRr * QT; i += 256 * VEC)
-            *reinterpret_cast<V*>(&xs[i]) = *reinterpret_cast<const V*>(Xs + i);
-        const T* __restrict__ Zs = a.Zs + (int64_t)s * a.sZs + col0 * QT;
+        Xrows = Xs_all + (int64_t)s * a.sXs + row0 * QT;       // wave-uniform
+        const T* __restrict__ Zs = Zs_all + (int64_t)s * a.sZs + col0 * QT;
 #pragma unroll
         for (int i = 0; i < VEC * QT; i += VEC)
             *reinterpret_cast<V*>(&z[0][0] + i) = *reinterpret_cast<const V*>(Zs + i);
     }
-    __syncthreads();
-    if (col0 >= a.N2) return;
 
     const T dadd = a.square ? ((a.dadd ? a.dadd[(int64_t)s * a.sdadd] : (T)0) + a.jitter) : (T)0;
-    const bool full = VECST && (col0 + VEC <= a.N2);
-    const int64_t rmax = (a.N - row0) < TRr ? (a.N - row0) : TRr;
+    const bool full = FAST ? true : (VECST && (col0 + VEC <= a.N2));
+    // (an interleaved row assignment -- the NB workgroups that run side by side own every NB-th row of a band, so that the rows being
+    //  written at any moment are consecutive -- was measured: 6.4 -> 4.1-5.4 TB/s; rows per workgroup stay consecutive)
 
-#pragma unroll 2
-    for (int r = 0; r < rmax; ++r) {
+    // one row: kv = covariances of (row, col0 .. col0+VEC-1), then the store.  DIAG (the "+ noise / jitter on the diagonal" and the
+    // WHITE kernel) is a compile-time flag: only the few waves whose tile touches the diagonal run the variant with the compares.
+    // the "+ noise / jitter on the diagonal" and the WHITE kernel touch one element per row: a SCALAR test (is this row inside the
+    // wave's column range?) guards the per-lane compares, so the row loop carries no vector compare for them
+    const int64_t wcol0 = ((int64_t)(blockIdx.x % a.ncb) * NW + wave) * (64 * VEC);      // first column of the wave (wave-uniform)
+    const bool diag_possible = __builtin_amdgcn_readfirstlane((int)(a.square && (KIND == MXF_K_WHITE || dadd != (T)0))) != 0;
+    auto do_row = [&](int r) {
         const int64_t row = row0 + r;
+        const bool DIAG = diag_possible && (uint64_t)(row - wcol0) < (uint64_t)(64 * VEC);
         T kv[VEC];
         if (KIND == MXF_K_BIAS) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) kv[v] = variance;
         } else if (KIND == MXF_K_WHITE) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) kv[v] = (a.square && (col0 + v == row)) ? variance : (T)0;
+            for (int v = 0; v < VEC; ++v) kv[v] = (DIAG && (col0 + v == row)) ? variance : (T)0;
         } else {
             T x[QT];
 #pragma unroll
-            for (int q = 0; q < QT; ++q) x[q] = xs[r * QT + q];
+            for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];      // s_load: the address is the same in every lane
             if constexpr (sizeof(T) == 4 && KIND != MXF_K_LINEAR) {
                 // float: two outputs per v_pk_add_f32 / v_pk_fma_f32 (halves the VALU issue slots of the distance loop)
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
                 kv[v] = cov_from<T, KIND>(acc, variance);
             }
         }
-        if (dadd != (T)0) {
+        if (DIAG) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) if (col0 + v == row) kv[v] += dadd;
         }
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
             T* po = reinterpret_cast<T*>(&out);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) po[v] = kv[v];
-            if (MODE == MXF_WRITE && a.nt) __builtin_nontemporal_store(out, reinterpret_cast<V*>(dst));
+            if (MODE == MXF_WRITE && (FAST || a.nt)) __builtin_nontemporal_store(out, reinterpret_cast<V*>(dst));
             else *reinterpret_cast<V*>(dst) = out;
         } else {
 #pragma unroll
@@ -172,6 +186,96 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs<T> a) {
                 }
             }
         }
+    };
+    // number of this workgroup's rows that exist (wave-uniform)
+    const int rmax = (a.N - row0) < TRr ? (int)(a.N - row0) : TRr;
+#pragma unroll 2
+    for (int r = 0; r < rmax; ++r) do_row(r);
+}
+
+// The overwrite path (MXF_WRITE, aligned, N2 % VEC == 0) of the coordinate kernels as ONE-WAVE workgroups with a short argument list:
+// 5 pointers + 12 scalars instead of the 25-field GramArgs, whose lazily loaded fields put ~6 dependent s_load round trips in front
+// of a workgroup that lives for only 16 rows.
+// Grid: x = column block (fastest: neighbouring workgroups write neighbouring 1 KiB pieces of the same rows), y = row block, z = sample
+// -- no integer division in the prologue.  The diagonal term is branch-free, dadd = dscale * dadd_p[s] + jitter (the host passes
+// dscale = 0 and any valid pointer when there is none), so that all scalar loads of the prologue are issued back to back.
+template <typename T> struct GramLean {
+    int64_t N, N2, ldk, sXs, sZs, sK, svar, sdadd;
+    int tr, has_diag;
+    T dscale, jitter;
+};
+
+template <typename T, int QT, int KIND>
+__global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_all, const T* __restrict__ Zs_all, T* __restrict__ K_all,
+                                                       const T* __restrict__ var, const T* __restrict__ dadd_p, GramLean<T> a) {
+    constexpr int VEC = Vec16<T>::n;
+    typedef typename Vec16<T>::type V;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.z;
+    // (forcing the whole argument segment into SGPRs up front with an `asm volatile("" :: "s"(...))` makes the compiler fetch the x rows
+    //  with per-lane vector loads instead of s_loads: 6.4 -> 5.7 TB/s, tests/probes/gram_variants.hip "force")
+    const int64_t row0 = (int64_t)blockIdx.y * a.tr;
+    const int64_t wcol0 = (int64_t)blockIdx.x * (64 * VEC);       // first column of the wave
+    const int64_t col0 = wcol0 + (int64_t)lane * VEC;
+    const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : var[(int64_t)s * a.svar];
+    const T dadd = a.dscale * dadd_p[(int64_t)s * a.sdadd] + a.jitter;
+    if (col0 >= a.N2) return;
+    T z[VEC][QT];
+    {
+        const T* __restrict__ Zs = Zs_all + (int64_t)s * a.sZs + col0 * QT;
+#pragma unroll
+        for (int i = 0; i < VEC * QT; i += VEC)
+            *reinterpret_cast<V*>(&z[0][0] + i) = *reinterpret_cast<const V*>(Zs + i);
+    }
+    const T* __restrict__ Xrows = Xs_all + (int64_t)s * a.sXs + row0 * QT;       // wave-uniform: scalar loads
+    T* __restrict__ Krow = K_all + (int64_t)s * a.sK + row0 * a.ldk + col0;
+    const bool diag_possible = a.has_diag != 0;          // decided on the host: a diagonal term exists (its value may still be 0)
+    const int rmax = (a.N - row0) < a.tr ? (int)(a.N - row0) : a.tr;
+#pragma unroll 2
+    for (int r = 0; r < rmax; ++r) {
+        T x[QT];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];
+        T kv[VEC];
+        if constexpr (sizeof(T) == 4 && KIND != MXF_K_LINEAR) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int p = 0; p < VEC / 2; ++p) {
+                f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < QT; ++q) {
+                    const f32x2 xx = {(float)x[q], (float)x[q]};
+                    const f32x2 zz = {(float)z[2 * p][q], (float)z[2 * p + 1][q]};
+                    const f32x2 d = xx - zz;
+                    acc2 = __builtin_elementwise_fma(d, d, acc2);
+                }
+                kv[2 * p] = cov_from<T, KIND>((T)acc2.x, variance);
+                kv[2 * p + 1] = cov_from<T, KIND>((T)acc2.y, variance);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                T acc = 0;
+                if (KIND == MXF_K_LINEAR) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) acc = fma(x[q], z[v][q], acc);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) { T d = x[q] - z[v][q]; acc = fma(d, d, acc); }
+                }
+                kv[v] = cov_from<T, KIND>(acc, variance);
+            }
+        }
+        // "+ noise / jitter on the diagonal": a scalar test (is this row inside the wave's column range?) guards the per-lane compares
+        if (diag_possible && (uint64_t)(row0 + r - wcol0) < (uint64_t)(64 * VEC)) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) if (col0 + v == row0 + r) kv[v] += dadd;
+        }
+        V out;
+        T* po = reinterpret_cast<T*>(&out);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) po[v] = kv[v];
+        __builtin_nontemporal_store(out, reinterpret_cast<V*>(Krow + (int64_t)r * a.ldk));
     }
 }
 
@@ -235,14 +339,16 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
         return 0;
     }
     a.vecst = (a.ldk % VEC == 0) && (a.sK % VEC == 0) && (((uintptr_t)a.K) % 16 == 0);
-    {   // tuning knobs (debug / A-B probes only): rows per block and the store flavour
-        static const int tr_env = getenv("MXF_GRAM_TR") ? atoi(getenv("MXF_GRAM_TR")) : 0;
-        static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
-        // measured on MI355X (N=65536,Q=8): f32 RBF is fastest with 16-row blocks (5.38 vs 5.15 TB/s), the heavier epilogues with 64
-        a.tr = (tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((sizeof(T) == 4 && KIND == MXF_K_RBF) ? 16 : TR);
-        a.nt = (nt_env >= 0) ? nt_env : 1;
-    }
-    a.ncb = (unsigned)((a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC));
+    // tuning knobs (A/B probes): rows per block, waves per block, store flavour.  Defaults measured on MI355X at N=65536, Q=8
+    // (tests/probes/gram_variants.hip, tests/probes/gram_time.py): single-wave workgroups of 16 rows.
+    static const int tr_env = getenv("MXF_GRAM_TR") ? atoi(getenv("MXF_GRAM_TR")) : 0;
+    static const int nw_env = getenv("MXF_GRAM_NW") ? atoi(getenv("MXF_GRAM_NW")) : 0;
+    static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
+    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : 16;
+    a.nt = (nt_env >= 0) ? nt_env : 1;
+    const int NW = (nw_env == 1 || nw_env == 4) ? nw_env : 1;
+    const int64_t cw = (int64_t)NW * 64 * VEC;          // columns per workgroup
+    a.ncb = (unsigned)((a.N2 + cw - 1) / cw);
     const int64_t nblk = (int64_t)a.ncb * ((a.N + a.tr - 1) / a.tr);
     if (nblk > 2147483647LL) MXF_FAIL(h, -3, "mxf_gram: problem too large for one launch");
     dim3 g((unsigned)nblk, 1, (unsigned)S);
@@ -266,7 +372,21 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
                 a.Zs = bz; a.sZs = (Sz == 1) ? 0 : padc * QT;                                                         \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((gram_kernel<T, QT, KIND>), g, dim3(256), 0, st, a);                                       \
+        const bool fast = a.vecst && mode == MXF_WRITE && a.nt && (a.N2 % VEC == 0);                                  \
+        static const int lean_env = getenv("MXF_GRAM_LEAN") ? atoi(getenv("MXF_GRAM_LEAN")) : 1;                     \
+        if (NW == 1 && fast && lean_env && KIND != MXF_K_BIAS && KIND != MXF_K_WHITE && (a.N + a.tr - 1) / a.tr <= 65535) {                               \
+            GramLean<T> l;                                                                                            \
+            l.N = a.N; l.N2 = a.N2; l.ldk = a.ldk; l.sXs = a.sXs; l.sZs = a.sZs; l.sK = a.sK; l.svar = a.svar; l.tr = a.tr; \
+            const bool hd = a.square && a.dadd != nullptr;                                                            \
+            l.sdadd = hd ? a.sdadd : 0; l.dscale = hd ? (T)1 : (T)0; l.jitter = a.square ? a.jitter : (T)0;           \
+            l.has_diag = (hd || l.jitter != (T)0) ? 1 : 0;                                                            \
+            const T* dptr = hd ? a.dadd : (a.var ? a.var : a.Xs);          /* any readable word when there is no diagonal term */ \
+            dim3 gl(a.ncb, (unsigned)((a.N + a.tr - 1) / a.tr), (unsigned)S);                                         \
+            hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, l); \
+        } else if (NW == 1 && fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, true>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K); \
+        else if (NW == 1) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, false>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K);            \
+        else if (fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 4, true>), g, dim3(256), 0, st, a, a.Xs, a.Zs, a.K);               \
+        else hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 4, false>), g, dim3(256), 0, st, a, a.Xs, a.Zs, a.K);                        \
     } while (0)
     if (KIND == MXF_K_BIAS || KIND == MXF_K_WHITE) GO(2);
     else if (a.Q <= 2) GO(2);

@@ -2,6 +2,7 @@
 
   SparseGPRegressionLogPdf.compute                 -> mxf_sgp_logpdf (streaming Psi2 / psi1 statistics, C = Kuu + Psi2/s2, closed-form reverse mode)
   SparseGPRegressionMeanVariancePrediction.compute -> mxf_gram + mxf_trsm + mxf_gemm + mxf_coldot
+  SparseGPRegressionSamplingPrediction.compute     -> the same moments + mxf_potrf + mxf_gemm (trmm) on injected noise
 """
 from types import SimpleNamespace
 
@@ -13,7 +14,9 @@ from ...components.variables.variable import Variable
 from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
+from ...inference.forward_sampling import ForwardSamplingAlgorithm
 from ._fused import SGPLogPdfFn
+from ._sampling_graph import build_sparse_gp_sampling_model
 from ...components.distributions.gp import _linalg as lin
 from .gp_regression import _grad_mode
 
@@ -62,8 +65,8 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         self.noise_free = noise_free
         self.diagonal_variance = diagonal_variance
 
-    def compute(self, F, variables):
-        with _grad_mode(variables[self.model.X]):       # differentiable w.r.t. the test inputs (PILCO rollouts)
+    def _moments(self, F, variables, jitter=0.):
+        if True:
             X = variables[self.model.X]
             N = X.shape[-2]
             Z = variables[self.model.inducing_inputs]
@@ -101,10 +104,51 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
                 var = ops.gemm(LAinvLinvKxt, LAinvLinvKxt, transA=True, alpha=1.0, beta=1.0, out=var)
                 if not self.noise_free:
                     var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+        return mu, var
+
+    def compute(self, F, variables):
+        with _grad_mode(variables[self.model.X]):       # differentiable w.r.t. the test inputs (PILCO rollouts)
+            mu, var = self._moments(F, variables)
         outcomes = {self.model.Y.uuid: (mu, var)}
         if self.target_variables:
             return tuple(outcomes[v] for v in self.target_variables)
         return outcomes
+
+
+class SparseGPRegressionSamplingPrediction(SparseGPRegressionMeanVariancePrediction):
+    """sparsegp_regression.py:177-255: draws from the predictive distribution -- mu + eps sqrt(var) (diagonal) or mu + chol(cov + jitter I) eps."""
+
+    def __init__(self, model, posterior, observed, rand_gen=None, noise_free=True, diagonal_variance=True, jitter=0.):
+        super(SparseGPRegressionSamplingPrediction, self).__init__(model, posterior, observed, noise_free=noise_free,
+                                                                   diagonal_variance=diagonal_variance)
+        from ...components.distributions.random_gen import TorchRandomGenerator
+        self._rand_gen = TorchRandomGenerator if rand_gen is None else rand_gen
+        self.jitter = jitter
+
+    def compute(self, F, variables):
+        with _grad_mode(variables[self.model.X]):
+            if torch.is_grad_enabled() and not self.diagonal_variance:
+                raise NotImplementedError('SparseGPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
+                                          'test inputs here (it needs a reverse-mode Cholesky); use diagonal_variance=True')
+            mu, var = self._moments(F, variables)
+            out_shape = (self.num_samples,) + tuple(mu.shape[1:])
+            die = self._rand_gen.sample_normal(shape=out_shape, dtype=mu.dtype, ctx=mu.device)
+            if self.diagonal_variance:
+                samples = mu + die * torch.sqrt(var.unsqueeze(-1))                       # :228-234
+            else:
+                N = var.shape[-1]
+                cov = var
+                if self.jitter > 0.:                                                      # :241-242
+                    cov = cov + torch.eye(N, dtype=cov.dtype, device=cov.device).unsqueeze(0) * self.jitter
+                Lc, info = ops.potrf_(cov.contiguous().clone())
+                self._last_info = info
+                samples = mu + ops.gemm(Lc, die)                                          # trmm(L, die): L is lower with a zero upper part
+        outcomes = {self.model.Y.uuid: samples}
+        if self.target_variables:
+            return tuple(outcomes[v] for v in self.target_variables)
+        return outcomes
+
+
 
 
 class SparseGPRegression(Module):
@@ -157,6 +201,10 @@ class SparseGPRegression(Module):
                                        algorithm=SparseGPRegressionLogPdf(self._module_graph, self._extra_graphs[0], observed),
                                        alg_name='sgp_log_pdf')
         observed = [v for _, v in self.inputs]
+        # sparsegp_regression.py:374-378: draw_samples <- ForwardSamplingAlgorithm over the generative internal graph U -> F -> Y
+        self._sampling_graph = build_sparse_gp_sampling_model(self, 'sparsegp_regression')
+        self.attach_draw_samples_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                            algorithm=ForwardSamplingAlgorithm(self._sampling_graph, observed), alg_name='sgp_sampling')
         self.attach_prediction_algorithms(targets=self.output_names, conditionals=self.input_names,
                                           algorithm=SparseGPRegressionMeanVariancePrediction(self._module_graph, self._extra_graphs[0], observed),
                                           alg_name='sgp_predict')

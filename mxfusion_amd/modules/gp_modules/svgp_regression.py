@@ -15,7 +15,9 @@ from ...components.variables.var_trans import PositiveTransformation
 from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
+from ...inference.forward_sampling import ForwardSamplingAlgorithm
 from ._fused import SVGPLogPdfFn, SVGPMatLogPdfFn
+from ._sampling_graph import build_sparse_gp_sampling_model
 from ...components.distributions.gp import _linalg as lin
 from .gp_regression import _grad_mode
 
@@ -179,21 +181,15 @@ class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
             if torch.is_grad_enabled() and not self.diagonal_variance:
                 raise NotImplementedError('SVGPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
                                           'test inputs here; use diagonal_variance=True')
-            jit, self.jitter = self.jitter, 0.      # the reference adds `jitter` to the predictive covariance here (:268-270)
-            try:
-                mu, var = self._moments(F, variables)
-            finally:
-                self.jitter = jit
+            mu, var = self._moments(F, variables)      # `jitter` goes on Kuu (:236-238), as in the mean/variance algorithm
             out_shape = (self.num_samples,) + tuple(mu.shape[1:])
             die = self._rand_gen.sample_normal(shape=out_shape, dtype=mu.dtype, ctx=mu.device)
             if self.diagonal_variance:
                 samples = mu + die * torch.sqrt(var)
             else:
-                cov = var[..., 0]
-                N = cov.shape[-1]
-                if self.jitter > 0.:
-                    cov = cov + torch.eye(N, dtype=cov.dtype, device=cov.device).unsqueeze(0) * self.jitter
-                Lc, _ = ops.potrf_(cov.contiguous().clone())
+                cov = var[..., 0]                       # (:262-267: the reference adds no jitter to the predictive covariance)
+                Lc, info = ops.potrf_(cov.contiguous().clone())
+                self._last_info = info
                 samples = mu + ops.gemm(Lc, die)
         outcomes = {self.model.Y.uuid: samples}
         if self.target_variables:
@@ -250,6 +246,10 @@ class SVGPRegression(Module):
                                        algorithm=SVGPRegressionLogPdf(self._module_graph, self._extra_graphs[0], observed),
                                        alg_name='svgp_log_pdf')
         observed = [v for _, v in self.inputs]
+        # svgp_regression.py:399-403: draw_samples <- ForwardSamplingAlgorithm over the generative internal graph U -> F -> Y
+        self._sampling_graph = build_sparse_gp_sampling_model(self, 'sparsegp_regression')
+        self.attach_draw_samples_algorithms(targets=self.output_names, conditionals=self.input_names,
+                                            algorithm=ForwardSamplingAlgorithm(self._sampling_graph, observed), alg_name='svgp_sampling')
         self.attach_prediction_algorithms(targets=self.output_names, conditionals=self.input_names,
                                           algorithm=SVGPRegressionMeanVariancePrediction(self._module_graph, self._extra_graphs[0], observed),
                                           alg_name='svgp_predict')

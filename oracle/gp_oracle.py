@@ -527,6 +527,18 @@ def svgp_predict(kern, Xt, Z, noise_var, mu, S_W, S_diag, kern_params, jitter=0.
     return mu_t, var
 
 
+def svgp_predict_sample(kern, Xt, Z, noise_var, mu, S_W, S_diag, kern_params, eps, jitter=0., mean=None,
+                        noise_free=True, diagonal_variance=True):
+    """svgp_regression.py:203-280: the moments of :226-260 (jitter on Kuu, :236-238), then mu + eps sqrt(var) (:254-255) or
+    mu + chol(cov) eps (:262-272; no jitter on the predictive covariance); eps:(S,Nt,P)."""
+    mu_t, var = svgp_predict(kern, Xt, Z, noise_var, mu, S_W, S_diag, kern_params, jitter=jitter, mean=mean,
+                             noise_free=noise_free, diagonal_variance=diagonal_variance)
+    if diagonal_variance:
+        return mu_t + eps * torch.sqrt(var)
+    Lc = potrf(var[..., 0])
+    return mu_t + trmm(Lc.expand(eps.shape[0], -1, -1), eps)
+
+
 def svgp_log_pdf_suffstats(kern, X, Y, Z, noise_var, mu, S_W, S_diag, kern_params, jitter=0.,
                            log_pdf_scaling=1., mean=None):
     """SURVEY Appendix A.5 (NOT in the reference): the same bound written in the streaming
@@ -613,6 +625,30 @@ def sgp_predict(kern, Xt, Z, noise_var, L, LA, wv, kern_params, mean=None,
         if not noise_free:
             var = var + torch.eye(N, dtype=Xt.dtype).unsqueeze(0) * noise_var.unsqueeze(-2)
     return mu, var
+
+
+def sgp_predict_sample(kern, Xt, Z, noise_var, L, LA, wv, kern_params, eps, mean=None, noise_free=True,
+                       diagonal_variance=True, jitter=0.):
+    """sparsegp_regression.py:188-255: mu + eps sqrt(var) (:228-234) or mu + chol(cov + jitter I) eps (:236-249); eps:(S,Nt,P)."""
+    mu, var = sgp_predict(kern, Xt, Z, noise_var, L, LA, wv, kern_params, mean=mean, noise_free=noise_free,
+                          diagonal_variance=diagonal_variance)
+    if diagonal_variance:
+        return mu + eps * torch.sqrt(var.unsqueeze(-1))
+    N = Xt.shape[-2]
+    if jitter > 0.:
+        var = var + torch.eye(N, dtype=Xt.dtype).unsqueeze(0) * jitter
+    Lc = potrf(var)
+    return mu + trmm(Lc.expand(eps.shape[0], -1, -1), eps)
+
+
+def sparse_gp_forward_sample(kern, X, Z, noise_var, kern_params, eps_u, eps_f, eps_y, mean=None):
+    """The default draw_samples of SVGPRegression / SparseGPRegression: ForwardSamplingAlgorithm (forward_sampling.py:24-37 ->
+    factor_graph.py:240-297) over the module graph of svgp_regression.py:349-374 / sparsegp_regression.py:323-347:
+    U ~ GP(Z) (gp.py:124-153), F ~ GP(X | Z, U) (cond_gp.py:185-223), Y ~ N(F, noise_var) (normal.py:72-92).
+    eps_u:(S,M,P), eps_f, eps_y:(S,N,P), consumed in that order."""
+    U = gp_dist_draw(kern, Z, kern_params, eps_u)
+    Fv = cond_gp_dist_draw(kern, X, Z, U, kern_params, eps_f, mean=mean)
+    return normal_draw(Fv, noise_var.unsqueeze(-1) if noise_var.dim() == 2 else noise_var, eps_y), U, Fv
 
 
 # ----------------------------------------------------------------------------
@@ -715,6 +751,19 @@ def svi_latent_svgp_loss(kern, Y, Z, raw, eps, jitter=0., log_pdf_scaling=1.):
     return -(lp_prior + lp_svgp - lq)
 
 
+def map_svgp_loss(kern, X, Y, raw, jitter=0., log_pdf_scaling=1.):
+    """map.py:79-84 + inference_alg.py:75-83 for the SVGP model of examples/notebooks/svgp_regression.ipynb cell 9 (X, Y observed; the
+    module's hidden parameters qU_* and the inducing inputs are plain parameters, positive ones in softplus-raw space).
+    raw: Z, noise_var(raw), lengthscale(raw), variance(raw), qU_mean, qU_cov_W, qU_cov_diag(raw)."""
+    params = {kern.name + '_lengthscale': add_sample_dimension(softplus(raw['lengthscale'])),
+              kern.name + '_variance': add_sample_dimension(softplus(raw['variance']))}
+    logL = svgp_log_pdf(kern, add_sample_dimension(X), add_sample_dimension(Y), add_sample_dimension(raw['Z']),
+                        add_sample_dimension(softplus(raw['noise_var'])), add_sample_dimension(raw['qU_mean']),
+                        add_sample_dimension(raw['qU_cov_W']), add_sample_dimension(softplus(raw['qU_cov_diag'])), params, jitter=jitter,
+                        log_pdf_scaling=log_pdf_scaling)
+    return -factor_sum(logL)
+
+
 # ----------------------------------------------------------------------------
 # Optimiser: MXNet `adam` as driven by gluon.Trainer.step (batch_loop.py:46-60)
 # ----------------------------------------------------------------------------
@@ -784,3 +833,33 @@ def pilco_rollout(predict, policy, cost_function, s_0, n_time_steps):
         a_t = policy(s_next).reshape(S, 1, -1)
         x_t = torch.cat([s_next, a_t], dim=2)
     return torch.sum(cost)
+
+
+def run_svgp_notebook(X, Y, raw0, permutations, batch_size=10, phases=((50, 0.1), (50, 0.01)), jitter=1e-6):
+    """examples/notebooks/svgp_regression.ipynb cell 11: MAP on the SVGP model through MinibatchInferenceLoop(batch_size=10,
+    rv_scaling={Y: N/B}) (minibatch_loop.py:65-93: a fresh shuffled DataLoader and a fresh Adam per run() call, Trainer.step(batch_size=B),
+    last_batch='rollover'), 50 epochs at lr 0.1 then 50 at lr 0.01.  `permutations` yields one index permutation per epoch (the
+    DataLoader shuffle is MXNet-RNG dependent in the reference; injected here).  raw0: the initial raw parameters (see map_svgp_loss).
+    Returns the final raw parameters and the per-epoch mean losses."""
+    kern = RBF(X.shape[-1], ARD=False)          # RBF(input_dim=1, variance=1, lengthscale=1): ARD defaults to False (rbf.py:38)
+    N = X.shape[0]
+    raw = {k: v.clone() for k, v in raw0.items()}
+    perms = iter(permutations)
+    epoch_losses = []
+    for n_epochs, lr in phases:
+        opt = MXNetAdam(lr)
+        carry = torch.empty(0, dtype=torch.long)
+        for _ in range(n_epochs):
+            idx = torch.cat([carry, torch.as_tensor(next(perms), dtype=torch.long)])
+            n_full = idx.numel() // batch_size
+            tot = 0.
+            for i in range(n_full):
+                sel = idx[i * batch_size:(i + 1) * batch_size]
+                lv = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+                loss = map_svgp_loss(kern, X[sel], Y[sel], lv, jitter=jitter, log_pdf_scaling=N / batch_size)
+                loss.backward()
+                raw = opt.step({k: v.detach() for k, v in lv.items()}, {k: v.grad for k, v in lv.items()}, batch_size=batch_size)
+                tot += float(loss)
+            carry = idx[n_full * batch_size:]
+            epoch_losses.append(tot / max(n_full, 1))
+    return raw, epoch_losses
