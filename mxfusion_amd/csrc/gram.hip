@@ -344,7 +344,8 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     static const int tr_env = getenv("MXF_GRAM_TR") ? atoi(getenv("MXF_GRAM_TR")) : 0;
     static const int nw_env = getenv("MXF_GRAM_NW") ? atoi(getenv("MXF_GRAM_NW")) : 0;
     static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
-    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : 16;
+    // f32 RBF: 16 rows (6.05 TB/s; 32: 5.75, 64: 5.29, 8: 5.27); the VALU-heavier epilogues (Matern, all float64) prefer 64 (f64 RBF 5.25 vs 5.13)
+    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((sizeof(T) == 4 && KIND == MXF_K_RBF) ? 16 : 64);
     a.nt = (nt_env >= 0) ? nt_env : 1;
     const int NW = (nw_env == 1 || nw_env == 4) ? nw_env : 1;
     const int64_t cw = (int64_t)NW * 64 * VEC;          // columns per workgroup

@@ -5,7 +5,7 @@ from .variational import VariationalInference, StochasticVariationalInference  #
 from .map import MAP  # noqa: F401
 from .meanfield import create_Gaussian_meanfield  # noqa: F401
 from .batch_loop import BatchInferenceLoop, DistributedBatchInferenceLoop  # noqa: F401
-from .minibatch_loop import MinibatchInferenceLoop  # noqa: F401
+from .minibatch_loop import MinibatchInferenceLoop, DistributedMinibatchInferenceLoop  # noqa: F401
 from .prediction import ModulePredictionAlgorithm  # noqa: F401
 from .forward_sampling import ForwardSamplingAlgorithm, ForwardSampling  # noqa: F401
 from .expectation import ExpectationAlgorithm  # noqa: F401

@@ -20,7 +20,9 @@ class GradBasedInference(Inference):
         return self._inference_algorithm.create_executor(data_def=self.observed_variable_UUIDs, params=self.params,
                                                          var_ties=self.params.var_ties, rv_scaling=rv_scaling)
 
-    def run(self, optimizer='adam', learning_rate=1e-3, max_iter=2000, verbose=False, **kwargs):
+    def run(self, optimizer='adam', learning_rate=1e-3, max_iter=2000, verbose=False, permutations=None, generator=None, **kwargs):
+        """grad_based_inference.py:73-104.  `permutations` / `generator`: the minibatch loop's shuffle seam (one index sequence per epoch /
+        a torch.Generator for torch.randperm) -- the reference's DataLoader shuffle is MXNet-RNG driven."""
         data = [self._to_device(kwargs[v]) for v in self.observed_variable_names]
         self.initialize(**kwargs)
         infr = self.create_executor()
@@ -30,7 +32,7 @@ class GradBasedInference(Inference):
                 self.params.update_constants(discover_shape_constants(shapes, self._graphs))
             return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
                                        optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
-                                       update_shape_constants=update_shape_constants)
+                                       update_shape_constants=update_shape_constants, generator=generator, permutations=permutations)
         return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
                                    optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
 

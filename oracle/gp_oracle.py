@@ -764,6 +764,27 @@ def map_svgp_loss(kern, X, Y, raw, jitter=0., log_pdf_scaling=1.):
     return -factor_sum(logL)
 
 
+def svi_uncertain_input_svgp_loss(kern, Xobs, Y, raw, eps, prior_var=1e-2, jitter=0., log_pdf_scaling=1.):
+    """variational.py:91-108 on the minibatch-capable latent-input model (BASELINE.json configs[3]):
+        X ~ N(Xobs, prior_var) row-wise,  Y ~ SVGP(X),  q(X) = N(Xobs, softplus(qx_var)) with ONE shared variance parameter,
+    so that every factor is a sum over rows and a minibatch (rows of Xobs and Y) with rv_scaling = N/B on both X and Y is unbiased
+    (minibatch_loop.py:36-40 -> inference_alg.py:183-187 -> normal.py:70, svgp_regression.py:108).  eps:(S,B,Q) injected noise.
+    raw: qx_var(raw), noise_var(raw), lengthscale(raw), variance(raw), qU_mean, qU_cov_W, qU_cov_diag(raw), Z."""
+    Xo = add_sample_dimension(Xobs)
+    qv = softplus(raw['qx_var']).reshape(1, 1, 1)
+    Xs = normal_draw(Xo, qv, eps)
+    params = {kern.name + '_lengthscale': add_sample_dimension(softplus(raw['lengthscale'])),
+              kern.name + '_variance': add_sample_dimension(softplus(raw['variance']))}
+    pv = torch.full((1, 1, 1), float(prior_var), dtype=Xs.dtype)
+    lp_prior = factor_sum(normal_log_pdf(Xo, pv, Xs, log_pdf_scaling=log_pdf_scaling))
+    lp_svgp = factor_sum(svgp_log_pdf(
+        kern, Xs, add_sample_dimension(Y), add_sample_dimension(raw['Z']), add_sample_dimension(softplus(raw['noise_var'])),
+        add_sample_dimension(raw['qU_mean']), add_sample_dimension(raw['qU_cov_W']), add_sample_dimension(softplus(raw['qU_cov_diag'])),
+        params, jitter=jitter, log_pdf_scaling=log_pdf_scaling))
+    lq = factor_sum(normal_log_pdf(Xo, qv, Xs, log_pdf_scaling=log_pdf_scaling))
+    return -(lp_prior + lp_svgp - lq)
+
+
 # ----------------------------------------------------------------------------
 # Optimiser: MXNet `adam` as driven by gluon.Trainer.step (batch_loop.py:46-60)
 # ----------------------------------------------------------------------------

@@ -234,6 +234,11 @@ def reference_recorded():
         "gp_notebook_learned": {"variance": 0.616992, "lengthscale": 1.649073, "noise_var": 0.002251},  # cell 14
         "gp_notebook_gpy_optimum": {"objective": -16.903456670910902, "variance": 0.6148038604494702,
                                     "lengthscale": 1.6500299722611123, "noise_var": 0.002270049772204339},  # cell 16
+        # examples/notebooks/svgp_regression.ipynb: cell 13 output (the learned hyper-parameters after 50 epochs at lr 0.1 + 50 at 0.01,
+        # N=1000, M=20, minibatch 10) and the per-epoch mean losses printed by cell 11 (verbose=True); MXNet-RNG dependent (initial
+        # qU_*, DataLoader shuffles), so a BAND pin, not a bit pin
+        "svgp_notebook_learned": {"variance": 0.220715, "lengthscale": 0.498507, "noise_var": 0.003107},
+        "svgp_notebook_epoch_losses": {"phase1": [10413624.614005275, 686034.5295730559, 427065.8343717841, 297071.493696023, 219808.0871498559, 169486.20729875282, 134765.1471133905, 109798.66321648406, 91257.8705670977, 77084.06942481917, 65962.38163622493, 57037.39009905885, 49725.50869601666, 43635.70855486856, 38501.415430223606, 34139.30892930683, 30414.713307491817, 27222.957705478882, 24466.753696665117, 22063.866203795988, 19959.435781693166, 18093.70564938978, 16435.61461383947, 14947.197437326102, 13605.954880888436, 12393.880316263208, 11293.27810727986, 10292.698091923068, 9379.934609293405, 8542.778732654882, 7780.101399774407, 7083.3906599663305, 6442.360608787293, 5856.924952855579, 5319.662670742758, 4827.494923733251, 4375.152951451802, 3958.746627662967, 3574.2727718396727, 3216.389789008766, 2880.8040627817663, 2563.2893900928902, 2259.124250598867, 1963.4009524512699, 1683.301052960261, 1421.08925599032, 1181.4882875552755, 972.8920812023131, 794.3919410633861, 643.6129305537779], "phase2": [122.02590714978953, -861.8691127743712, -1142.8551043268158, -1248.3343954963652, -1319.0632400945233, -1375.485088640635, -1415.3387799226973, -1398.7259993571608, -1406.2506096944428, -1425.3786072098467, -1385.4821177117121, -1148.7904243974, -1248.4710558849933, -1302.58240646708, -1422.9290660653176, -1296.0532055882159, -1432.8777691683824, -1443.8657069101057, -1421.0467725977735, -1411.19388568273, -1427.8889874691674, -1379.492333117903, -1356.5797617962307, -1358.5256191991677, -1405.5467914984783, -1409.6484860247688, -1368.1521038967614, -1351.3528504368003, -1413.816013007459, -1426.6550440932342, -1356.5267725452202, -1425.2884165221458, -1420.5483351285052, -1430.2946033617723, -1380.3330104443605, -1399.0665992260174, -1360.9939473244767, -1419.1421503464217, -1415.0248356293594, -1398.6618957762776, -1402.3061839927834, -1425.2654433536431, -1384.815978968837, -1400.3690408109871, -1402.4205821010662, -1412.2783526889364, -1391.0496208478644, -1390.1175558545679, -1389.4460105298315, -1403.3841449208112]},
         "survey_kats": {"gp_loglik": -18.814420362103, "svgp_elbo": -32.725635407458,
                         "sgp_bound": -20.731336414403,
                         "svgp_pred_mu": [0.13216128, 0.01463357, 0.05120182, 0.42671159, 0.25158748],
@@ -246,11 +251,50 @@ def reference_recorded():
         json.dump(rec, f, indent=1)
 
 
+def svgp_notebook_setup(seed=2):
+    """Data, inducing inputs and run protocol of examples/notebooks/svgp_regression.ipynb cells 4, 9, 11.  Reproducible from NumPy: the
+    data (np.random.seed(0); uniform; randn), the default inducing inputs drawn by SVGPRegression.__init__ (svgp_regression.py:317-320)
+    and the randn(20, 1) cell 11 assigns.  NOT reproducible (MXNet RNG): the initial qU_mean / qU_cov_W / raw qU_cov_diag -- MXNet's
+    default initialiser Uniform(0.07) (inference_parameters.py:81-88 passes init=None) -- and the DataLoader shuffles; both are drawn
+    here from RandomState(seed) and injected through the product's seams."""
+    np.random.seed(0)
+    X = np.random.uniform(-3., 3., (1000, 1))
+    Y = np.sin(X) + np.random.randn(1000, 1) * 0.05
+    _ = np.random.randn(20, 1)
+    Z0 = np.random.randn(20, 1)
+    r = np.random.RandomState(seed)
+    U = lambda *sh: r.uniform(-0.07, 0.07, sh)
+    init = {'Z': Z0, 'noise_var': np.array([0.01]), 'lengthscale': np.array([1.0]), 'variance': np.array([1.0]),
+            'qU_mean': U(20, 1), 'qU_cov_W': U(20, 20), 'qU_cov_diag_raw': U(20)}
+    perms = [r.permutation(1000) for _ in range(100)]
+    return X, Y, init, perms
+
+
+def svgp_notebook_raw0(init):
+    return {'Z': T(init['Z']), 'noise_var': O.inv_softplus(T(init['noise_var'])), 'lengthscale': O.inv_softplus(T(init['lengthscale'])),
+            'variance': O.inv_softplus(T(init['variance'])), 'qU_mean': T(init['qU_mean']), 'qU_cov_W': T(init['qU_cov_W']),
+            'qU_cov_diag': T(init['qU_cov_diag_raw'])}
+
+
+def svgp_notebook():
+    """The oracle's run of the notebook protocol (about half a minute on one core): final parameters + per-epoch losses."""
+    X, Y, init, perms = svgp_notebook_setup()
+    raw, epoch_losses = O.run_svgp_notebook(T(X), T(Y), svgp_notebook_raw0(init), perms)
+    out = {k: v.numpy() for k, v in raw.items()}
+    out['epoch_losses'] = np.asarray(epoch_losses)
+    out['variance'] = O.softplus(raw['variance']).numpy()
+    out['lengthscale'] = O.softplus(raw['lengthscale']).numpy()
+    out['noise'] = O.softplus(raw['noise_var']).numpy()
+    out['full_batch_loss'] = float(O.map_svgp_loss(O.RBF(1), T(X), T(Y), raw, jitter=1e-6))
+    save('svgp_notebook_oracle', **out)
+
+
 if __name__ == '__main__':
     kat_gp()
     kat_svgp()
     kat_sgp()
     kat_kernels()
     kat_svi()
+    svgp_notebook()
     reference_recorded()
     print('golden fixtures written to', HERE)

@@ -90,3 +90,103 @@ def test_sharded_samples_allreduce_equals_unsharded():
     for rank, grad, mean_loss in outs:
         assert np.allclose(grad, ref_grad, rtol=1e-12, atol=1e-12), rank     # identical on every rank, equal to 1-process
         assert abs(mean_loss - ref_loss) < 1e-10 * abs(ref_loss)
+
+
+# ---- minibatches x sample sharding (BASELINE.json configs[3]): the PRODUCT loop (DistributedMinibatchInferenceLoop.run) end to end ------
+class _CpuAdam(object):
+    """MXNet Adam on the flat CPU leaf (the product's trainer is the HIP kernel mxf_adam_step; the loop's trainer seam swaps it here)."""
+
+    def __init__(self, params, lr):
+        self.p, self.opt, self.key = params, O.MXNetAdam(lr), 'flat'
+
+    def step(self, batch_size=1):
+        with torch.no_grad():
+            new = self.opt.step({self.key: self.p.flat.detach().clone()}, {self.key: self.p.flat.grad.clone()}, batch_size=batch_size)[self.key]
+            self.p.flat.data.copy_(new)
+        self.p.flat.grad = None
+
+
+def _mb_problem():
+    rng = np.random.RandomState(3)
+    N, Q, M, S, B = 24, 2, 4, 4, 8
+    X, Y = rng.rand(N, Q), rng.rand(N, 1)
+    eps = rng.randn(S, B, Q)               # reparameterisation noise of the uncertain inputs, one row block per minibatch position
+    sizes = dict(qx_var=(1,), noise_var=(1,), lengthscale=(Q,), variance=(1,), qU_mean=(M, 1), qU_cov_W=(M, M), qU_cov_diag=(M,), Z=(M, Q))
+    flat = torch.as_tensor(rng.randn(sum(int(np.prod(s)) for s in sizes.values())) * 0.3, dtype=torch.float64)
+    perms = [rng.permutation(N) for _ in range(3)]
+    return X, Y, eps, sizes, flat, perms, B
+
+
+def _mb_executor(eps, sizes, params, scaling, weight):
+    """SVI objective of the uncertain-input SVGP (inputs X ~ N(Xobs, 0.01), q(X) = N(Xobs, softplus(qx_var))) on one minibatch, for the
+    MC samples given by `eps`, weighted `weight` (= 1 / world for a shard)."""
+    k = O.RBF(2, ARD=True)
+    sp = O.softplus
+
+    def run(Xb, Yb):
+        raw, off = {}, 0
+        for n, shp in sizes.items():
+            cnt = int(np.prod(shp))
+            raw[n] = params.flat[off:off + cnt].view(shp)
+            off += cnt
+        qv = sp(raw['qx_var']).reshape(1, 1, 1)
+        Xs = O.normal_draw(Xb[None], qv, O.T(eps))
+        kp = {'rbf_lengthscale': sp(raw['lengthscale'])[None], 'rbf_variance': sp(raw['variance'])[None]}
+        lp = O.factor_sum(O.svgp_log_pdf(k, Xs, Yb[None], raw['Z'][None], sp(raw['noise_var'])[None], raw['qU_mean'][None], raw['qU_cov_W'][None],
+                                        sp(raw['qU_cov_diag'])[None], kp, jitter=1e-6, log_pdf_scaling=scaling))
+        lpx = O.factor_sum(O.normal_log_pdf(Xb[None], torch.full((1, 1, 1), 0.01, dtype=Xs.dtype), Xs, log_pdf_scaling=scaling))
+        lq = O.factor_sum(O.normal_log_pdf(Xb[None], qv, Xs, log_pdf_scaling=scaling))
+        loss = -(lp + lpx - lq) * weight
+        return loss, loss
+    return run
+
+
+def _mb_loop_cls():
+    from mxfusion_amd.inference import DistributedMinibatchInferenceLoop
+
+    class Loop(DistributedMinibatchInferenceLoop):
+        def _make_trainer(self, param_dict, learning_rate, optimizer):
+            return _CpuAdam(param_dict, learning_rate)
+    return Loop
+
+
+def _mb_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    X, Y, eps, sizes, flat, perms, B = _mb_problem()
+    S = eps.shape[0]
+    shard = eps[rank * (S // world):(rank + 1) * (S // world)]
+    # rank 1 starts from DIFFERENT parameters and would draw DIFFERENT shuffles: the loop must broadcast both from rank 0
+    params = _Params(flat + (0.5 if rank == 1 else 0.0))
+    loop = _mb_loop_cls()(batch_size=B)
+    my_perms = perms if rank == 0 else [p[::-1].copy() for p in perms]
+    loop.run(_mb_executor(shard, sizes, params, X.shape[0] / B, 1.0), [O.T(X), O.T(Y)], params, None, learning_rate=0.05, max_iter=3,
+             permutations=my_perms)
+    q.put((rank, params.flat.detach().clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_distributed_minibatch_loop_equals_the_single_process_loop():
+    """3 epochs x 3 minibatches of 8 rows, 4 MC samples: 2 ranks x 2 samples through DistributedMinibatchInferenceLoop.run == 1 process with
+    all 4 samples through the same loop -- parameters after 9 Adam steps agree to 1e-10 on every rank."""
+    X, Y, eps, sizes, flat, perms, B = _mb_problem()
+    params = _Params(flat)
+    loop = _mb_loop_cls()(batch_size=B)
+    loop.run(_mb_executor(eps, sizes, params, X.shape[0] / B, 1.0), [O.T(X), O.T(Y)], params, None, learning_rate=0.05, max_iter=3,
+             permutations=perms)
+    ref = params.flat.detach().numpy()
+    assert np.abs(ref - flat.numpy()).max() > 1e-2          # the optimiser moved
+
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got in outs:
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-10), (rank, np.abs(got - ref).max())

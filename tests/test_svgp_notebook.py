@@ -1,0 +1,119 @@
+"""The only SVGP output the reference holds: examples/notebooks/svgp_regression.ipynb (N=1000, M=20, minibatch 10, 50 epochs at lr 0.1 +
+50 at 0.01) prints the learned hyper-parameters 0.220715 / 0.498507 / 0.003107 (cell 13) and 100 per-epoch mean losses (cell 11).
+
+The run depends on MXNet's RNG (initial qU_* ~ Uniform(0.07), DataLoader shuffles) and on notebook execution history, so it cannot be
+reproduced bit for bit; it pins the SVGP rows (a10, a19, a20 minibatch loop, rv_scaling, Trainer.step(batch_size)) as a BAND:
+
+  * CPU leg (`not gpu`): the oracle re-runs the notebook protocol (tests/golden/make_golden.py::svgp_notebook_setup: the NumPy-reproducible
+    data and inducing inputs, injected initial values and shuffles) and must (i) reproduce the committed fixture, (ii) end inside the band
+    around the notebook's printed parameters and (iii) end on the notebook's loss plateau.
+  * GPU leg (`gpu`): the same protocol through mxfusion_amd (GradBasedInference(MAP) + MinibatchInferenceLoop, 10 000 minibatch steps on
+    the HIP path) must follow the oracle's trajectory and end in the same band.
+
+Band (stated, not derived from the reference): three RNG streams of the same protocol through the oracle end at variance 0.155 / 0.198 /
+0.215, length-scale 0.650 / 0.543 / 0.540, noise 0.00329 / 0.00311 / 0.00335 (notebook: 0.2207 / 0.4985 / 0.00311), i.e. the notebook's
+numbers are SGD iterates, not an optimum: L-BFGS on the full-batch bound from that end point keeps moving to variance > 0.44,
+length-scale > 1.3, noise 0.0023.  Accepted: variance within x/ 2, length-scale within x/ 1.5, noise within x/ 1.3 of the notebook's values; mean
+loss of the last 10 epochs within 3 % of the notebook's (-1397)."""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _band_ok(variance, lengthscale, noise, rec):
+    nb = rec['svgp_notebook_learned']
+    return (nb['variance'] / 2 <= variance <= nb['variance'] * 2 and nb['lengthscale'] / 1.5 <= lengthscale <= nb['lengthscale'] * 1.5
+            and nb['noise_var'] / 1.3 <= noise <= nb['noise_var'] * 1.3)
+
+
+def _recorded(golden_dir):
+    with open(os.path.join(golden_dir, 'reference_recorded.json')) as f:
+        return json.load(f)
+
+
+def test_oracle_lands_in_the_band_of_the_reference_svgp_notebook(golden_dir):
+    import make_golden as G
+    rec = _recorded(golden_dir)
+    fx = np.load(os.path.join(golden_dir, 'svgp_notebook_oracle.npz'))
+    X, Y, init, perms = G.svgp_notebook_setup()
+    torch.set_num_threads(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        raw, epoch_losses = O.run_svgp_notebook(O.T(X), O.T(Y), G.svgp_notebook_raw0(init), perms)
+    var, ls, noise = (float(O.softplus(raw[k])) for k in ('variance', 'lengthscale', 'noise_var'))
+    # (i) the committed fixture is what the oracle produces
+    assert np.allclose(np.asarray(epoch_losses), fx['epoch_losses'], rtol=1e-6, atol=1e-6)
+    assert np.allclose([var, ls, noise], [float(fx['variance']), float(fx['lengthscale']), float(fx['noise'])], rtol=1e-6)
+    # (ii) the band around the numbers the notebook printed
+    assert _band_ok(var, ls, noise, rec), (var, ls, noise)
+    # (iii) the plateau: mean loss of the last 10 epochs vs the notebook's
+    nb_tail = np.mean(rec['svgp_notebook_epoch_losses']['phase2'][-10:])
+    assert abs(np.mean(epoch_losses[-10:]) - nb_tail) <= 0.03 * abs(nb_tail), (np.mean(epoch_losses[-10:]), nb_tail)
+    # the transient stays within an order of magnitude of the notebook's at every epoch of the first phase (both decay 1e7 -> 5e2)
+    nb1 = np.asarray(rec['svgp_notebook_epoch_losses']['phase1'])
+    assert np.all(np.abs(np.log10(np.asarray(epoch_losses[:50]) / nb1)) < 1.0)
+
+
+@pytest.mark.gpu
+def test_hip_path_follows_the_oracle_on_the_svgp_notebook_protocol(golden_dir):
+    import make_golden as G
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, MinibatchInferenceLoop
+    rec = _recorded(golden_dir)
+    fx = np.load(os.path.join(golden_dir, 'svgp_notebook_oracle.npz'))
+    X, Y, init, perms = G.svgp_notebook_setup()
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64).cuda()
+    # cells 9 and 11 of the notebook, verbatim up to the array type
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 1))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.kernel = RBF(input_dim=1, variance=1, lengthscale=1, dtype='float64')
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, shape=(m.N, 1), num_inducing=20, dtype='float64')
+    m.Y.factor.svgp_log_pdf.jitter = 1e-6
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]),
+                              grad_loop=MinibatchInferenceLoop(batch_size=10, rv_scaling={m.Y: 1000 / 10}), dtype='float64')
+    infr.initialize(X=(1000, 1), Y=(1000, 1))
+    gp = m.Y.factor
+    post = gp._extra_graphs[0]
+    infr.params[gp.inducing_inputs] = t(init['Z'])
+    infr.params[post.qU_mean] = t(init['qU_mean'])
+    infr.params[post.qU_cov_W] = t(init['qU_cov_W'])
+    infr.params[post.qU_cov_diag] = torch.nn.functional.softplus(t(init['qU_cov_diag_raw']))      # params[...] takes constrained values
+    losses = []
+    loop = infr._grad_loop
+    step0 = loop.step
+
+    def rec_step(*a, **k):
+        out = step0(*a, **k)
+        losses.append(out.detach())
+        return out
+    loop.step = rec_step
+    infr.run(X=t(X), Y=t(Y), max_iter=50, learning_rate=0.1, permutations=perms[:50])
+    infr.run(X=t(X), Y=t(Y), max_iter=50, learning_rate=0.01, permutations=perms[50:])
+    ep = torch.stack(losses).reshape(100, 100).mean(1).cpu().numpy()
+    var, ls, noise = (float(infr.params[v]) for v in (m.kernel.variance, m.kernel.lengthscale, m.noise_var))
+    assert int(gp.svgp_log_pdf._last_info.abs().sum()) == 0
+    # the HIP path follows the oracle's trajectory (same initial values, same shuffles; float64 on both sides): the first epochs
+    # tightly; later the two runs separate slowly -- the transient runs at cond(Kuu + 1e-6 I) ~ 1e12 (20 inducing points on a line,
+    # length-scale 1) and 10 000 Adam steps amplify last-bit differences -- but they stay on the same path and end together
+    assert np.allclose(ep[:3], fx['epoch_losses'][:3], rtol=1e-6), (ep[:3], fx['epoch_losses'][:3])
+    assert np.allclose(ep, fx['epoch_losses'], rtol=0.15, atol=30.0), np.abs(ep - fx['epoch_losses']).max()
+    assert np.allclose([var, ls, noise], [float(fx['variance']), float(fx['lengthscale']), float(fx['noise'])], rtol=0.05), (var, ls, noise)
+    # and ends in the band of the numbers the reference notebook printed
+    assert _band_ok(var, ls, noise, rec), (var, ls, noise)
+    nb_tail = np.mean(rec['svgp_notebook_epoch_losses']['phase2'][-10:])
+    assert abs(ep[-10:].mean() - nb_tail) <= 0.03 * abs(nb_tail)
