@@ -48,6 +48,10 @@ int mxf_destroy(mxf_handle h);
 const char* mxf_last_error(mxf_handle h);
 /* bytes of scratch currently held by the handle */
 int64_t mxf_workspace_bytes(mxf_handle h);
+/* Counts (re-)allocations of the handle's scratch.  The library owns its workspace and grows it on demand (hipFree + hipMalloc, never
+ * inside a stream capture); a caller that captured launches into a hipGraph must re-capture when this number has changed, because the
+ * captured kernels carry the old scratch addresses.  (The reference has no counterpart: MXNet owns its temporaries.) */
+int64_t mxf_workspace_generation(mxf_handle h);
 
 /* ---------------------------------------------------------------------------------------------
  * Gram build.  Replaces Kernel.K -> _compute_K (kernels/kernel.py:96-123), i.e.

@@ -57,6 +57,7 @@ PLAIN = {  # entry points without the (handle, ...) -> int shape
     'mxf_destroy': ([_vp], _i),
     'mxf_last_error': ([_vp], _c.c_char_p),
     'mxf_workspace_bytes': ([_vp], _i64),
+    'mxf_workspace_generation': ([_vp], _i64),
     'mxf_f32x3_plane_elems': ([_i64, _i64], _i64),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
@@ -108,6 +109,12 @@ def handle(device_index):
         h = out
         _handles[key] = h
     return h
+
+
+def workspace_generation(device_index):
+    """Re-allocation count of the (thread, device) handle's scratch (mxf_workspace_generation): hipGraph holders compare it before a
+    replay -- a captured launch carries the scratch addresses of capture time."""
+    return int(load().mxf_workspace_generation(handle(device_index)))
 
 
 def call(name, h, *args):

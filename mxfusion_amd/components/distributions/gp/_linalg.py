@@ -1,5 +1,6 @@
 """autograd bridges over the dense linear algebra of the C ABI (mxf_potrf / mxf_trsm / mxf_trtri / mxf_gemm) with closed-form
-reverse modes: no reverse-mode Cholesky is needed anywhere on the path."""
+reverse modes.  The log-pdf algorithms never differentiate through a Cholesky factor (their reverse modes are closed forms of the whole
+expression); the reparameterised GP draws do, through CholFn."""
 import math
 
 import torch
@@ -41,6 +42,37 @@ class CholLogPdfFn(torch.autograd.Function):
         if ctx.yshape[0] == 1 and gY.shape[0] > 1:
             gY = gY.sum(0, keepdim=True)
         return gK, gY, None
+
+
+class CholFn(torch.autograd.Function):
+    """L = chol(K) through mxf_potrf (lower, clean upper triangle), differentiable: with Gl = tril(dL) the reverse mode is
+        dK = sym(L^-T Phi(L^T Gl) L^-1),   Phi(A) = tril(A) with a halved diagonal,   sym(S) = (S + S^T) / 2
+    (the blocked form of Murray 2016, "Differentiation of the Cholesky decomposition") -- one mxf_trtri and three mxf_gemm.  Used where
+    the reference differentiates through linalg.potrf and no closed form of the whole expression exists: the reparameterised draws
+    L eps of the GP distributions and of the sampling algorithms (gp.py:124-153, cond_gp.py:185-223, gp_regression.py:92-135)."""
+
+    @staticmethod
+    def forward(ctx, K):
+        L, info = ops.potrf_(K.contiguous().clone())
+        ctx.save_for_backward(L)
+        ctx.mark_non_differentiable(info)
+        return L, info
+
+    @staticmethod
+    def backward(ctx, G, *_):
+        L, = ctx.saved_tensors
+        Linv = ops.trtri(L)
+        P = torch.tril(ops.gemm(L, torch.tril(G).contiguous(), transA=True))
+        P = P - 0.5 * torch.diag_embed(torch.diagonal(P, dim1=-2, dim2=-1))
+        S = ops.gemm(ops.gemm(Linv, P, transA=True), Linv)
+        return 0.5 * (S + S.transpose(-1, -2))
+
+
+def chol(K):
+    """(L, info): differentiable when K requires grad (CholFn), the plain mxf_potrf on a copy otherwise."""
+    if _needs_grad(K):
+        return CholFn.apply(K)
+    return ops.potrf_(K.contiguous().clone())
 
 
 class SpdInverseFn(torch.autograd.Function):

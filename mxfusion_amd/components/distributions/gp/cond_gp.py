@@ -1,13 +1,13 @@
 """ConditionalGaussianProcess distribution (mxfusion/components/distributions/gp/cond_gp.py:25-235):
 Y ~ N(K*c Kcc^-1 (Yc - g(Xc)) + g(X),  K** - K*c Kcc^-1 K*c^T).
-The conditioning algebra runs through the explicit SPD inverse of Kcc (potrf + trtri + gemm, closed-form reverse mode) instead
-of reverse-mode Cholesky; values agree with the reference's trsm form to rounding."""
+The conditioning algebra is the reference's own (cond_gp.py:164-177): Lcc = chol(Kcc), V = Lcc^-1 Kc, cov = K - V^T V,
+mean = V^T Lcc^-1 Yc -- error amplified by sqrt(cond(Kcc)), not cond(Kcc); reverse mode through _linalg.CholFn / TrsmFn / MatmulFn."""
 import torch
 
 from .... import ops
 from ....common.exceptions import ModelSpecificationError
 from ..distribution import Distribution
-from ._linalg import CholLogPdfFn, SpdInverseFn, matmul
+from ._linalg import CholLogPdfFn, chol, gemm, trsm
 
 
 class ConditionalGaussianProcess(Distribution):
@@ -42,12 +42,13 @@ class ConditionalGaussianProcess(Distribution):
         K = self.kernel.K(F, X, **kernel_params)
         Kc = self.kernel.K(F, X_cond, X, **kernel_params)
         Kcc = self.kernel.K(F, X_cond, **kernel_params)
-        A, info = SpdInverseFn.apply(Kcc)                         # Kcc^-1
-        AKc = matmul(A, Kc)                                       # Kcc^-1 K_c*
-        cov = K - matmul(Kc, AKc, transA=True)                    # cond_gp.py:170 (K - syrk(Lcc^-1 Kc, transpose))
+        Lcc, info = chol(Kcc)                                     # cond_gp.py:167
+        V = trsm(Lcc, Kc)                                         # Lcc^-1 K_c*  (:168)
+        cov = K - gemm(V, V, transA=True)                         # :170 (K - syrk(Lcc^-1 Kc, transpose))
         if mean_cond is not None:
             Y_cond = Y_cond - mean_cond
-        rv_mean = matmul(AKc, Y_cond, transA=True)                # cond_gp.py:177
+        LccInvY = trsm(Lcc, Y_cond)                               # :176
+        rv_mean = gemm(V, LccInvY, transA=True)                   # :177
         return cov, rv_mean, mean, info
 
     def log_pdf_impl(self, X, X_cond, Y_cond, random_variable, F=None, **kernel_params):
@@ -64,13 +65,12 @@ class ConditionalGaussianProcess(Distribution):
 
     def draw_samples_impl(self, X, X_cond, Y_cond, rv_shape, num_samples=1, F=None, **kernel_params):
         """cond_gp.py:185-223."""
-        with torch.no_grad():
-            cov, rv_mean, mean, info = self._moments(F, X, X_cond, Y_cond, dict(kernel_params))
-            L, info2 = ops.potrf_(cov.contiguous().clone())
+        cov, rv_mean, mean, info = self._moments(F, X, X_cond, Y_cond, dict(kernel_params))
+        L, info2 = chol(cov)
         self._last_info = info + info2
         out_shape = (num_samples,) + tuple(rv_shape)
         die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
-        rv = ops.gemm(L, die.reshape(out_shape).contiguous()) + rv_mean
+        rv = gemm(L, die.reshape(out_shape).contiguous()) + rv_mean
         if mean is not None:
             rv = rv + mean
         return rv

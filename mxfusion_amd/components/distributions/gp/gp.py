@@ -5,7 +5,7 @@ import torch
 from .... import ops
 from ..distribution import Distribution
 from ...variables.variable import Variable
-from ._linalg import CholLogPdfFn
+from ._linalg import CholLogPdfFn, chol, gemm
 
 
 class GaussianProcess(Distribution):
@@ -40,15 +40,15 @@ class GaussianProcess(Distribution):
         return logL * self.log_pdf_scaling
 
     def draw_samples_impl(self, X, rv_shape, num_samples=1, F=None, **kernel_params):
-        """gp.py:124-153: L eps (+ mean).  The Cholesky factor is not differentiated through (no reverse-mode potrf on this path)."""
+        """gp.py:124-153: L eps (+ mean); differentiable w.r.t. X and the kernel parameters (reparameterised draw) through the
+        reverse-mode Cholesky of _linalg.CholFn, as the reference is through linalg.potrf."""
         mean = kernel_params.pop('mean', None) if self._has_mean else None
-        with torch.no_grad():
-            K = self.kernel.K(F, X, **kernel_params)
-            L, info = ops.potrf_(K.contiguous().clone())
+        K = self.kernel.K(F, X, **kernel_params)
+        L, info = chol(K)
         self._last_info = info
         out_shape = (num_samples,) + tuple(rv_shape)
         die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
-        rv = ops.gemm(L, die.reshape(out_shape).contiguous())                    # linalg.trmm(L, die): L is lower with a zero upper part
+        rv = gemm(L, die.reshape(out_shape).contiguous())                        # linalg.trmm(L, die): L is lower with a zero upper part
         if mean is not None:
             rv = rv + mean
         return rv

@@ -19,6 +19,7 @@ struct mxf_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
+    int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
     int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
     unsigned flag_cursor = 0;
 };
@@ -67,6 +68,7 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
         h->ws = nullptr;
         h->ws_bytes = 0;
     }
+    ++h->ws_generation;
     size_t want = bytes + (bytes >> 2) + (1u << 20);
     if (hipMalloc(&h->ws, want) != hipSuccess) {
         h->ws = nullptr;
@@ -107,6 +109,7 @@ static inline void* mxf_gram_ws(mxf_ctx* h, size_t bytes) {
         h->gram_ws = nullptr;
         h->gram_ws_bytes = 0;
     }
+    ++h->ws_generation;
     size_t want = bytes + (bytes >> 2) + (1u << 16);
     if (hipMalloc(&h->gram_ws, want) != hipSuccess) { h->gram_ws = nullptr; return nullptr; }
     h->gram_ws_bytes = want;

@@ -529,7 +529,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // sampled Y over shared X (hence shared Kuf, T, U): the S samples share the B columns -- generic path, the data term is quadratic in Y
     const bool ysamp = S > 1 && sX == 0 && sY != 0;
     if (ysamp && sY != B * P) MXF_FAIL(h, -2, "mxf_svgp_logpdf: Y samples must be contiguous");
-    const bool het = nrows > 1 || ncols > 1 || use_mat || ysamp;   // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass)
+    // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass); also for Q > 16 inputs, which the
+    // register-tiled fused reverse pass does not cover (gram_bwd.hip: generic kernel)
+    const bool het = nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16;
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
     if (S > 1 && sX == 0 && sY == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S > 1 with neither X nor Y sampled");
     const int SS = (sX == 0) ? 1 : S;   // samples that need their own columns

@@ -313,6 +313,185 @@ __global__ __launch_bounds__(SNT, (NP == 2 && !DMA) ? 4 : 3) void gemm_split_ker
             }
 }
 
+// ------------------------------------------------------------------------------------------------ the 128 x 256 kernel (f16x2 operands)
+// The 128 x 128 kernel above moves every operand through LDS: per 16-wide k block and workgroup 16 KB of LDS-DMA writes and 32 KB of
+// fragment reads for 48 MFMAs, and the LDS (not the matrix pipe: 58 % busy) is what it runs out of.  This kernel cuts the LDS traffic per
+// MFMA to a quarter:
+//   * block tile 128 (A rows) x 256 (B rows), four waves side by side along B: wave w owns ALL 128 rows x columns [64 w, 64 w + 64)
+//     = 4 x 2 MFMA tiles, 24 v_mfma_f32_32x32x16_f16 per k block (128 accumulator VGPRs);
+//   * A (shared by the four waves) goes through LDS as before: 8 KB of LDS-DMA per k block, a three-slot ring, 8 ds_read_b128 per wave;
+//   * B is private to a wave, so it never touches LDS: each lane fetches its 16-byte fragment units straight from global memory
+//     (the plane layout makes a wave's 32 rows x 16 k one contiguous 1 KB run) two k blocks ahead into a three-deep register ring.
+// One barrier per k block.  Inline-asm loads + hand-counted s_waitcnt vmcnt: the compiler's own waits would drain the LDS-DMA queue at the
+// first use of an ordinary load (cdna_hip_programming.md section 5, "mixing load kinds").  The MFMA operands are swapped (D = B A^T), which
+// leaves every lane with four CONSECUTIVE output columns per accumulator quad: the epilogue is 16-byte stores.
+constexpr int WBM = 128, WBN = 256;
+
+__device__ __forceinline__ u32x4 gload16(unsigned voff, const void* sbase) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
+    __shared__ u32x4 smem[3][2][256];              // [ring slot][plane][16-byte unit]: 3 x 8 KB (A only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t wid = blockIdx.x;
+    {   // XCD-aware mapping: every XCD owns a contiguous run of tiles
+        const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t split = wid / g.ntiles;
+    int64_t t = wid % g.ntiles;
+    int64_t tile_m, tile_n;
+    if (g.lower_only) {             // tiles (tm, tn) with 256 tn <= 128 tm + 127, i.e. tn <= tm / 2: row tm holds tm / 2 + 1 tiles
+        int64_t row = 0;
+        while (t >= row / 2 + 1) { t -= row / 2 + 1; ++row; }
+        tile_m = row; tile_n = t;
+    } else {
+        tile_m = t % g.tm; tile_n = t / g.tm;       // the row tiles of one column tile are neighbours: they share the B columns in L2
+    }
+    const int64_t m0 = tile_m * WBM, n0 = tile_n * WBN;
+    const int64_t kbeg = split * g.kchunk;
+    const int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
+
+    f32x16 c[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;
+
+    // A: LDS-DMA, thread t fills 16-byte unit t of each plane's (128 x 16) slab; the XOR swizzle of the two k halves is applied to the source
+    const int drow = tid >> 1, dkh = (tid & 1) ^ ((drow >> 3) & 1);
+    const unsigned short* da = g.A + (m0 + drow) * 16 + dkh * 8;
+    // B: lane <-> (row = lane & 31, k half = lane >> 5) of the wave's two 32-row fragments; per-lane byte offset inside the k block's slab
+    const unsigned bvoff = (unsigned)(((64 * wave + (lane & 31)) * 16 + (lane >> 5) * 8) * 2);
+    const unsigned short* bbase = g.B + n0 * 16;                     // wave-uniform
+    const int li = lane & 31, lk = lane >> 5;
+    int ua[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ua[x] = lds_unit(32 * x + li, lk);
+
+    u32x4 b0[2][2], b1[2][2], b2[2][2];          // register ring of the B fragments [y][plane]: blocks kb, kb + 1, kb + 2
+    // per k block six requests, in this order: four B fragment loads (registers), two LDS-DMA requests (A slab)
+#define W_ISSUE(kb, SLOT, BR)                                                                                                       \
+    do {                                                                                                                            \
+        const unsigned short* bk_ = bbase + (kb) * g.N * 16;                                                                        \
+        BR[0][0] = gload16(bvoff, bk_);                                                                                             \
+        BR[1][0] = gload16_o1024(bvoff, bk_);                                                                                       \
+        BR[0][1] = gload16(bvoff, bk_ + g.pB);                                                                                      \
+        BR[1][1] = gload16_o1024(bvoff, bk_ + g.pB);                                                                                \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + (kb) * g.M * 16),                     \
+                                         (__attribute__((address_space(3))) void*)(&smem[SLOT][0][wave * 64]), 16, 0, 0);           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + g.pA + (kb) * g.M * 16),              \
+                                         (__attribute__((address_space(3))) void*)(&smem[SLOT][1][wave * 64]), 16, 0, 0);           \
+    } while (0)
+    // all but the N requests issued last have landed (this wave's share; the barrier extends it to the workgroup).  The B registers
+    // that are now complete are tied to the wait ("+v"), so that no use of them can be scheduled above it.  The wait always sits in
+    // STRAIGHT-LINE code: inside a branch the compiler may place the register copies of a control-flow merge in front of it, i.e. copy
+    // registers whose loads are still in flight (seen in an earlier form of this kernel; csrc/check_wide_isa.py guards against it).
+#define W_WAIT(N, BR)                                                                                                               \
+    do {                                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(BR[0][0]), "+v"(BR[0][1]), "+v"(BR[1][0]), "+v"(BR[1][1])::"memory");          \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        asm volatile("" ::: "memory");                                                                                              \
+    } while (0)
+#define HF(v) __builtin_bit_cast(f16x8, v)
+#define W_COMPUTE(SLOT, BR)                                                                                                         \
+    do {                                                                                                                            \
+        u32x4 a_[4][2];                                                                                                             \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }          \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
+                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][1]), c[x][y], 0, 0, 0);      /* hi' lo */   \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
+                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][1]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* lo' hi */   \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
+                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* hi' hi */   \
+    } while (0)
+    // one k block `kk`: ring slot SLOT / registers BR hold it; block kk + 2 (clamped to the last block: the loop is branch-free, the
+    // surplus requests of the last two steps re-read the last block and are never used) is requested into SLOT2 / BR2 -- free since the
+    // barrier that closed block kk - 1 --, then the MFMAs, then the wait for block kk + 1 (registers BRN) with block kk + 2 in flight
+#define W_STEP(kk, SLOT, BR, SLOT2, BR2, BRN)                                                                                       \
+    do {                                                                                                                            \
+        const int64_t k2_ = (kk) + 2 < kend ? (kk) + 2 : klast;                                                                     \
+        W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
+        W_COMPUTE(SLOT, BR);                                                                                                        \
+        W_WAIT(6, BRN);                                                                                                             \
+    } while (0)
+    if (kbeg < kend) {
+        const int64_t klast = kend - 1;
+        int64_t kb = kbeg;
+        // the block count modulo 3 first, unpipelined (request, drain, multiply): the pipelined loop then runs whole trips of three
+        for (int i = (int)((kend - kbeg) % 3); i > 0; --i, ++kb) {
+            W_ISSUE(kb, 0, b0);
+            W_WAIT(0, b0);
+            W_COMPUTE(0, b0);
+            __builtin_amdgcn_s_barrier();          // slot 0 is rewritten by the next request
+        }
+        if (kb < kend) {
+            W_ISSUE(kb, 0, b0);
+            W_ISSUE(kb + 1, 1, b1);
+            W_WAIT(6, b0);
+            for (; kb < kend; kb += 3) {           // three k blocks per trip: ring indices are compile-time constants, one loop exit
+                W_STEP(kb, 0, b0, 2, b2, b1);
+                W_STEP(kb + 1, 1, b1, 0, b0, b2);
+                W_STEP(kb + 2, 2, b2, 1, b1, b0);
+            }
+            // the surplus requests of the last two steps target registers / LDS the epilogue does not read, but they must have landed
+            // before the registers are reused
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b1[0][0]), "+v"(b1[0][1]),
+                         "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
+        }
+    }
+#undef W_STEP
+#undef HF
+#undef W_WAIT
+#undef W_ISSUE
+    float alpha = g.alpha;
+    const float beta = g.beta;
+    if (g.ad0) { const float v = g.ad0[0]; for (int i = 0; i < g.pow0; ++i) alpha *= v; }
+    if (g.maxbits) alpha /= scale_from_maxbits(g.maxbits[0]);
+    if (g.maxbits2) alpha /= scale_from_maxbits(g.maxbits2[0]);
+    const bool atomic = g.atomic != 0;
+    // D = B A^T: accumulator register r of tile (x, y) is C[m0 + 32 x + (lane & 31)][n0 + 64 wave + 32 y + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int64_t row = m0 + 32 * x + li;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = n0 + 64 * wave + 32 * y + 8 * q + 4 * lk;
+                float* p = g.C + row * g.ldc + col;
+                f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
+                if (g.lower_only && col + 3 > row) {             // tile on the diagonal: element-wise
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e <= row) { if (atomic) atomic_add(p + e, v[e]); else p[e] = (beta == 0.f) ? v[e] : v[e] + beta * p[e]; }
+                } else if (atomic) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomic_add(p + e, v[e]);
+                } else if (beta == 0.f) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+                } else {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(p);
+                    *reinterpret_cast<f32x4*>(p) = v + beta * o;
+                }
+            }
+    }
+}
+
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
     if (col < N && !(lower_only && col > row)) {
@@ -363,12 +542,24 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     g.nprod = nprod;
     static const int use_dma = getenv("MXF_SPLIT_DMA") ? atoi(getenv("MXF_SPLIT_DMA")) : 1;
     g.use_dma = use_dma;
-    const int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
+    static const int wide_env = getenv("MXF_SPLIT_WIDE") ? atoi(getenv("MXF_SPLIT_WIDE")) : 2;
+    // MXF_SPLIT_WIDE: 0 = never, 1 = whenever the shape allows, 2 (default) = only for the long-K lower-triangle products (Psi2)
+    const bool wide = wide_env && (wide_env != 2 || lower_only) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % WBM) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
+                      (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N);
+    int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
-    const int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    if (wide) {
+        tm = M / WBM; tn = N / WBN;
+        tiles = 0;
+        if (lower_only) { for (int64_t r = 0; r < tm; ++r) tiles += r / 2 + 1; }
+        else tiles = tm * tn;
+    }
     int splitk = 1;
-    // split-K target: ~one wave of workgroups (3 fit a CU; 3 or 4 per CU measure the same per step, 6 and more are slower)
-    const int64_t slots = (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
+    // split-K target: ~one wave of workgroups (3 fit a CU; 3 or 4 per CU measure the same per step, 6 and more are slower; the wide kernel: 2)
+    // (a caller that reserves more than half of the chip wants a FEW workgroups next to other work -- phase A of Psi2, sized for the
+    //  four-per-CU kernel: keep its workgroup count with the two-per-CU wide kernel)
+    const int64_t slots = (int64_t)(256 - reserve_cus) * (wide ? (reserve_cus >= 128 ? 4 : 2) : (mode == MXF_SPLIT_F16X2 ? 4 : 3));
     if (tiles < slots && g.K16 >= 16) {
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
@@ -390,6 +581,11 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         hipLaunchKernelGGL(split_scale_kernel, gs, dim3(256), 0, st, C, M, N, ldc, (float)beta, lower_only);
     }
     const bool dma = g.use_dma && (M % SBM) == 0 && (N % SBN) == 0;
+    if (wide) {
+        hipLaunchKernelGGL(gemm_f16x2_wide_kernel, dim3((unsigned)g.nwg), dim3(256), 0, st, g);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (mode == MXF_SPLIT_F16X2) {
         if (dma) hipLaunchKernelGGL((gemm_split_kernel<true, 2>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);
         else hipLaunchKernelGGL((gemm_split_kernel<false, 2>), dim3((unsigned)g.nwg), dim3(SNT), 0, st, g);

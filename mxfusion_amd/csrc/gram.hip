@@ -303,27 +303,28 @@ __global__ __launch_bounds__(256) void gram_generic_kernel(GramArgs<T> a) {
     const int MODE = a.mode;
     const int s = blockIdx.z;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t row = blockIdx.y;
     if (col >= a.N2) return;
-    const T* X = a.X + (int64_t)s * a.sX + row * a.Q;
     const T* X2 = a.X2 + (int64_t)s * a.sX2 + col * a.Q;
     const T* ls = a.ls + (int64_t)s * a.sls;
     const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : a.var[(int64_t)s * a.svar];
-    T acc = 0;
-    if (KIND == MXF_K_LINEAR) {
-        for (int q = 0; q < a.Q; ++q) acc = fma(X[q] * ls[a.ard ? q : 0], X2[q], acc);
-    } else if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {
-        for (int q = 0; q < a.Q; ++q) { T d = (X[q] - X2[q]) * (coord_scale<T, KIND>() / ls[a.ard ? q : 0]); acc = fma(d, d, acc); }
+    for (int64_t row = blockIdx.y; row < a.N; row += gridDim.y) {      // grid.y is capped at 65535 row slots
+        const T* X = a.X + (int64_t)s * a.sX + row * a.Q;
+        T acc = 0;
+        if (KIND == MXF_K_LINEAR) {
+            for (int q = 0; q < a.Q; ++q) acc = fma(X[q] * ls[a.ard ? q : 0], X2[q], acc);
+        } else if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {
+            for (int q = 0; q < a.Q; ++q) { T d = (X[q] - X2[q]) * (coord_scale<T, KIND>() / ls[a.ard ? q : 0]); acc = fma(d, d, acc); }
+        }
+        T k;
+        if (KIND == MXF_K_BIAS) k = variance;
+        else if (KIND == MXF_K_WHITE) k = (a.square && row == col) ? variance : (T)0;
+        else k = cov_from<T, KIND>(acc, variance);
+        if (a.square && row == col) k += (a.dadd ? a.dadd[(int64_t)s * a.sdadd] : (T)0) + a.jitter;
+        T* dst = a.K + (int64_t)s * a.sK + row * a.ldk + col;
+        if (MODE == MXF_ACC_ADD) k = *dst + k;
+        if (MODE == MXF_ACC_MUL) k = *dst * k;
+        *dst = k;
     }
-    T k;
-    if (KIND == MXF_K_BIAS) k = variance;
-    else if (KIND == MXF_K_WHITE) k = (a.square && row == col) ? variance : (T)0;
-    else k = cov_from<T, KIND>(acc, variance);
-    if (a.square && row == col) k += (a.dadd ? a.dadd[(int64_t)s * a.sdadd] : (T)0) + a.jitter;
-    T* dst = a.K + (int64_t)s * a.sK + row * a.ldk + col;
-    if (MODE == MXF_ACC_ADD) k = *dst + k;
-    if (MODE == MXF_ACC_MUL) k = *dst * k;
-    *dst = k;
 }
 
 template <typename T, int KIND>
@@ -332,8 +333,7 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     if (mode < 0 || mode > 2) MXF_FAIL(h, -2, "mxf_gram: bad mode %d", mode);
     a.mode = mode;
     if (a.Q > 16) {
-        dim3 g((unsigned)((a.N2 + 255) / 256), (unsigned)a.N, (unsigned)S);
-        if (a.N > 65535) MXF_FAIL(h, -3, "mxf_gram: Q>16 fallback supports N<=65535");
+        dim3 g((unsigned)((a.N2 + 255) / 256), (unsigned)(a.N < 65535 ? a.N : 65535), (unsigned)S);
         hipLaunchKernelGGL((gram_generic_kernel<T, KIND>), g, dim3(256), 0, st, a);
         MXF_LAUNCH_CHECK(h);
         return 0;

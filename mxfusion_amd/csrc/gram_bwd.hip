@@ -296,6 +296,51 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
     }
 }
 
+// Generic reverse mode for Q > 16 inputs (the tiled kernel keeps Q values per lane in registers): one thread per (row, column) pair, the
+// coordinates re-read from global memory (L2-resident: (N + N2) Q values), row-side sums block-reduced per coordinate.  Correct for any Q,
+// far from the tiled kernel's speed -- the counterpart of gram_generic_kernel in gram.hip.  Same accumulate-into semantics.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void gram_bwd_generic_kernel(GramBwdArgs<T> a) {
+    __shared__ T red[16];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.z;
+    const int64_t col = (int64_t)blockIdx.x * 256 + tid;
+    const bool cvalid = col < a.N2;
+    const int Q = a.Q;
+    const T* __restrict__ X = a.X + (int64_t)s * a.sX;
+    const T* __restrict__ X2 = a.X2 + (int64_t)s * a.sX2;
+    const T* __restrict__ ls = a.ls + (int64_t)s * a.sls;
+    const T variance = a.var[(int64_t)s * a.svar];
+    const T* __restrict__ dK = a.dK + (int64_t)s * a.sdK;
+    T* dXc = a.square ? a.dX : a.dX2;
+    const int64_t sXc = a.square ? a.sX : a.sX2;
+    T gvar = 0, gl0 = 0;
+    for (int64_t row = blockIdx.y; row < a.N; row += gridDim.y) {
+        T r2 = 0;
+        if (cvalid)
+            for (int q = 0; q < Q; ++q) { const T d = (X[row * Q + q] - X2[col * Q + q]) / ls[a.ard ? q : 0]; r2 = fma(d, d, r2); }
+        T k, w;
+        cov_and_slope<T, KIND>(r2, k, w);
+        const T g = cvalid ? dK[row * a.lddk + col] : (T)0;
+        gvar = fma(g, k, gvar);
+        const T W2 = (T)2 * g * w * variance;       // 2 dL/d(r2)
+        for (int q = 0; q < Q; ++q) {
+            const T il = (T)1 / ls[a.ard ? q : 0];
+            const T d = cvalid ? (X[row * Q + q] - X2[col * Q + q]) * il : (T)0;
+            const T t = W2 * d;                      // dL/d(scaled x_q)
+            if (dXc && cvalid) atomic_add(dXc + (int64_t)s * sXc + col * Q + q, -t * il);
+            const T gl = -t * d * il;                // dL/dl_q
+            if (a.dX) { const T v = block_sum<T>(t * il, red); if (tid == 0) atomic_add(a.dX + (int64_t)s * a.sX + row * Q + q, v); }
+            if (a.dls) {
+                if (a.ard) { const T v = block_sum<T>(gl, red); if (tid == 0) atomic_add(a.dls + (int64_t)s * a.sls + q, v); }
+                else gl0 += gl;
+            }
+        }
+    }
+    if (a.dls && !a.ard) { const T v = block_sum<T>(gl0, red); if (tid == 0) atomic_add(a.dls + (int64_t)s * a.sls, v); }
+    if (a.dvar) { const T v = block_sum<T>(gvar, red); if (tid == 0) atomic_add(a.dvar + (int64_t)s * a.svar, v); }
+}
+
 template <typename T, int QT, int KIND, int PT>
 int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     constexpr bool FUSED = PT > 0;
@@ -335,7 +380,14 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
 
 template <typename T, int KIND, int PT>
 int launch_bwd(mxf_ctx* h, const GramBwdArgs<T>& a, int S, hipStream_t st) {
-    if (a.Q > 16) MXF_FAIL(h, -3, "mxf_gram_bwd: Q > 16 not supported");
+    if (a.Q > 16) {
+        if (PT > 0) MXF_FAIL(h, -3, "svgp fused reverse pass: Q > 16 runs through the generic (materialised dKuf) path");
+        dim3 g((unsigned)((a.N2 + 255) / 256), (unsigned)(a.N < 65535 ? a.N : 65535), (unsigned)S);
+        if (g.z > 65535u) MXF_FAIL(h, -3, "mxf_gram_bwd: grid too large");
+        hipLaunchKernelGGL((gram_bwd_generic_kernel<T, KIND>), g, dim3(256), 0, st, a);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (a.Q <= 2) return launch_q<T, 2, KIND, PT>(h, a, S, st);
     if (a.Q <= 4) return launch_q<T, 4, KIND, PT>(h, a, S, st);
     if (a.Q <= 8) return launch_q<T, 8, KIND, PT>(h, a, S, st);

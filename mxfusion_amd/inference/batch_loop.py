@@ -60,9 +60,18 @@ class BatchInferenceLoop(GradLoop):
         return loss
 
     def _graph_step(self, infr_executor, data, param_dict):
+        from .. import _lib
+        dev = param_dict.flat.device.index if param_dict.flat.device.index is not None else torch.cuda.current_device()
+        key = (id(infr_executor), tuple((tuple(d.shape), d.dtype) for d in data))
         st = getattr(self, '_gstate', None)
-        if st is None or st.get('flat') is not param_dict.flat:
-            st = self._gstate = {'n': 0, 'flat': param_dict.flat}
+        if st is None or st.get('flat') is not param_dict.flat or st.get('key') != key:
+            st = self._gstate = {'n': 0, 'flat': param_dict.flat, 'key': key}
+        if 'graph' in st and st['ws_gen'] != _lib.workspace_generation(dev):
+            # the library re-allocated its scratch since the capture (a larger call in between: a prediction, another module): the
+            # captured kernels carry the OLD scratch addresses -- drop the graph, warm up once more eagerly, capture again
+            for k in ('graph', 'loss', 'grad', 'data', 'ws_gen'):
+                st.pop(k, None)
+            st['n'] = 1
         if 'graph' not in st:
             if st['n'] < 2:                      # eager warm-up, on a side stream (the documented whole-step capture recipe: autograd's
                 st['n'] += 1                     # AccumulateGrad node of the flat leaf must not be bound to the default stream)
@@ -76,11 +85,14 @@ class BatchInferenceLoop(GradLoop):
                 return loss.detach()
             torch.cuda.synchronize()
             param_dict.zero_grad()
+            gen0 = _lib.workspace_generation(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss, loss_for_gradient = infr_executor(*data)
                 loss_for_gradient.backward()
-            st.update(graph=g, loss=loss.detach(), grad=param_dict.flat.grad, data=[d for d in data])
+            if _lib.workspace_generation(dev) != gen0:      # the library never allocates inside a capture; belt and braces
+                raise RuntimeError('mxfusion_amd: the scratch workspace was re-allocated during hipGraph capture')
+            st.update(graph=g, loss=loss.detach(), grad=param_dict.flat.grad, data=[d for d in data], ws_gen=gen0)
         for d, d0 in zip(data, st['data']):
             if d is not d0:
                 d0.copy_(d)

@@ -175,6 +175,13 @@ class Inference(object):
                     for g in self._graphs:
                         if cu in g.variables:
                             self.params._vars[cu] = g.variables[cu]
+        # every trainable parameter of the current graphs must have been restored: a checkpoint that silently leaves some of them at their
+        # random initial values is worse than an error
+        restored = {uuid_map[su] for su in saved_params if su in uuid_map}
+        missing = [u for u in self.params._slices if u not in restored]
+        if missing:
+            names = [getattr(self.params._vars.get(u), 'name', None) or u for u in missing]
+            raise SerializationError('the checkpoint holds no value for %d trainable parameter(s): %s' % (len(missing), ', '.join(map(str, names[:8]))))
         consts = {}
         for su, arr in saved_consts.items():
             if su in uuid_map:

@@ -4,6 +4,18 @@ import torch
 from ... import ops
 
 
+def _uniform_weight(g):
+    """sum(g) for an upstream gradient that weights every sample equally -- the only reduction the reference applies to a module's
+    log-pdf is mean_S (factor_graph.py:233), and the fused composites return the gradients of gscale * sum_s logL[s] with ONE gscale.
+    A non-uniform weighting cannot be represented by that call: instead of returning silently wrong gradients the result is poisoned
+    with NaN (checked on the device: no host synchronisation, safe inside a hipGraph capture)."""
+    c = g.sum()
+    if g.numel() > 1:
+        spread = (g - c / g.numel()).abs().max()
+        c = torch.where(spread <= 1e-6 * c.abs() / g.numel(), c, torch.full_like(c, float('nan')))
+    return c
+
+
 class GPLogPdfFn(torch.autograd.Function):
     """mxf_gp_logpdf: logL (S,), and the posterior side products L, LinvY (gp_regression.py:72-75)."""
 
@@ -50,7 +62,7 @@ class SVGPLogPdfFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_):
-        c = g.sum()
+        c = _uniform_weight(g)
         out = []
         for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:]):
             out.append((grad.reshape(shp) * c) if need else None)
@@ -76,7 +88,7 @@ class SVGPMatLogPdfFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_):
-        c = g.sum()          # gradients were produced for mean_S(logL) (gscale = 1/S): scale by sum(grad_output), as SVGPLogPdfFn does
+        c = _uniform_weight(g)          # gradients were produced for mean_S(logL) (gscale = 1/S): scale by sum(grad_output), as SVGPLogPdfFn does
         out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:])]
         return (None, None) + tuple(out)
 

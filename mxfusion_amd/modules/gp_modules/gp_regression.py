@@ -83,13 +83,14 @@ class GPRegressionSampling(SamplingAlgorithm):
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
         X, noise_var, kern_params = arrays_as_samples(F, [X, noise_var, kern_params])
-        with torch.no_grad():
-            K = kern.K(F, X, **kern_params) + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
-            L, _ = ops.potrf_(K.contiguous().clone())
-            Y_shape = (N, int(self.model.Y.shape[-1]))
-            out_shape = (self.num_samples,) + Y_shape
-            die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
-            y_samples = ops.gemm(L, die)          # trmm: L is lower with a clean upper triangle
+        # differentiable w.r.t. X, the noise and the kernel parameters (reverse-mode Cholesky: _linalg.CholFn), as the reference's
+        # linalg.potrf is -- a GP prior draw inside a differentiated objective keeps its gradients
+        K = kern.K(F, X, **kern_params) + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+        L, _ = lin.chol(K)
+        Y_shape = (N, int(self.model.Y.shape[-1]))
+        out_shape = (self.num_samples,) + Y_shape
+        die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
+        y_samples = lin.gemm(L, die)          # trmm: L is lower with a clean upper triangle
         if has_mean:
             y_samples = y_samples + variables[self.model.mean]
         samples = {self.model.Y.uuid: y_samples}

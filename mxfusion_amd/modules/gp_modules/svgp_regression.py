@@ -34,6 +34,8 @@ class SVGPRegressionLogPdf(VariationalInference):
         self.log_pdf_scaling = 1
         self.jitter = jitter
 
+    PMAX = 8     # output columns per fused call (register tile of the composites); wider Y is processed in column blocks
+
     def compute(self, F, variables):
         has_mean = self.model.F.factor.has_mean
         X = variables[self.model.X]
@@ -45,14 +47,33 @@ class SVGPRegressionLogPdf(VariationalInference):
         S_diag = variables[self.posterior.qU_cov_diag]
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
+        if has_mean:
+            Y = Y - variables[self.model.mean]
+        P = Y.shape[-1]
+        if P > self.PMAX:
+            # The bound is a SUM over output columns for a shared q(u) covariance (svgp_regression.py:93-108: every term carries the
+            # factor D or a sum over the D columns; the -KL part D times the covariance terms plus |L^-1 mu_d|^2 per column), so
+            # log L(Y[:, :D]) = sum over column blocks of log L(block): one fused call per block of <= 8 columns, autograd adds the
+            # gradients of the shared parameters.
+            total, infos = None, []
+            per_col = noise_var.shape[-1] == P and P > 1
+            for p0 in range(0, P, self.PMAX):
+                sl = slice(p0, min(p0 + self.PMAX, P))
+                part = self._compute_columns(F, X, Y[..., sl], Z, noise_var[..., sl] if per_col else noise_var, mu[..., sl], S_W, S_diag,
+                                             kern, kern_params)
+                infos.append(self._last_info)
+                total = part if total is None else total + part
+            self._last_info = torch.stack(infos).sum(0)
+            return total
+        return self._compute_columns(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
+
+    def _compute_columns(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         spec = kern.fused_spec()
         if spec is None:
-            return self._compute_materialised(F, variables, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params, has_mean)
+            return self._compute_materialised(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
-        if has_mean:
-            Y = Y - variables[self.model.mean]
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
         scaling = float(self.log_pdf_scaling)
         if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
@@ -70,11 +91,9 @@ class SVGPRegressionLogPdf(VariationalInference):
         return logL
 
 
-    def _compute_materialised(self, F, variables, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params, has_mean):
+    def _compute_materialised(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         """Combination kernels (add_kernel.py:44-68, multiply_kernel.py:44-67): Kuu / Kuf / Kdiag come from kern.K (each sub-kernel one
         mxf_gram pass with its own reverse mode) and the bound from mxf_svgp_logpdf_mat, one call per sample."""
-        if has_mean:
-            Y = Y - variables[self.model.mean]
         Kuu = kern.K(F, Z, **kern_params)
         Kuf = kern.K(F, Z, X, **kern_params)
         Kdiag = kern.Kdiag(F, X, **kern_params)

@@ -42,13 +42,19 @@ def load_json_from_zip(zip_filename, target_file):
 
 
 def load_parameters(npz_filename, zip_file):
-    """serialization.py:115-135 (an empty archive loads as {})."""
+    """serialization.py:115-135.  A missing member or an archive without arrays loads as {} (the reference writes an empty .npz when there
+    are no constants); a member that IS there but cannot be read -- truncated, corrupt, not an .npz -- raises SerializationError instead of
+    silently restoring nothing."""
+    if npz_filename not in zip_file.namelist():
+        return {}
     raw = zip_file.read(npz_filename)
+    if len(raw) == 0:
+        return {}
     try:
         loaded = np.load(io.BytesIO(raw))
-    except (OSError, ValueError):
-        return {}
-    return {k: loaded[k] for k in loaded.files}
+        return {k: loaded[k] for k in loaded.files}
+    except Exception as e:      # zipfile.BadZipFile, OSError, ValueError, pickle errors ...
+        raise SerializationError('cannot read %s from the checkpoint: %s' % (npz_filename, e))
 
 
 def write_zip(zip_filename, json_files, npz_files):

@@ -82,6 +82,44 @@ def test_zip_layout_and_uuid_reconciliation_cpu(tmp_path):
         infr2.load(z2)
 
 
+def test_corrupt_or_incomplete_checkpoint_is_an_error_cpu(tmp_path):
+    """A truncated parameter archive or one that lacks a trainable parameter must raise, not leave the model at its initial values."""
+    from mxfusion_amd.inference import Inference, MAP
+    from mxfusion_amd.common.exceptions import SerializationError
+    rng = np.random.RandomState(1)
+    m = _model('cpu', rng.rand(1), rng.rand(3), rng.rand(1))
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype=DT, context=torch.device('cpu'))
+    infr.initialize(X=(10, 3), Y=(10, 1))
+    z = str(tmp_path / 'inference.zip')
+    infr.save(z)
+
+    def rewrite(edit):
+        out = str(tmp_path / 'edited.zip')
+        with zipfile.ZipFile(z) as src, zipfile.ZipFile(out, 'w') as dst:
+            for name in src.namelist():
+                data = edit(name, src.read(name))
+                if data is not None:
+                    dst.writestr(name, data)
+        return out
+    m2 = _model('cpu', rng.rand(1), rng.rand(3), rng.rand(1))
+    infr2 = Inference(MAP(model=m2, observed=[m2.X, m2.Y]), dtype=DT, context=torch.device('cpu'))
+    infr2.initialize(X=(10, 3), Y=(10, 1))
+    with pytest.raises(SerializationError):          # truncated mxnet_parameters.npz
+        infr2.load(rewrite(lambda n, d: d[:len(d) // 2] if n == 'mxnet_parameters.npz' else d))
+
+    def drop_one(n, d):                               # a valid archive that lacks one trainable parameter
+        if n != 'mxnet_parameters.npz':
+            return d
+        npz = np.load(io.BytesIO(d))
+        keep = {k: npz[k] for k in npz.files if k != m.noise_var.uuid}
+        b = io.BytesIO()
+        np.savez(b, **keep)
+        return b.getvalue()
+    with pytest.raises(SerializationError):
+        infr2.load(rewrite(drop_one))
+    infr2.load(z)                                     # the intact checkpoint still loads
+
+
 @pytest.mark.gpu
 def test_gp_module_save_and_load_gpu(tmp_path):
     from mxfusion_amd.inference import Inference, MAP, TransferInference, ModulePredictionAlgorithm

@@ -17,12 +17,37 @@ def _dev(a, dtype=torch.float64):
     return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
 
 
-def _close(got, ref, rtol, name=''):
+_REPORT = {}
+
+
+def _close(got, ref, rtol, name='', floor=None):
+    """Element-wise: |got - ref| <= rtol * (|ref| + floor * max|ref|).  floor = 1e-3 for the float64 comparisons (rtol < 1e-6): an entry
+    a thousand times smaller than the largest one is still checked to rtol relative to ITSELF plus a small absolute allowance -- the
+    earlier normwise form (atol = rtol * max|ref|) left small-magnitude gradient entries effectively unchecked.  The float32 streaming
+    path keeps floor = 1 (normwise): its f32 accumulations carry errors relative to the LARGEST partial sum, not to the entry."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     ref = ref.detach().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
-    scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    assert np.allclose(got, ref, rtol=rtol, atol=rtol * scale), (name, np.abs(got - ref).max(), scale)
+    if not ref.size:
+        return
+    if floor is None:
+        floor = 1e-3 if rtol < 1e-6 else 1.0
+    scale = max(1.0 if floor >= 1.0 else 0.0, float(np.abs(ref).max()))
+    bound = rtol * (np.abs(ref) * (0.0 if floor >= 1.0 else 1.0) + floor * scale) if floor < 1.0 else rtol * (np.abs(ref) + scale)
+    ratio = float((np.abs(got - ref) / np.maximum(bound, 1e-300)).max())
+    if os.environ.get('MXF_TEST_REPORT'):
+        key = (name, rtol)
+        _REPORT[key] = max(_REPORT.get(key, 0.0), ratio)
+    assert ratio <= 1.0, (name, float(np.abs(got - ref).max()), scale, ratio)
+
+
+if os.environ.get('MXF_TEST_REPORT'):
+    import atexit
+
+    @atexit.register
+    def _print_report():
+        for (name, rtol), r in sorted(_REPORT.items(), key=lambda kv: -kv[1]):
+            print('CLOSE-REPORT %-18s rtol %.1e  worst error / bound = %.3f' % (name, rtol, r))
 
 
 def test_gp_logpdf_golden(golden_dir):
@@ -366,3 +391,21 @@ def test_svgp_split_path_is_insensitive_to_the_problem_scale(var, noise, yscale)
     for key in ('dX', 'dZ', 'dW', 'dSdiag', 'dmu', 'dls', 'dvar', 'dnoise', 'dY'):
         a, b = ref[key].double().cpu().numpy(), got[key].double().cpu().numpy()
         assert np.linalg.norm(a - b) <= 5e-4 * np.linalg.norm(a), (key, np.linalg.norm(a - b) / np.linalg.norm(a))
+
+
+def test_fused_bridges_reject_non_uniform_sample_weights():
+    """modules/gp_modules/_fused.py: the fused composites return the gradients of gscale * sum_s logL[s] with ONE gscale; an upstream
+    gradient that weights the samples differently cannot be represented and must not come back as a plausible-looking number."""
+    from mxfusion_amd.modules.gp_modules._fused import SVGPLogPdfFn
+    rng = np.random.RandomState(0)
+    S, B, M, Q = 3, 40, 6, 2
+    X = _dev(rng.rand(S, B, Q)).requires_grad_(True)
+    Y, Z = _dev(rng.rand(1, B, 1)), _dev(rng.rand(1, M, Q)).requires_grad_(True)
+    args = (_dev([[0.1]]), _dev(rng.randn(1, M, 1) * 0.1), _dev(rng.randn(1, M, M) * 0.05), _dev(rng.rand(1, M) + 0.5), _dev(np.ones((1, Q))),
+            _dev([[1.0]]))
+    logL, _ = SVGPLogPdfFn.apply('rbf', True, 1e-6, 1.0, X, Y, Z, *args)
+    gX, gZ = torch.autograd.grad(logL.mean(), (X, Z), retain_graph=True)          # the reference's reduction: fine
+    assert torch.isfinite(gX).all() and torch.isfinite(gZ).all()
+    w = _dev([1.0, 2.0, 3.0])
+    gX2, gZ2 = torch.autograd.grad((logL * w).sum(), (X, Z))                         # per-sample weights: poisoned, not silently wrong
+    assert torch.isnan(gX2).all() and torch.isnan(gZ2).all()

@@ -69,20 +69,50 @@ def test_duplicated_points_zero_distance(kind):
 
 
 def test_wide_inputs_beyond_the_tiled_kernels():
-    """Q > 16: the Gram falls back to the generic kernel (same values); the tiled reverse mode and the fused SVGP composite refuse loudly."""
-    from mxfusion_amd import ops, _lib
+    """Q > 16 inputs and P > 8 outputs (the register tiles of the fast kernels): the Gram and its reverse mode fall back to the generic
+    kernels, the SVGP bound runs the materialised-dKuf path and splits Y into column blocks (the bound is additive over output columns) --
+    same values and gradients as the oracle, no refusal (the reference handles any Q and D)."""
+    from mxfusion_amd import ops
     rng = np.random.RandomState(2)
     Q = 20
     X, X2, ls, var = rng.rand(1, 33, Q), rng.rand(1, 17, Q), rng.rand(1, Q) + 0.8, np.array([[1.1]])
+    dK = rng.randn(1, 33, 17)
     K = ops.gram('rbf', _t(X), _t(X2), _t(ls), _t(var), True)
     k = O.RBF(Q, ARD=True)
-    Ko = k.K(O.T(X), O.T(X2), rbf_lengthscale=O.T(ls), rbf_variance=O.T(var))
-    assert np.allclose(K.cpu().numpy(), Ko.numpy(), rtol=1e-11, atol=1e-12)
-    with pytest.raises(_lib.MXFError):
-        ops.gram_bwd('rbf', _t(X), _t(X2), _t(ls), _t(var), True, _t(rng.randn(1, 33, 17)))
-    with pytest.raises(_lib.MXFError):       # P > 8 outputs
-        ops.svgp_logpdf('rbf', _t(rng.rand(1, 8, 3)), _t(rng.rand(1, 8, 9)), _t(rng.rand(4, 3)), _t([0.1]), _t(rng.rand(4, 9)), _t(np.zeros((4, 4))),
-                        _t(np.ones(4)), _t(np.ones(3)), _t([1.0]), True, want_grad=True)
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=X, X2=X2, ls=ls, var=var).items()}
+    Ko = k.K(lv['X'], lv['X2'], rbf_lengthscale=lv['ls'], rbf_variance=lv['var'])
+    assert np.allclose(K.cpu().numpy(), Ko.detach().numpy(), rtol=1e-11, atol=1e-12)
+    (Ko * O.T(dK)).sum().backward()
+    g = dict(zip(('dX', 'dX2', 'dls', 'dvar'), ops.gram_bwd('rbf', _t(X), _t(X2), _t(ls), _t(var), True, _t(dK))))
+    for key, n in (('dX', 'X'), ('dX2', 'X2'), ('dls', 'ls'), ('dvar', 'var')):
+        assert np.allclose(g[key].cpu().numpy().reshape(lv[n].grad.shape), lv[n].grad.numpy(), rtol=1e-9, atol=1e-11), key
+    # square Gram (both roles flow into dX), non-ARD length-scale, Matern
+    k2 = O.Matern32(Q, ARD=False)
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=X, ls=ls[:, :1], var=var).items()}
+    dKs = rng.randn(1, 33, 33)
+    (k2.K(lv['X'], matern32_lengthscale=lv['ls'], matern32_variance=lv['var']) * O.T(dKs)).sum().backward()
+    g = dict(zip(('dX', 'dX2', 'dls', 'dvar'), ops.gram_bwd('matern32', _t(X), None, _t(ls[:, :1]), _t(var), False, _t(dKs))))
+    for key, n in (('dX', 'X'), ('dls', 'ls'), ('dvar', 'var')):
+        assert np.allclose(g[key].cpu().numpy().reshape(lv[n].grad.shape), lv[n].grad.numpy(), rtol=1e-9, atol=1e-10), key
+    # SVGP bound with Q = 20 inputs and P = 11 outputs through the module path (column blocks of 8 + 3)
+    from mxfusion_amd.modules.gp_modules._fused import SVGPLogPdfFn
+    B, M, P = 40, 6, 11
+    Xs, Y, Z = rng.rand(2, B, Q), rng.rand(1, B, P), rng.rand(1, M, Q)
+    qm, qW, qd, noise = rng.randn(1, M, P) * 0.1, rng.randn(1, M, M) * 0.05, rng.rand(1, M) + 0.5, np.array([[0.1]])
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=Xs, Z=Z, qm=qm, qW=qW, qd=qd, ls=ls, noise=noise).items()}
+    ref = O.svgp_log_pdf(k, lv['X'], O.T(Y), lv['Z'], lv['noise'], lv['qm'], lv['qW'], lv['qd'], {'rbf_lengthscale': lv['ls'], 'rbf_variance': O.T(var)},
+                         jitter=1e-6)
+    ref.mean().backward()
+    dv = {n: _t(v).requires_grad_(True) for n, v in dict(X=Xs, Z=Z, qm=qm, qW=qW, qd=qd, ls=ls, noise=noise).items()}
+    total = 0
+    for p0 in range(0, P, 8):
+        sl = slice(p0, min(p0 + 8, P))
+        total = total + SVGPLogPdfFn.apply('rbf', True, 1e-6, 1.0, dv['X'], _t(Y[..., sl]), dv['Z'], dv['noise'], dv['qm'][..., sl], dv['qW'], dv['qd'],
+                                           dv['ls'], _t(var))[0]
+    assert np.allclose(total.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-9)
+    total.mean().backward()
+    for n in lv:
+        assert np.allclose(dv[n].grad.cpu().numpy(), lv[n].grad.numpy(), rtol=1e-7, atol=1e-9 * float(lv[n].grad.abs().max())), n
 
 
 def test_nan_input_is_reported_not_hidden():

@@ -53,7 +53,11 @@ def test_gemm_f32x3_is_f32_accurate(M, N, K, lower):
 
 
 @pytest.mark.parametrize('M,N,K,lower', [(128, 128, 16, False), (256, 384, 1024, False), (130, 70, 50, False), (1, 5, 7, False),
-                                          (1024, 1024, 4096, True), (300, 300, 333, True), (512, 8192, 512, False)])
+                                          (1024, 1024, 4096, True), (300, 300, 333, True), (512, 8192, 512, False),
+                                          # the 128 x 256 kernel (M % 128 == 0, N % 256 == 0): one, odd and even k-block counts, split-K,
+                                          # lower-only with rectangular tiles on the diagonal
+                                          (128, 256, 16, False), (128, 256, 48, False), (256, 512, 1040, False), (384, 768, 2064, False),
+                                          (1024, 1024, 80, True), (256, 256, 100000, True), (128, 512, 70000, False)])
 @pytest.mark.parametrize('mag', [1.0, 3e-6, 7e5])
 def test_gemm_f16x2_is_f32_accurate(M, N, K, lower, mag):
     """mxf_gemm_f16x2 (two power-of-two-scaled f16 terms per operand, three f16 MFMA products, f32 accumulate): error against float64

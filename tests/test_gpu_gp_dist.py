@@ -138,3 +138,67 @@ def test_cond_gp_dist_log_pdf_draws_and_gradients(D, S, with_means):
         ref_d = O.cond_gp_dist_draw(O.RBF(2, ARD=True), O.T(X), O.T(Xc), O.T(Yc), {'rbf_lengthscale': O.T(ls), 'rbf_variance': O.T(var)},
                                     O.T(eps), mean=om, mean_cond=omc)
     _close(draws, ref_d, 1e-8)
+
+
+def test_reverse_mode_cholesky_matches_torch():
+    """_linalg.CholFn (mxf_potrf + the closed-form reverse mode through mxf_trtri / mxf_gemm) against torch.linalg.cholesky's autograd on
+    the CPU, with a gradient seed that also has upper-triangle entries (ignored: L is lower)."""
+    from mxfusion_amd.components.distributions.gp._linalg import CholFn
+    rng = np.random.RandomState(0)
+    S, N = 3, 37
+    A = rng.randn(S, N, N)
+    K = A @ np.swapaxes(A, 1, 2) / N + np.eye(N) * 0.5
+    W = rng.randn(S, N, N)
+    Kd = _t(K).requires_grad_(True)
+    L, info = CholFn.apply(Kd)
+    (L * _t(W)).sum().backward()
+    Kc = O.T(K).clone().requires_grad_(True)
+    (torch.linalg.cholesky(Kc) * O.T(W)).sum().backward()
+    assert int(info.abs().sum()) == 0
+    ref = 0.5 * (Kc.grad + Kc.grad.transpose(-1, -2))             # torch returns a symmetrised gradient as well; compare the symmetric parts
+    got = 0.5 * (Kd.grad + Kd.grad.transpose(-1, -2))
+    _close(got, ref, 1e-9)
+
+
+@pytest.mark.parametrize('S', [1, 3])
+def test_gp_and_cond_gp_draws_are_differentiable(S):
+    """The reparameterised draws L eps of gp.py:124-153 / cond_gp.py:185-223 keep their gradients w.r.t. the inputs and the kernel parameters
+    (the reference differentiates through linalg.potrf): oracle autograd on the same injected noise."""
+    from mxfusion_amd import Variable
+    from mxfusion_amd.components.distributions import GaussianProcess, ConditionalGaussianProcess
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    rng = np.random.RandomState(20 + S)
+    N, Nc, D = 6, 8, 2
+    X, Xc, Yc = rng.rand(1, N, 2), rng.rand(1, Nc, 2), rng.randn(1, Nc, D)
+    ls, var = rng.rand(1, 2) * 0.3 + 0.3, rng.rand(1, 1) + 0.5
+    eps, w = rng.randn(S, N, D), rng.randn(S, N, D)
+    rbf = RBF(2, True, 1., 1., 'rbf', None, DT)
+    # GaussianProcess
+    gp = GaussianProcess.define_variable(X=Variable(shape=(N, 2)), kernel=rbf, shape=(N, D), dtype=DT,
+                                         rand_gen=MockRandomGenerator(_t(eps.reshape(-1)))).factor
+    dev = {n: _t(v).requires_grad_(True) for n, v in dict(X=X, ls=ls, var=var).items()}
+    got = gp.draw_samples(F=None, variables={gp.X.uuid: dev['X'], gp.rbf_lengthscale.uuid: dev['ls'], gp.rbf_variance.uuid: dev['var']},
+                          num_samples=S)
+    (got * _t(w)).sum().backward()
+    ora = {n: O.T(v).clone().requires_grad_(True) for n, v in dict(X=X, ls=ls, var=var).items()}
+    ref = O.gp_dist_draw(O.RBF(2, ARD=True), ora['X'], {'rbf_lengthscale': ora['ls'], 'rbf_variance': ora['var']}, O.T(eps))
+    (ref * O.T(w)).sum().backward()
+    _close(got, ref, 1e-9)
+    for n in ('X', 'ls', 'var'):
+        _close(dev[n].grad, ora[n].grad, 1e-6)
+    # ConditionalGaussianProcess
+    cgp = ConditionalGaussianProcess.define_variable(X=Variable(shape=(N, 2)), X_cond=Variable(shape=(Nc, 2)), Y_cond=Variable(shape=(Nc, D)),
+                                                     kernel=rbf, shape=(N, D), dtype=DT, rand_gen=MockRandomGenerator(_t(eps.reshape(-1)))).factor
+    vals = dict(X=X, Xc=Xc, Yc=Yc, ls=ls, var=var)
+    dev = {n: _t(v).requires_grad_(True) for n, v in vals.items()}
+    got = cgp.draw_samples(F=None, variables={cgp.X.uuid: dev['X'], cgp.X_cond.uuid: dev['Xc'], cgp.Y_cond.uuid: dev['Yc'],
+                                              cgp.rbf_lengthscale.uuid: dev['ls'], cgp.rbf_variance.uuid: dev['var']}, num_samples=S)
+    (got * _t(w)).sum().backward()
+    ora = {n: O.T(v).clone().requires_grad_(True) for n, v in vals.items()}
+    ref = O.cond_gp_dist_draw(O.RBF(2, ARD=True), ora['X'], ora['Xc'], ora['Yc'], {'rbf_lengthscale': ora['ls'], 'rbf_variance': ora['var']},
+                              O.T(eps))
+    (ref * O.T(w)).sum().backward()
+    _close(got, ref, 1e-8)
+    for n in vals:
+        _close(dev[n].grad, ora[n].grad, 1e-5)
