@@ -76,6 +76,79 @@ def build(N, Q, M, S_local, dtype, X, Y, Z, distributed, use_graph=False):
     return m, q, infr, loop, qX
 
 
+def build_minibatch(N, Q, M, B, S_local, dtype, Z, prior_var=1e-2):
+    """BASELINE.json configs[3]: the SVGP config with minibatches of B rows (rv_scaling = N / B) and the MC samples sharded over the GPUs.
+    Minibatches and per-row latent inputs are compatible in MXFusion's API when every factor is a sum over rows: X ~ N(Xobs, s) row-wise,
+    Y ~ SVGP(X), q(X) = N(Xobs, v) with ONE shared variance parameter (the minibatch loop slices the observed rows Xobs, Y and scales all
+    three factors by N / B).  S_local samples of X per step and rank."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.models.posterior import Posterior
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, StochasticVariationalInference, DistributedMinibatchInferenceLoop
+    m = Model()
+    m.N = Variable()
+    m.Xobs = Variable(shape=(m.N, Q))
+    m.X = Normal.define_variable(mean=m.Xobs, variance=prior_var, shape=(m.N, Q), dtype=dtype)
+    m.Z = Variable(shape=(M, Q), initial_value=Z)
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    kernel = RBF(input_dim=Q, ARD=True, variance=1., lengthscale=np.ones(Q), dtype=dtype)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=dtype)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    q = Posterior(m)
+    q.qx_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=1e-2)
+    q[m.X].set_prior(Normal(mean=q[m.Xobs], variance=q.qx_var, dtype=dtype))
+    loop = DistributedMinibatchInferenceLoop(batch_size=B, rv_scaling={m.Y: N / B, m.X: N / B})
+    infr = GradBasedInference(StochasticVariationalInference(model=m, posterior=q, num_samples=S_local, observed=[m.Xobs, m.Y]), grad_loop=loop,
+                              dtype=dtype)
+    infr.initialize(Xobs=(B, Q), Y=(B, 1))
+    post = gp._extra_graphs[0]
+    dev = infr.mxnet_context
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    infr.params[post.qU_mean] = torch.zeros(M, 1, dtype=td, device=dev)
+    infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td, device=dev)
+    infr.params[post.qU_cov_diag] = torch.ones(M, dtype=td, device=dev)
+    return m, infr, loop
+
+
+def time_minibatch_steps(infr, loop, Xd, Yd, B, steps, warmup, lr, distributed):
+    """One step = one minibatch: slice B rows of a fixed shuffle (the same on every rank), forward + reverse mode on this rank's MC samples,
+    gradient all-reduce, Trainer.step(batch_size=B)."""
+    import torch.distributed as dist
+    executor = infr.create_executor()
+    trainer = loop._make_trainer(infr.params, lr, 'adam')
+    N = Xd.shape[0]
+    perm = torch.randperm(N, device=Xd.device, generator=torch.Generator(device=Xd.device).manual_seed(99))
+    nb = N // B
+
+    def one(i):
+        sel = perm[(i % nb) * B:(i % nb + 1) * B]
+        loss = loop.step(executor, [Xd[sel], Yd[sel]], infr.params)
+        trainer.step(batch_size=B)
+        return loss
+    loss = None
+    for i in range(warmup):
+        loss = one(i)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(warmup + i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(loss.detach())
+
+
 def build_deepgp(N, Q, M, Dh, S_local, dtype, X, Y, distributed):
     """BASELINE.json configs[4]: two chained SVGPRegression modules, first layer Matern52 + RBF (AddKernel), hidden layer H (N x Dh) with a
     mean-field q(H), second layer RBF-ARD on the sampled H.  Built purely from the API."""
@@ -438,6 +511,7 @@ def main():
     ap.add_argument('--samples', type=int, default=32)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp', 'pilco'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
+    ap.add_argument('--minibatch', type=int, default=0, help="svgp workload: minibatch size (0 = full batch = configs[2]; 8192 = configs[3])")
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--horizon', type=int, default=100, help='time steps of the PILCO rollout workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
@@ -519,6 +593,26 @@ def main():
         return
     N, Q, M = args.N, args.Q, args.M
     X, Y, Z = synth(N, Q, M)
+    if args.minibatch:          # BASELINE.json configs[3]: minibatch x sample sharding
+        B = args.minibatch
+        td = torch.float32 if args.dtype == 'float32' else torch.float64
+        m, infr, loop = build_minibatch(N, Q, M, B, S_local, args.dtype, Z)
+        dt, last_loss = time_minibatch_steps(infr, loop, torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda(), B, args.steps,
+                                             args.warmup, args.lr, distributed)
+        if rank == 0:
+            emit({"metric": "ELBO-steps/sec (minibatch steps), SVGP N=65k D=8 M=1024 minibatch=%d (BASELINE.json configs[3])" % B,
+                  "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                  "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
+                  "config": {"workload": "SVGPRegression RBF-ARD N=%d Q=%d M=%d, uncertain inputs X ~ N(Xobs, 1e-2), q(X) = N(Xobs, v), minibatch %d "
+                                         "(rv_scaling %g), %d MC samples, step = minibatch ELBO + reverse mode + grad all-reduce + Adam"
+                                         % (N, Q, M, B, N / B, args.samples),
+                             "samples_per_gpu": S_local, "parallelism": "mc-samples sharded x%d, 1 RCCL all-reduce of the flat gradient/step" % world},
+                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())})
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed, use_graph=args.graph)
     td = torch.float32 if args.dtype == 'float32' else torch.float64
     Yd = torch.as_tensor(Y, dtype=td).cuda()

@@ -634,18 +634,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
                                       (int64_t)pl_big, gscr0, sd_, split_mode);
         if (rc) return rc;
-        // ordering for bandwidth only (the Kfu planes are written next to Psi2 rather than next to the Kuf planes); skipped while the
-        // step is being captured into a hipGraph: a dependency between the two forked streams crashes hipStreamEndCapture (ROCm 7.0)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        if (cap == hipStreamCaptureStatusNone) {
-            MXF_HIP(h, hipEventRecord(h->ev_aux2, sd_));
-            MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
-        }
-        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
-                                      (int64_t)pl_big, gscr1, s2_, split_mode);
-        if (rc) return rc;
-        MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes ready: the T GEMM waits for it
+        // (the Kfu planes -- operand (n, k = m) of the T GEMM -- are written later, on the second side stream, once w = Kuu^-1 mu exists:
+        //  the same pass then also forms the row U = w^T Kuf)
     } else {
         rc = mxf_gram(h, kind, dtype, 1, M, SB, Q, Z, 0, X, 0, ls, ard, 0, var, 0, nullptr, 0, 0.0, MXF_WRITE, Kuf, SB, 0, sd_);          // Kuf_all = k(Z, X_all) :73
         if (rc) return rc;
@@ -701,6 +691,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+    hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
+    if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w ready: the Kfu planes + U pass may start
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
@@ -716,6 +708,15 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     }
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
+    if (use_split) {
+        // Kfu planes (operand (n, k = m) of the T GEMM) + the row U = w^T Kuf in ONE pass, behind the Su chain on the second side stream:
+        // HBM-write bound, it runs next to the MFMA-bound Psi2 product
+        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
+        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
+                                      (int64_t)pl_big, gscr1, s2_, split_mode, (const float*)wT, P, (float*)(Text + M * SB), SB);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes and U ready: the T GEMM / the reverse pass wait for it
+    }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su formed (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
@@ -726,7 +727,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // A_ext = [H0 ; w^T] in the streaming dtype
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
     hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
-    hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);
 
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
@@ -745,18 +745,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
     if (use_split) {
-        dim3 gu((unsigned)((SB + 255) / 256));
-#define WT_GO(PTV)                                                                                                                              \
-        do {                                                                                                                               \
-            if (split_mode == MXF_SPLIT_F16X2)                                                                                             \
-                hipLaunchKernelGGL((wt_planes_kernel<PTV, 2>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, \
-                                   (const float*)wT, (float*)(Text + M * SB), (const float*)var);                                         \
-            else                                                                                                                           \
-                hipLaunchKernelGGL((wt_planes_kernel<PTV, 3>), gu, dim3(256), 0, st, M, SB, P, (const unsigned short*)plKfu, (int64_t)pl_big, \
-                                   (const float*)wT, (float*)(Text + M * SB), (const float*)var);                                         \
-        } while (0)
-        if (P == 1) WT_GO(1); else WT_GO(8);
-#undef WT_GO
+        // (U = w^T Kuf was written by the Kfu planes pass)
     } else {
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));

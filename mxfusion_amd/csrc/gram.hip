@@ -407,12 +407,20 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
 typedef unsigned int gp_u32x4 __attribute__((ext_vector_type(4)));
 // NP = 2 (f16x2 format of gemm_split.hip): the planes hold cov / variance * 2^14 as hi + lo (f16 each); the consumer multiplies by
 // variance * 2^-14 (unit-variance covariances are <= 1, so the format's power-of-two scale is known without a reduction).
-template <int QT, int KIND, int NP>
+// PT > 0: the same pass also forms  U[p][r] = sum_k w[k][p] cov(xmin[r], xmaj[k])  (the row w^T Kuf of the SVGP step, svgp_regression.py:98:
+// Kuf^T Kuu^-1 mu) from the f32 covariances it has in registers -- the separate 8.6 GB read of the planes that product used to cost
+// (1.45 ms at the bench size) is gone.  Needs grid.y == 1 (every block walks all k blocks of its rows).
+template <int QT, int KIND, int NP, int PT>
 __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                           const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
-                                                          int chunks_per_block) {
+                                                          int chunks_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
+                                                          int64_t ldU) {
     constexpr int CH = 16;                                   // k blocks per staged chunk (256 major points)
     __shared__ __attribute__((aligned(16))) float xs[CH * 16 * QT];
+    __shared__ float ws[PT > 0 ? CH * 16 * PT : 1];          // w of the staged chunk, [k][p]
+    float uacc[PT > 0 ? PT : 1];
+#pragma unroll
+    for (int p = 0; p < (PT > 0 ? PT : 1); ++p) uacc[p] = 0.f;
     const int tid = threadIdx.x, rl = tid >> 1, half = tid & 1;
     const int64_t r = (int64_t)blockIdx.x * 128 + rl;
     const bool rvalid = r < R;
@@ -427,6 +435,13 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
         __syncthreads();
         for (int i = tid * 4; i < CH * 16 * QT; i += 256 * 4)
             *reinterpret_cast<f32x4_t*>(&xs[i]) = *reinterpret_cast<const f32x4_t*>(Xmaj_s + kb0 * 16 * QT + i);                   // padded
+        if (PT > 0) {
+            for (int i = tid; i < CH * 16 * PT; i += 256) {
+                const int64_t k = kb0 * 16 + i / PT;
+                const int p = i % PT;
+                ws[i] = (k < Kn && p < Pw) ? wk[k * Pw + p] : 0.f;
+            }
+        }
         __syncthreads();
         const int nkb = (int)((K16 - kb0) < CH ? (K16 - kb0) : CH);
         for (int kbl = 0; kbl < nkb; ++kbl) {
@@ -448,6 +463,10 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
                     }
                     const float red = acc2.x + acc2.y;
                     kv[e] = (kb0 * 16 + nl < Kn) ? cov_from<float, KIND>(red, variance) : 0.f;
+                    if (PT > 0) {
+#pragma unroll
+                        for (int p = 0; p < PT; ++p) uacc[p] = fmaf(ws[nl * PT + p], kv[e], uacc[p]);
+                    }
                 }
                 unsigned hh = 0, mm = 0, ll = 0;
 #pragma unroll
@@ -478,11 +497,20 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
             }
         }
     }
+    if (PT > 0) {      // the two threads of a row hold the two k halves: fold them, undo the plane scaling, one store per (row, p)
+        const float sc = NP == 2 ? var[0] * (1.f / 16384.f) : 1.f;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float v = uacc[p] + __shfl_xor(uacc[p], 1, 64);
+            if (half == 0 && rvalid && p < Pw) U[(int64_t)p * ldU + r] = v * sc;
+        }
+    }
 }
 
 template <int KIND>
 int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
-                     const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode) {
+                     const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode,
+                     const float* wk, int Pw, float* U, int64_t ldU) {
     const int QT = Q <= 8 ? 8 : 16;
     const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
     float* buf = scratch;     // (padr + padk) * QT floats, caller-owned: two of these run concurrently on different streams
@@ -490,6 +518,11 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     const int64_t K16 = (Kn + 15) / 16, chunks = (K16 + 15) / 16, rblocks = padr / 128;
     int cpb = 1;
     while (rblocks * ((chunks + cpb - 1) / cpb) > 16384 && cpb < chunks) cpb *= 2;      // fewer, longer blocks once the chip is full
+    const bool fuse_u = U != nullptr;
+    if (fuse_u) {
+        if (Pw > 8 || !wk) MXF_FAIL(h, -3, "gram planes: fused w^T K needs w and P <= 8");
+        cpb = (int)chunks;                                                              // every block walks all k blocks of its rows
+    }
     dim3 grid((unsigned)rblocks, (unsigned)((chunks + cpb - 1) / cpb));
     if (grid.y > 65535u) MXF_FAIL(h, -3, "gram planes: grid too large");
 #define GO(QTV)                                                                                                                       \
@@ -498,10 +531,18 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
                            (int64_t)0, ard, R, Q, padr, buf);                                                                         \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
                            (int64_t)0, ard, Kn, Q, padk, bmaj);                                                                       \
-        if (mode == MXF_SPLIT_F16X2)                                                                                                  \
-            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
+        if (mode == MXF_SPLIT_F16X2 && fuse_u && Pw == 1)                                                                             \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2, 1>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
+        else if (mode == MXF_SPLIT_F16X2 && fuse_u)                                                                                   \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2, 8>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
+        else if (mode == MXF_SPLIT_F16X2)                                                                                             \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2, 0>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
+        else if (fuse_u && Pw == 1)                                                                                                   \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 3, 1>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
+        else if (fuse_u)                                                                                                              \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 3, 8>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
         else                                                                                                                          \
-            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 3>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb); \
+            hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 3, 0>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
     } while (0)
     if (QT == 8) GO(8); else GO(16);
 #undef GO
@@ -569,15 +610,16 @@ size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q) {
 }
 
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
-                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode) {
+                             int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode,
+                             const float* wk, int Pw, float* U, int64_t ldU) {
     if (R <= 0 || Kn <= 0) return 0;
     if (!scratch) MXF_FAIL(h, -2, "gram planes: scratch of mxf_gram_planes_scratch_bytes() bytes required");
     if (Q > 16) MXF_FAIL(h, -3, "gram planes: Q > 16 not supported");
     switch (kind) {
-        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
-        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
-        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
-        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode);
+        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
+        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
+        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
+        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
     }
     MXF_FAIL(h, -2, "gram planes: stationary kernels only (kind %d)", kind);
 }
