@@ -410,12 +410,21 @@ def gram_roofline(N, Q, dtype, reps=10):
     nbytes = (N * N + 2 * N * Q) * out.element_size()
     del out
     torch.cuda.empty_cache()
-    # HBM bytes per launch from the PMC passes (WRITE_SIZE*1024 + 2*FETCH_SIZE*1024, separate rocprofv3 --pmc runs of exactly this
-    # launch; profiles/r01_gram_pmc.txt).  Only collected for the headline shape / dtype.
-    traffic = 17201975722 if (N == 65536 and Q == 8 and dtype == 'float32') else None
-    return {"bound": "hbm", "kernel": "gram_kernel<%s,8,RBF> N=%d Q=%d" % (dtype, N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
-            "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic, "ms_per_launch": ms, "algorithmic_bytes": nbytes,
-            "write_only_ceiling_GBps": 6080.0}
+    # HBM bytes per launch from the PMC passes of exactly this launch (separate rocprofv3 --pmc runs, WRITE_SIZE * 1024 + 2 * FETCH_SIZE *
+    # 1024 as MI355X_MICROARCH.md prescribes for gfx950): read from the committed summary profiles/r02_gram_pmc.json (produced by
+    # profiles/run_profiles_r02.sh + profiles/pmc_summary.py); only collected for the headline shape / dtype.  null if the file is absent.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, 'profiles', 'r02_gram_pmc.json')
+    if N == 65536 and Q == 8 and dtype == 'float32' and os.path.exists(pmc):
+        with open(pmc) as f:
+            pj = json.load(f)
+        if 'hbm_traffic_bytes_per_launch' in pj:
+            traffic, traffic_src = int(pj['hbm_traffic_bytes_per_launch']), 'profiles/r02_gram_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)'
+    return {"bound": "hbm", "kernel": "gram_lean_kernel<%s,8,RBF> N=%d Q=%d" % (dtype, N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": ms,
+            "algorithmic_bytes": nbytes, "write_only_pattern_ceiling_GBps": 6930.0,
+            "ceiling_note": "fastest pure-store pattern measured on this part (tests/probes/gram_variants.hip, one row per workgroup): "
+                            "6.93 TB/s; hipMemsetAsync 6.15 TB/s"}
 
 
 def mfma_roofline(M, SB, dtype, reps=3):
@@ -453,6 +462,31 @@ def mfma_roofline(M, SB, dtype, reps=3):
          "traffic": None, "ms_per_launch": ms, "algorithmic_flops": fl}
     r.update(extra)
     return r
+
+
+def mfma_roofline_psi2(M, SB, reps=3):
+    """The second MFMA kernel of the float32 step: Psi2 = Kuf Kuf^T (M x M x SB, lower blocks only) on gemm_f16x2_wide_kernel (128 x 256
+    tiles, B fragments straight from global memory).  Flops counted for the lower triangle incl. the diagonal blocks it computes in full."""
+    from mxfusion_amd import ops
+    C = torch.rand(M, SB, device='cuda')
+    pc = ops.f16x2_split(C)
+    del C
+    psi = torch.zeros(M, M, device='cuda')
+    run = lambda: ops.gemm_f16x2_planes(pc, pc, M, M, SB, out=psi, lower_only=True)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    torch.cuda.empty_cache()
+    fl = 2.0 * (M * (M + 1) / 2.0) * SB
+    return {"bound": "mfma", "kernel": "gemm_f16x2_wide_kernel (lower blocks, split-K) %dx%dx%d" % (M, M, SB), "achieved": fl / ms / 1e9,
+            "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / (2500.0 / 3.0), "traffic": None, "ms_per_launch": ms,
+            "algorithmic_flops": fl}
 
 
 def cpu_baseline(N, Q, M, S, X, Y, Z):
@@ -636,6 +670,8 @@ def main():
         torch.cuda.empty_cache()
         out["roofline"] = gram_roofline(N, Q, args.dtype)
         out["roofline_mfma"] = mfma_roofline(M, N * S_local, args.dtype)
+        if args.dtype == 'float32':
+            out["roofline_mfma_psi2"] = mfma_roofline_psi2(M, N * S_local)
         other = 'float64' if args.dtype == 'float32' else 'float32'
         out["roofline_" + ("f64" if other == 'float64' else "f32")] = gram_roofline(N, Q, other)
         # the same step in the other precision (f64 = the parity precision of the reference's tests), plus the
@@ -648,19 +684,31 @@ def main():
         del infr2, m2, q2
         torch.cuda.empty_cache()
         from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
-        vals = {}
         eps64 = torch.randn(4, N, Q, dtype=torch.float64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
-        for dname in ('float32', 'float64'):
-            tdd = torch.float32 if dname == 'float32' else torch.float64
-            mm, qq, ii, ll, qx = build(N, Q, M, 4, dname, X, Y, Z, False)
-            qx._rand_gen = MockRandomGenerator(eps64.to(tdd))     # identical injected noise in both precisions
-            ex = ii.create_executor()
-            # evaluated WITH the reverse mode requested: that is the call the timed step makes (float32: Grams as split planes, both big
-            # GEMMs on the f16 matrix pipe); the forward-only call would run the plain f32-MFMA kernels instead
-            vals[dname] = float(ex(torch.as_tensor(Y, dtype=tdd).cuda())[0].detach())
-            del mm, qq, ii, ex
-            torch.cuda.empty_cache()
-        out["elbo_f32_vs_f64_rel"] = abs(vals['float32'] - vals['float64']) / abs(vals['float64'])
+        rngq = np.random.default_rng(11)
+        qm_t, qW_t, qd_t = 0.3 * rngq.standard_normal((M, 1)), 0.4 * rngq.standard_normal((M, M)) / math.sqrt(M), rngq.uniform(0.05, 0.5, M)
+        for key, trained in (("elbo_f32_vs_f64_rel", False), ("elbo_f32_vs_f64_rel_trained_like", True)):
+            # the initial parameters of the timed run (length-scale 1: Kuu ~ I), and a trained-like set -- length-scale 2.2 (where a 300-step
+            # optimisation of this model ends, tests/probes/train_probe.py; cond(Kuu + 1e-6 I) ~ 1.4e3), noise 0.02, a non-trivial q(u)
+            vals = {}
+            for dname in ('float32', 'float64'):
+                tdd = torch.float32 if dname == 'float32' else torch.float64
+                mm, qq, ii, ll, qx = build(N, Q, M, 4, dname, X, Y, Z, False)
+                if trained:
+                    gp_ = mm.Y.factor
+                    post_ = gp_._extra_graphs[0]
+                    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=tdd).cuda()
+                    ii.params[gp_.kernel.lengthscale] = tt(np.full(Q, 2.2))
+                    ii.params[mm.noise_var] = tt([0.02])
+                    ii.params[post_.qU_mean], ii.params[post_.qU_cov_W], ii.params[post_.qU_cov_diag] = tt(qm_t), tt(qW_t), tt(qd_t)
+                qx._rand_gen = MockRandomGenerator(eps64.to(tdd))     # identical injected noise in both precisions
+                ex = ii.create_executor()
+                # evaluated WITH the reverse mode requested: that is the call the timed step makes (float32: Grams as split planes, both big
+                # GEMMs on the f16 matrix pipe); the forward-only call would run the plain f32-MFMA kernels instead
+                vals[dname] = float(ex(torch.as_tensor(Y, dtype=tdd).cuda())[0].detach())
+                del mm, qq, ii, ex
+                torch.cuda.empty_cache()
+            out[key] = abs(vals['float32'] - vals['float64']) / abs(vals['float64'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, Q, M, args.samples, X, Y, Z)
     if rank == 0:

@@ -52,6 +52,12 @@ int64_t mxf_workspace_bytes(mxf_handle h);
  * inside a stream capture); a caller that captured launches into a hipGraph must re-capture when this number has changed, because the
  * captured kernels carry the old scratch addresses.  (The reference has no counterpart: MXNet owns its temporaries.) */
 int64_t mxf_workspace_generation(mxf_handle h);
+/* 1-norm condition number |Kuu + jitter I|_1 |(Kuu + jitter I)^-1|_1 of the last mxf_svgp_logpdf training call on this handle (both norms
+ * are computed on the device next to the factorisation; this call copies them to the host, i.e. it synchronises).  The float32 streaming
+ * form of the bound applies H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1 explicitly, so its rounding error grows like cond * 2^-24: measured ELBO
+ * agreement with float64 is 3e-6 at cond 1.4e3 and 2e-3 at 5e4 (tests/probes/f32_accuracy.py) -- above ~3e3 use float64.  0 if there was
+ * no such call.  (No reference counterpart: svgp_regression.py:83-92 solves with the Cholesky factor, in whatever dtype the model has.) */
+int mxf_svgp_last_cond(mxf_handle h, double* cond1_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Gram build.  Replaces Kernel.K -> _compute_K (kernels/kernel.py:96-123), i.e.

@@ -50,6 +50,7 @@ SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_sgp_logpdf': [_i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i,
                        _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'mxf_svgp_last_cond': [_c.POINTER(_d)],
 }
 PLAIN = {  # entry points without the (handle, ...) -> int shape
     'mxf_version': ([], _i),
@@ -115,6 +116,14 @@ def workspace_generation(device_index):
     """Re-allocation count of the (thread, device) handle's scratch (mxf_workspace_generation): hipGraph holders compare it before a
     replay -- a captured launch carries the scratch addresses of capture time."""
     return int(load().mxf_workspace_generation(handle(device_index)))
+
+
+def svgp_last_cond(device_index):
+    """1-norm condition number of Kuu + jitter I of the last SVGP training call on this (thread, device) handle (mxf_svgp_last_cond;
+    synchronises)."""
+    out = _d(0.0)
+    call('mxf_svgp_last_cond', handle(device_index), ctypes.byref(out))
+    return float(out.value)
 
 
 def call(name, h, *args):

@@ -20,6 +20,7 @@ struct mxf_ctx {
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
+    double* cond_dev = nullptr; // [ |Kuu + jitter I|_1, |(Kuu + jitter I)^-1|_1 ] of the last SVGP training call (mxf_svgp_last_cond)
     int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
     unsigned flag_cursor = 0;
 };

@@ -518,6 +518,17 @@ __global__ void svgp_het_finalize_kernel(int S, int64_t M, int P, const double* 
     if (dvar_direct) dvar_direct[0] = -0.5 * a1 * sb;
 }
 
+// |A|_1 of a symmetric (n x n) float64 matrix: max over rows of the absolute row sum (= column sum), into *out as a double (non-negative
+// doubles order like unsigned 64-bit integers: one atomicMax per workgroup; *out must be zeroed)
+__global__ __launch_bounds__(256) void norm1_sym_kernel(int64_t n, const double* __restrict__ A, int64_t lda, double* __restrict__ out) {
+    __shared__ double red[16];
+    const int64_t row = blockIdx.x;
+    double s = 0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) s += fabs(A[row * lda + j]);
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, s));
+}
+
 template <typename T>
 int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P, const T* X, int64_t sX, const T* Y,
                       int64_t sY, const T* Z, const T* noise, int64_t nrows, int ncols, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
@@ -681,12 +692,17 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
     }
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
+    // condition number of Kuu + jitter I (1-norm), for the float32 validity check of mxf_svgp_last_cond: |Kuu|_1 here, |Ki|_1 below
+    if (!h->cond_dev && hipMalloc((void**)&h->cond_dev, 2 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
+    MXF_HIP(h, hipMemsetAsync(h->cond_dev, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(norm1_sym_kernel, dim3((unsigned)M), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
+    hipLaunchKernelGGL(norm1_sym_kernel, dim3((unsigned)M), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;

@@ -20,6 +20,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->flags) (void)hipFree(h->flags);
+    if (h->cond_dev) (void)hipFree(h->cond_dev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
@@ -40,3 +41,13 @@ extern "C" const char* mxf_last_error(mxf_handle h) { return h ? h->err.c_str() 
 extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)(h->ws_bytes + h->gram_ws_bytes) : -1; }
 
 extern "C" int64_t mxf_workspace_generation(mxf_handle h) { return h ? h->ws_generation : -1; }
+
+extern "C" int mxf_svgp_last_cond(mxf_handle h, double* cond1_out) {
+    if (!h || !cond1_out) return -1;
+    *cond1_out = 0.0;
+    if (!h->cond_dev) return 0;                      // no SVGP training call on this handle yet
+    double v[2];
+    MXF_HIP(h, hipMemcpy(v, h->cond_dev, sizeof(v), hipMemcpyDeviceToHost));      // synchronises with the stream work that produced it
+    *cond1_out = v[0] * v[1];
+    return 0;
+}

@@ -525,6 +525,9 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     }
     dim3 grid((unsigned)rblocks, (unsigned)((chunks + cpb - 1) / cpb));
     if (grid.y > 65535u) MXF_FAIL(h, -3, "gram planes: grid too large");
+    // (measured and dropped: one-wave workgroups with lane <-> row and the k-side points through scalar loads, as in the Gram kernel -- each
+    //  store instruction then covers 16-byte pieces at a 32-byte stride and the step went from 30.1 to 40.0 ms; the (row, k half) <-> thread
+    //  mapping below writes whole lines per instruction)
 #define GO(QTV)                                                                                                                       \
     do {                                                                                                                              \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padr * QTV + 255) / 256), 1), dim3(256), 0, st, Xmin, (int64_t)0, ls, \

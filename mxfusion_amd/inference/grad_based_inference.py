@@ -30,11 +30,33 @@ class GradBasedInference(Inference):
             def update_shape_constants(data_batch):
                 shapes = {i: tuple(d.shape) for i, d in zip(self.observed_variable_UUIDs, data_batch)}
                 self.params.update_constants(discover_shape_constants(shapes, self._graphs))
-            return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
-                                       optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
-                                       update_shape_constants=update_shape_constants, generator=generator, permutations=permutations)
-        return self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
-                                   optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
+            out = self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
+                                      optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
+                                      update_shape_constants=update_shape_constants, generator=generator, permutations=permutations)
+        else:
+            out = self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
+                                      optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
+        self._check_float32_validity()
+        return out
+
+    F32_COND_LIMIT = 3e3
+
+    def _check_float32_validity(self):
+        """The float32 streaming form of the SVGP bound applies Kuu^-1 explicitly: its rounding error grows like cond(Kuu + jitter I) 2^-24
+        (ELBO agreement with float64: 3e-6 at cond 1.4e3, 2e-3 at 5e4).  After a float32 run, warn when the model has left that regime --
+        the reference's dtype switch (config.DEFAULT_DTYPE / dtype='float64') is the remedy, as in its own GP tests."""
+        if config.torch_dtype(self.dtype) != torch.float32 or not torch.cuda.is_available():
+            return
+        from ..modules.gp_modules.svgp_regression import SVGPRegression
+        if not any(isinstance(f, SVGPRegression) for g in self._graphs for f in getattr(g, '_factors', [])):
+            return
+        from .. import ops
+        cond = ops.svgp_last_cond(self.mxnet_context)
+        self.last_kuu_condition = cond
+        if cond > self.F32_COND_LIMIT:
+            import warnings
+            warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e after this float32 run: beyond ~%.0e the float32 streaming SVGP bound '
+                          'loses accuracy (error ~ cond * 2^-24); run the inference with dtype=\'float64\'.' % (cond, self.F32_COND_LIMIT))
 
 
 class GradTransferInference(GradBasedInference):

@@ -38,7 +38,7 @@ class SparseGPRegressionLogPdf(VariationalInference):
         kern_params = kern.fetch_parameters(variables)
         spec = kern.fused_spec()
         if spec is None:
-            raise NotImplementedError('SparseGPRegressionLogPdf on MI355X supports a single stationary kernel')
+            return self._compute_materialised(F, variables, X, Y, Z, noise_var, kern, kern_params)
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
@@ -53,6 +53,42 @@ class SparseGPRegressionLogPdf(VariationalInference):
             self.set_parameter(variables, self.graphs[1].wv, outs[0][1])
             self.set_parameter(variables, self.graphs[1].L, outs[0][2])
             self.set_parameter(variables, self.graphs[1].LA, outs[0][3])
+        return logL
+
+
+    def _compute_materialised(self, F, variables, X, Y, Z, noise_var, kern, kern_params):
+        """Combination kernels (Add / Multiply), Linear / Bias / White and kernels with active_dims have no fused description: the
+        reference's own operator sequence (sparsegp_regression.py:67-106) on materialised Kuu / Kuf / Kdiag from kern.K (one mxf_gram pass
+        per sub-kernel, each with its reverse mode), through the differentiable mxf_potrf / mxf_trsm / mxf_gemm bridges of _linalg."""
+        import math
+        if self.model.F.factor.has_mean:
+            Y = Y - variables[self.model.mean]
+        D, M = Y.shape[-1], Z.shape[-2]
+        eye = torch.eye(M, dtype=Z.dtype, device=Z.device).unsqueeze(0)
+        nv = noise_var.unsqueeze(-2)                                   # (S, 1, 1)
+        Kuu = kern.K(F, Z, **kern_params)
+        if self.jitter > 0.:
+            Kuu = Kuu + eye * self.jitter
+        Kuf = kern.K(F, Z, X, **kern_params)
+        Kff_diag = kern.Kdiag(F, X, **kern_params)
+        L, info = lin.chol(Kuu)                                        # :83
+        LinvKuf = lin.trsm(L, Kuf)                                     # :84
+        A = eye + lin.gemm(LinvKuf, LinvKuf, transB=True) / nv         # :86
+        LA, info2 = lin.chol(A)                                        # :87
+        LAInvLinvKufY = lin.trsm(LA, lin.gemm(LinvKuf, Y))             # :92
+        sumlog = torch.log(torch.diagonal(LA, dim1=-2, dim2=-1)).sum(-1)
+        logL = -D * sumlog                                                                                        # :94
+        logL = logL - ((Y ** 2) / nv + math.log(2 * math.pi) + torch.log(nv)).sum(-1).sum(-1) / 2               # :95
+        logL = logL + ((LAInvLinvKufY ** 2) / (2 * nv ** 2)).sum(-1).sum(-1)                                      # :96
+        logL = logL - D * (Kff_diag / (2 * noise_var)).sum(-1)                                                    # :97
+        logL = logL + D * ((LinvKuf ** 2) / (2. * nv)).sum(-1).sum(-1)                                            # :98
+        self._last_info = info + info2
+        with torch.no_grad():      # :99-106 persist sample 0 only
+            wv = ops.trsm_(L[:1].contiguous(), ops.trsm_(LA[:1].contiguous(), LAInvLinvKufY[:1].detach().contiguous().clone(), transpose=True),
+                           transpose=True) / nv[:1]
+            self.set_parameter(variables, self.graphs[1].wv, wv[0])
+            self.set_parameter(variables, self.graphs[1].L, L[0].detach())
+            self.set_parameter(variables, self.graphs[1].LA, LA[0].detach())
         return logL
 
 

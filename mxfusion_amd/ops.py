@@ -334,6 +334,13 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
     return out
 
 
+def svgp_last_cond(device=None):
+    """1-norm condition number of Kuu + jitter I seen by the last svgp_logpdf training call of this thread on `device` (mxf_svgp_last_cond;
+    synchronises).  The float32 streaming form is valid up to ~3e3 (include/mxf_gp.h)."""
+    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    return _lib.svgp_last_cond(idx)
+
+
 def svgp_logpdf_mat(Kuu, Kuf, Kdiag, Y, noise_var, qU_mean, qU_cov_W, qU_cov_diag, jitter=0.0, scaling=1.0, gscale=1.0, want_grad=False):
     """SVGP bound from materialised Grams: Kuu (M,M) without jitter, Kuf (M,B), Kdiag (B,), Y (B,P) or (S,B,P) [S samples of the outputs over
     the same inputs], noise_var (1,) | (P,) | (B,1) | (B,P).  Returns dict(logL (S,), info, and -- if want_grad -- dKuu, dKuf, dKdiag, dY,

@@ -1,0 +1,35 @@
+"""Aggregates rocprofv3 --pmc passes (…_counter_collection.csv, one directory per pass) for the dispatches of one kernel.
+usage: pmc_summary.py <kernel-name substring> <out.json> <dir> [<dir> ...]
+Writes {counter: {"mean", "min", "max", "n"}} (per-dispatch values summed over the counter's instances) and, for the Gram kernel, the HBM
+traffic per launch as MI355X_MICROARCH.md prescribes: WRITE_SIZE (KiB) * 1024 + 2 * FETCH_SIZE (KiB) * 1024 (gfx950: FETCH_SIZE reports half
+of the bytes of wide streaming reads)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main(pattern, out, dirs):
+    per = defaultdict(lambda: defaultdict(float))         # counter -> dispatch id -> value
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if pattern in r['Kernel_Name']:
+                    per[r['Counter_Name']][(f, r['Dispatch_Id'])] += float(r['Counter_Value'])
+    res = {}
+    for c, vals in per.items():
+        v = list(vals.values())
+        res[c] = {'mean': sum(v) / len(v), 'min': min(v), 'max': max(v), 'n': len(v)}
+    if 'WRITE_SIZE' in res and 'FETCH_SIZE' in res:
+        res['hbm_traffic_bytes_per_launch'] = res['WRITE_SIZE']['mean'] * 1024 + 2 * res['FETCH_SIZE']['mean'] * 1024
+    res['_kernel'] = pattern
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    for k in sorted(res):
+        print(k, res[k])
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])

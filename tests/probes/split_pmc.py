@@ -1,0 +1,25 @@
+"""One-kernel workloads for the PMC passes of the split GEMMs.  usage: split_pmc.py t|psi2 [SB]
+t: T = H0 Kuf shape (1024 x SB x 1024, 128 x 128 kernel); psi2: Kuf Kuf^T, lower blocks (1024 x 1024 x SB, 128 x 256 kernel).  3 launches."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+from mxfusion_amd import ops
+which = sys.argv[1]
+M, SB = 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 2097152
+if which == 't':
+    pa = ops.f16x2_split(torch.randn(M, M, device='cuda'))
+    B = torch.rand(SB, M, device='cuda')
+    pb = ops.f16x2_split(B)
+    del B
+    out = torch.empty(M, SB, device='cuda')
+    for _ in range(3):
+        ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out)
+else:
+    C = torch.rand(M, SB, device='cuda')
+    pc = ops.f16x2_split(C)
+    del C
+    psi = torch.zeros(M, M, device='cuda')
+    for _ in range(3):
+        ops.gemm_f16x2_planes(pc, pc, M, M, SB, out=psi, lower_only=True)
+torch.cuda.synchronize()

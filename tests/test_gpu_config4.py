@@ -70,7 +70,7 @@ def test_uncertain_input_svgp_minibatch_step_matches_oracle():
     ref = O.svi_uncertain_input_svgp_loss(O.RBF(Q, ARD=True), O.T(X[sel]), O.T(Y[sel]), lv, O.T(eps), prior_var=1e-2, jitter=1e-6,
                                           log_pdf_scaling=N / B)
     ref.backward()
-    assert abs(float(loss) - float(ref)) <= 1e-9 * abs(float(ref))
+    assert abs(float(loss) - float(ref.detach())) <= 1e-9 * abs(float(ref.detach()))
     P = infr.params
     g = P.flat.grad
     for var, name in ((q.qx_var, 'qx_var'), (m.noise_var, 'noise_var'), (kernel.lengthscale, 'lengthscale'), (kernel.variance, 'variance'),
@@ -122,3 +122,24 @@ def test_config4_shapes_scaling_linearity_and_f32_agreement():
         for k, tol in (('dX', 2e-4), ('dmu', 2e-4), ('dnoise', 2e-4), ('dZ', 5e-3), ('dls', 5e-3)):
             a, b = f[k].ravel(), r8[k].ravel()
             assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), (l, k, np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_float32_validity_guard_reports_the_condition_of_kuu():
+    """mxf_svgp_last_cond: the 1-norm condition number of Kuu + jitter I of the last training call, computed on the device next to the
+    factorisation -- equal to the float64 value formed with torch, below the float32 limit (3e3) at the initial and at the trained-like
+    length-scale, above it where the float32 streaming form is known to fail (tests/probes/f32_accuracy.py: ELBO error 2e-3 at 5e4)."""
+    from mxfusion_amd import ops
+    from mxfusion_amd.inference import GradBasedInference
+    B, Q, M, S = 2048, 8, 1024, 2
+    X, Y, Z, qm, qW, qd = _full_inputs(B, Q, M, S)
+    conds = {}
+    for l in (1.0, 2.2, 3.0):
+        _svgp(torch.float32, X, Y, Z, qm, qW, qd, np.full(Q, l), 1.0)
+        got = ops.svgp_last_cond()
+        Zt = torch.as_tensor(Z, dtype=torch.float64).cuda() / l
+        K = torch.exp(-0.5 * torch.cdist(Zt, Zt) ** 2) + 1e-6 * torch.eye(M, dtype=torch.float64, device='cuda')
+        ref = float(K.abs().sum(0).max() * torch.linalg.inv(K).abs().sum(0).max())
+        assert abs(got - ref) <= 1e-6 * ref, (l, got, ref)
+        conds[l] = got
+    lim = GradBasedInference.F32_COND_LIMIT
+    assert conds[1.0] < lim and conds[3.0] > lim, conds

@@ -81,3 +81,60 @@ def test_sgp_module_like_reference_tests(golden_dir):
             tag = ('nf' if nf else 'noisy') + ('_diag' if dg else '_full')
             assert np.allclose(res[0].cpu().numpy(), g['mu_' + tag], atol=1e-8), tag
             assert np.allclose(res[1].cpu().numpy(), g['var_' + tag], atol=1e-8), tag
+
+
+def test_sgp_with_a_combination_kernel_runs_the_materialised_path():
+    """SparseGPRegression with Matern52 + RBF (no fused description): the reference's operator sequence (sparsegp_regression.py:67-106) on
+    kern.K matrices through the differentiable potrf / trsm / gemm bridges -- loss and every gradient against the oracle, then prediction
+    from the stored posterior."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import SparseGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop, TransferInference, ModulePredictionAlgorithm
+    rng = np.random.RandomState(5)
+    N, Q, M, D = 50, 3, 7, 2
+    X, Y, Z, Xt = rng.uniform(-2, 2, (N, Q)), rng.randn(N, D), rng.uniform(-2, 2, (M, Q)), rng.uniform(-2, 2, (9, Q))
+    ls1, ls2, v1, v2, noise = np.array([1.3]), np.array([0.7]), np.array([0.9]), np.array([0.4]), np.array([0.2])
+    t64 = lambda a: _t(a, torch.float64)
+    kern = Matern52(Q, variance=t64(v1), lengthscale=t64(ls1), dtype='float64') + RBF(Q, variance=t64(v2), lengthscale=t64(ls2), dtype='float64')
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=t64(Z))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=t64(noise))
+    m.Y = SparseGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, D), dtype='float64')
+    m.Y.factor.sgp_log_pdf.jitter = 1e-6
+    grads, losses = [], []
+
+    class Rec(BatchInferenceLoop):
+        def step(self, ex, data, params):
+            loss = super(Rec, self).step(ex, data, params)
+            losses.append(float(loss.detach()))
+            return loss
+
+        def _exchange(self, param_dict):
+            grads.append(param_dict.flat.grad.clone())
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=Rec(), dtype='float64')
+    infr.run(X=t64(X), Y=t64(Y), max_iter=1, learning_rate=1e-9)
+    ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
+    sp = O.softplus
+    raw = {n: O.inv_softplus(O.T(v)).clone().requires_grad_(True) for n, v in dict(ls1=ls1, ls2=ls2, v1=v1, v2=v2, noise=noise).items()}
+    Zr = O.T(Z).clone().requires_grad_(True)
+    kp = lambda: {'add_matern52_lengthscale': sp(raw['ls1'])[None], 'add_matern52_variance': sp(raw['v1'])[None],
+                  'add_rbf_lengthscale': sp(raw['ls2'])[None], 'add_rbf_variance': sp(raw['v2'])[None]}
+    logL, post = O.sgp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], Zr[None], sp(raw['noise'])[None], kp(), jitter=1e-6, return_posterior=True)
+    (-logL.sum()).backward()
+    assert abs(losses[0] - float(-logL.sum())) <= 1e-9 * abs(float(logL.sum()))
+    P = infr.params
+    sub = {k.name: k for k in kern.sub_kernels}
+    for var, ref in ((m.noise_var, raw['noise'].grad), (sub['matern52'].lengthscale, raw['ls1'].grad), (sub['matern52'].variance, raw['v1'].grad),
+                     (sub['rbf'].lengthscale, raw['ls2'].grad), (sub['rbf'].variance, raw['v2'].grad), (m.Z, Zr.grad)):
+        o, n, _ = P._slices[var.uuid]
+        assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.numpy().ravel(), rtol=1e-7, atol=1e-9), var.name
+    infr2 = TransferInference(ModulePredictionAlgorithm(m, observed=[m.X], target_variables=[m.Y]), infr_params=infr.params, dtype='float64')
+    mu, var = infr2.run(X=t64(Xt))[0]
+    with torch.no_grad():
+        rmu, rvar = O.sgp_predict(ok, O.T(Xt)[None], O.T(Z)[None], O.T(noise)[None], post[1][None], post[2][None], post[0][None],
+                                  {k: v.detach() for k, v in kp().items()})
+    assert np.allclose(mu.cpu().numpy(), rmu.numpy(), atol=1e-7) and np.allclose(var.cpu().numpy(), rvar.numpy(), atol=1e-7)
