@@ -9,7 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the default bench command with its roofline micro-measurements: per-kernel averages (the gram_lean_kernel<float, 8, 0> row is the
 #    kernel bench.py's `roofline` times with HIP events), and one step as a timeline
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_trace_full.log 2>&1
-python $R/profiles/timeline.py $(find $O/trace_full -name "*kernel_trace.csv") 0.15 > $O/step_timeline.txt 2>&1
+# (the timeline tool shows the LAST step of a trace: the step alone, without the roofline extras that follow it in the full command)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_step -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_trace_step.log 2>&1
+python $R/profiles/timeline.py $(find $O/trace_step -name "*kernel_trace.csv") 0.15 > $O/step_timeline.txt 2>&1
 # 2. the per-rank share of an 8-GPU run (4 samples) as a timeline: the core chain is the critical path there
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s4 -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --samples 4 > $O/bench_trace_s4.log 2>&1
 python $R/profiles/timeline.py $(find $O/trace_s4 -name "*kernel_trace.csv") 0.03 > $O/step_timeline_s4.txt 2>&1
