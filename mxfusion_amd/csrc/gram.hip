@@ -64,6 +64,17 @@ template <typename T, int KIND> __device__ __forceinline__ T cov_from(T red, T v
     return red;   // LINEAR: the dot product itself
 }
 
+// 2^(t / 64) for float64 from a 64-entry table of 2^(j / 64) (LDS) and a degree-5 polynomial on |g| <= 1/2 (g in 64ths): 11 VALU
+// operations + one ds_read_b64 instead of the 18 of the degree-13 form (truncation (ln2/128)^6 / 6! = 3.5e-17; result within ~1 ulp).
+__device__ __forceinline__ double exp2_64ths_tab(double t, const double* __restrict__ tab) {
+    const double m = __builtin_rint(t), g = t - m;
+    double p = 1.241784370171692541187e-12;
+    p = fma(p, g, 5.732851688640402055966e-10); p = fma(p, g, 2.117313715546477506757e-7); p = fma(p, g, 0.00005864904955056169734706);
+    p = fma(p, g, 0.01083042469624914545964); p = fma(p, g, 1.0);
+    const int mi = (int)m;
+    return ldexp(p * tab[mi & 63], mi >> 6);
+}
+
 // NW = waves per workgroup.  The x rows are read through wave-uniform (scalar) loads straight from the pre-scaled copy: no LDS, no
 // barrier, and with NW = 1 every wave is its own workgroup, dispatched and retired independently (measured on MI355X, f32 RBF N=65536:
 // 4-wave blocks with an LDS x tile 5.67 TB/s, 4-wave blocks with scalar x 5.86, single-wave blocks with scalar x 6.52 TB/s --
@@ -200,18 +211,23 @@ __global__ __launch_bounds__(NW * 64) void gram_kernel(GramArgs<T> a, const T* _
 // -- no integer division in the prologue.  The diagonal term is branch-free, dadd = dscale * dadd_p[s] + jitter (the host passes
 // dscale = 0 and any valid pointer when there is none), so that all scalar loads of the prologue are issued back to back.
 template <typename T> struct GramLean {
-    int64_t N, N2, ldk, sXs, sZs, sK, svar, sdadd;
+    int64_t N, N2, ldk, sXs, sZs, sK, svar, sdadd, sXn, sZn;
     int tr, has_diag;
     T dscale, jitter;
 };
 
-template <typename T, int QT, int KIND>
+// XF (float64 RBF only): the squared distance in the reference's own expansion form |x|^2 + |z|^2 - 2 x.z (stationary.py:98-107) --
+// 1 + QT fused multiply-adds per element instead of 2 QT operations -- with the row norms from prescale_kernel, and the table-driven
+// exp2 above.  In float64 the kernel is bound by its VALU work, not by HBM (~40 issue slots per 8-byte element before, ~27 with XF).
+template <typename T, int QT, int KIND, int XF>
 __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_all, const T* __restrict__ Zs_all, T* __restrict__ K_all,
-                                                       const T* __restrict__ var, const T* __restrict__ dadd_p, GramLean<T> a) {
+                                                       const T* __restrict__ var, const T* __restrict__ dadd_p,
+                                                       const T* __restrict__ Xn_all, const T* __restrict__ Zn_all, GramLean<T> a) {
     constexpr int VEC = Vec16<T>::n;
     typedef typename Vec16<T>::type V;
     const int lane = threadIdx.x;
     const int s = blockIdx.z;
+    __shared__ double tab[XF ? 64 : 1];
     // (forcing the whole argument segment into SGPRs up front with an `asm volatile("" :: "s"(...))` makes the compiler fetch the x rows
     //  with per-lane vector loads instead of s_loads: 6.4 -> 5.7 TB/s, tests/probes/gram_variants.hip "force")
     const int64_t row0 = (int64_t)blockIdx.y * a.tr;
@@ -219,6 +235,10 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
     const int64_t col0 = wcol0 + (int64_t)lane * VEC;
     const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : var[(int64_t)s * a.svar];
     const T dadd = a.dscale * dadd_p[(int64_t)s * a.sdadd] + a.jitter;
+    if constexpr (XF) {
+        tab[lane] = (double)variance * mxf_exp2_neg_f64(-(double)lane * (1.0 / 64.0));       // variance 2^(lane / 64)
+        __syncthreads();
+    }
     if (col0 >= a.N2) return;
     T z[VEC][QT];
     {
@@ -231,13 +251,36 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
     T* __restrict__ Krow = K_all + (int64_t)s * a.sK + row0 * a.ldk + col0;
     const bool diag_possible = a.has_diag != 0;          // decided on the host: a diagonal term exists (its value may still be 0)
     const int rmax = (a.N - row0) < a.tr ? (int)(a.N - row0) : a.tr;
+    T zz[VEC];
+    const T* __restrict__ Xn = nullptr;
+    if constexpr (XF == 1) {     // t = -64 (|x|^2 + |z|^2 - 2 x.z) = fma(|x|^2, -64, -64 |z|^2) + sum_q x_q (128 z_q)
+        // Both norms come from prescale_kernel (for a square Gram from the SAME array) and the scalings are powers of two, so
+        // K[i][j] and K[j][i] go through identical roundings: the square Gram stays bit-symmetric.
+        Xn = Xn_all + (int64_t)s * a.sXn + row0;
+        const T* __restrict__ Zn = Zn_all + (int64_t)s * a.sZn + col0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            zz[v] = (T)-64 * Zn[v];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) z[v][q] *= (T)128;
+        }
+    }
 #pragma unroll 2
     for (int r = 0; r < rmax; ++r) {
         T x[QT];
 #pragma unroll
         for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];
         T kv[VEC];
-        if constexpr (sizeof(T) == 4 && KIND != MXF_K_LINEAR) {
+        if constexpr (XF == 1) {
+            const T xn = Xn[r];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                T acc = fma(xn, (T)-64, zz[v]);
+#pragma unroll
+                for (int q = 0; q < QT; ++q) acc = fma(x[q], z[v][q], acc);
+                kv[v] = (T)exp2_64ths_tab((double)acc, tab);     // the table carries the variance
+            }
+        } else if constexpr (sizeof(T) == 4 && KIND != MXF_K_LINEAR) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int p = 0; p < VEC / 2; ++p) {
@@ -269,7 +312,10 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
         // "+ noise / jitter on the diagonal": a scalar test (is this row inside the wave's column range?) guards the per-lane compares
         if (diag_possible && (uint64_t)(row0 + r - wcol0) < (uint64_t)(64 * VEC)) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) if (col0 + v == row0 + r) kv[v] += dadd;
+            for (int v = 0; v < VEC; ++v) if (col0 + v == row0 + r) {
+                if (XF == 1 && (a.has_diag & 2)) kv[v] = variance;     // k(x, x) = variance exactly (stationary.py:123-124), as the difference form gives
+                kv[v] += dadd;
+            }
         }
         V out;
         T* po = reinterpret_cast<T*>(&out);
@@ -280,9 +326,10 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
 }
 
 // out[s][row][q] = X[s][row][q] * m_q for row < N, q < Q, else 0  (row < pad, q < QT);  m_q = c/l_q or sqrt(v_q)
+// norms (optional): norms[s][row] = sum_q out[s][row][q]^2 (the QT threads of a row are neighbouring lanes)
 template <typename T, int QT, int KIND>
 __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __restrict__ ls, int64_t sls, int ard, int64_t N, int Q,
-                                int64_t pad, T* __restrict__ out) {
+                                int64_t pad, T* __restrict__ out, T* __restrict__ norms = nullptr) {
     const int s = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pad * QT) return;
@@ -295,6 +342,12 @@ __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __
         v = X[(int64_t)s * sX + row * Q + q] * m;
     }
     out[(int64_t)s * pad * QT + i] = v;
+    if (norms) {
+        T n2 = v * v;
+#pragma unroll
+        for (int o = QT / 2; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
+        if (q == 0) norms[(int64_t)s * pad + row] = n2;
+    }
 }
 
 // generic fallback for Q > 16: one output per thread, q-loop over global memory
@@ -345,7 +398,9 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     static const int nw_env = getenv("MXF_GRAM_NW") ? atoi(getenv("MXF_GRAM_NW")) : 0;
     static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
     // f32 RBF: 16 rows (6.05 TB/s; 32: 5.75, 64: 5.29, 8: 5.27); the VALU-heavier epilogues (Matern, all float64) prefer 64 (f64 RBF 5.25 vs 5.13)
-    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((sizeof(T) == 4 && KIND == MXF_K_RBF) ? 16 : 64);
+    // (float64 RBF in the expansion form, gram_lean_kernel XF: 16 rows 5.71 ms = 6.02 TB/s, 32: 5.95, 64: 6.36 ms)
+    static const int xf_tr = getenv("MXF_GRAM_F64_EXPAND") ? atoi(getenv("MXF_GRAM_F64_EXPAND")) : 1;
+    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((KIND == MXF_K_RBF && (sizeof(T) == 4 || xf_tr)) ? 16 : 64);
     a.nt = (nt_env >= 0) ? nt_env : 1;
     const int NW = (nw_env == 1 || nw_env == 4) ? nw_env : 1;
     const int64_t cw = (int64_t)NW * 64 * VEC;          // columns per workgroup
@@ -355,35 +410,45 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     dim3 g((unsigned)nblk, 1, (unsigned)S);
 #define GO(QT)                                                                                                        \
     do {                                                                                                              \
+        const bool fast = a.vecst && mode == MXF_WRITE && a.nt && (a.N2 % VEC == 0);                                  \
+        static const int lean_env = getenv("MXF_GRAM_LEAN") ? atoi(getenv("MXF_GRAM_LEAN")) : 1;                     \
+        static const int xf_env = getenv("MXF_GRAM_F64_EXPAND") ? atoi(getenv("MXF_GRAM_F64_EXPAND")) : 1;           \
+        const bool lean_ok = NW == 1 && fast && lean_env && KIND != MXF_K_BIAS && KIND != MXF_K_WHITE && (a.N + a.tr - 1) / a.tr <= 65535; \
+        const bool xf = lean_ok && sizeof(T) == 8 && KIND == MXF_K_RBF && xf_env;                                     \
+        T* xnorm = nullptr; T* znorm = nullptr; int64_t sxn = 0, szn = 0;                                             \
         if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {                                                              \
             const int64_t padr = (a.N + TR - 1) / TR * TR, padc = (a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC) * (4 * 64 * VEC); \
             const int Sx = (a.sX == 0 && a.sls == 0) ? 1 : S, Sz = (a.sX2 == 0 && a.sls == 0) ? 1 : S;                \
             const int64_t padx = a.square ? (padr > padc ? padr : padc) : padr;                                       \
-            const size_t need = ((size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc)) * QT * sizeof(T);           \
+            const size_t ncoord = ((size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc)) * QT;                     \
+            const size_t need = (ncoord + (xf ? (size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc) : 0)) * sizeof(T); \
             T* buf = (T*)mxf_gram_ws(h, need);                                                                        \
             if (!buf) MXF_FAIL(h, -4, "mxf_gram: cannot allocate %zu bytes for the pre-scaled coordinates", need);    \
+            xnorm = xf ? buf + ncoord : nullptr; sxn = (Sx == 1) ? 0 : padx;                                          \
             hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padx * QT + 255) / 256), Sx), dim3(256), 0, st, a.X, a.sX, \
-                               a.ls, a.sls, a.ard, a.N, a.Q, padx, buf);                                              \
+                               a.ls, a.sls, a.ard, a.N, a.Q, padx, buf, xnorm);                                       \
             a.Xs = buf; a.sXs = (Sx == 1) ? 0 : padx * QT;                                                            \
-            if (a.square) { a.Zs = buf; a.sZs = a.sXs; }                                                              \
+            if (a.square) { a.Zs = buf; a.sZs = a.sXs; znorm = xnorm; szn = sxn; }                                    \
             else {                                                                                                    \
                 T* bz = buf + (size_t)Sx * padx * QT;                                                                 \
+                znorm = xf ? xnorm + (size_t)Sx * padx : nullptr; szn = (Sz == 1) ? 0 : padc;                         \
                 hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padc * QT + 255) / 256), Sz), dim3(256), 0, st, a.X2, \
-                                   a.sX2, a.ls, a.sls, a.ard, a.N2, a.Q, padc, bz);                                   \
+                                   a.sX2, a.ls, a.sls, a.ard, a.N2, a.Q, padc, bz, znorm);                            \
                 a.Zs = bz; a.sZs = (Sz == 1) ? 0 : padc * QT;                                                         \
             }                                                                                                         \
         }                                                                                                             \
-        const bool fast = a.vecst && mode == MXF_WRITE && a.nt && (a.N2 % VEC == 0);                                  \
-        static const int lean_env = getenv("MXF_GRAM_LEAN") ? atoi(getenv("MXF_GRAM_LEAN")) : 1;                     \
-        if (NW == 1 && fast && lean_env && KIND != MXF_K_BIAS && KIND != MXF_K_WHITE && (a.N + a.tr - 1) / a.tr <= 65535) {                               \
+        if (lean_ok) {                                                                                                \
             GramLean<T> l;                                                                                            \
             l.N = a.N; l.N2 = a.N2; l.ldk = a.ldk; l.sXs = a.sXs; l.sZs = a.sZs; l.sK = a.sK; l.svar = a.svar; l.tr = a.tr; \
             const bool hd = a.square && a.dadd != nullptr;                                                            \
             l.sdadd = hd ? a.sdadd : 0; l.dscale = hd ? (T)1 : (T)0; l.jitter = a.square ? a.jitter : (T)0;           \
-            l.has_diag = (hd || l.jitter != (T)0) ? 1 : 0;                                                            \
+            l.has_diag = ((hd || l.jitter != (T)0) ? 1 : 0) | ((xf && a.square) ? 2 : 0); l.sXn = sxn; l.sZn = szn;   \
             const T* dptr = hd ? a.dadd : (a.var ? a.var : a.Xs);          /* any readable word when there is no diagonal term */ \
             dim3 gl(a.ncb, (unsigned)((a.N + a.tr - 1) / a.tr), (unsigned)S);                                         \
-            hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, l); \
+            if constexpr (sizeof(T) == 8 && KIND == MXF_K_RBF) {                                                      \
+                if (xf) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 1>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)xnorm, (const T*)znorm, l); \
+                else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+            } else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
         } else if (NW == 1 && fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, true>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K); \
         else if (NW == 1) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, false>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K);            \
         else if (fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 4, true>), g, dim3(256), 0, st, a, a.Xs, a.Zs, a.K);               \
