@@ -60,6 +60,26 @@ int64_t mxf_workspace_generation(mxf_handle h);
 int mxf_svgp_last_cond(mxf_handle h, double* cond1_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU gradient exchange (RCCL over xGMI), SURVEY.md section 8(b)/(e).  The reference has no multi-device path (one MXNet context
+ * per Inference object); north_star shards the Monte-Carlo samples of StochasticVariationalInference.compute
+ * (inference/variational.py:15-26) over the GPUs -- one process and one handle per GPU -- and sums the flat gradient ONCE per step
+ * before the optimiser update (what Trainer.step of inference/batch_loop.py:46-60 would do with a kvstore).  librccl is opened on first
+ * use; single-GPU callers never load it.
+ *   mxf_comm_unique_id : rank 0 creates the 128-byte rendezvous id; the caller distributes it to the other ranks by its own means
+ *                        (MPI, a file, the launcher's environment).
+ *   mxf_comm_init      : collective over all ranks; binds a communicator of `nranks` ranks to this handle's device.
+ *   mxf_allreduce_sum  : in-place sum over ranks of `count` elements (MXF_F32 / MXF_F64) at the device pointer `buf`, ordered on `stream`.
+ *   mxf_bcast          : in-place broadcast from `root` (initial parameters; the minibatch permutation of config 4).
+ *   mxf_comm_destroy   : releases the communicator (mxf_destroy does it too).
+ * Returns 0, or < 0 with mxf_last_error (-6: librccl not loadable, -7: an RCCL call failed). */
+#define MXF_COMM_ID_BYTES 128
+int mxf_comm_unique_id(mxf_handle h, void* id_out /* MXF_COMM_ID_BYTES, host */);
+int mxf_comm_init(mxf_handle h, int nranks, int rank, const void* id /* MXF_COMM_ID_BYTES, host */);
+int mxf_allreduce_sum(mxf_handle h, int dtype, void* buf, int64_t count, void* stream);
+int mxf_bcast(mxf_handle h, int dtype, void* buf, int64_t count, int root, void* stream);
+int mxf_comm_destroy(mxf_handle h);
+
+/* ---------------------------------------------------------------------------------------------
  * Gram build.  Replaces Kernel.K -> _compute_K (kernels/kernel.py:96-123), i.e.
  * StationaryKernel._compute_R2 (kernels/stationary.py:74-107) + RBF._compute_K (rbf.py:71-72) /
  * Matern{12,32,52}._compute_K (matern.py:84-88,116-120,148-151) / Linear (linear.py:59-89) /

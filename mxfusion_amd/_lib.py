@@ -51,6 +51,11 @@ SIGNATURES = {
     'mxf_sgp_logpdf': [_i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i,
                        _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_last_cond': [_c.POINTER(_d)],
+    'mxf_comm_unique_id': [_vp],
+    'mxf_comm_init': [_i, _i, _vp],
+    'mxf_allreduce_sum': [_i, _vp, _i64, _vp],
+    'mxf_bcast': [_i, _vp, _i64, _i, _vp],
+    'mxf_comm_destroy': [],
 }
 PLAIN = {  # entry points without the (handle, ...) -> int shape
     'mxf_version': ([], _i),

@@ -1,5 +1,6 @@
 // Handle management for libmxf_gp.so.
 #include "common.h"
+#include "internal.h"
 
 extern "C" int mxf_version(void) { return 100; }
 
@@ -17,6 +18,7 @@ extern "C" int mxf_create(int device, mxf_handle* out) {
 
 extern "C" int mxf_destroy(mxf_handle h) {
     if (!h) return -1;
+    mxf_comm_release(h);
     if (h->ws) (void)hipFree(h->ws);
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->flags) (void)hipFree(h->flags);

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+void mxf_comm_release(mxf_ctx* h);      // comm.hip: destroys the handle's RCCL communicator, if any
+
 // C = alpha op(A) op(B) + beta C; lower_only: skip blocks / entries strictly above the diagonal (syrk-style update)
 int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,

@@ -341,6 +341,43 @@ def svgp_last_cond(device=None):
     return _lib.svgp_last_cond(idx)
 
 
+# ---- gradient exchange through the C ABI (RCCL); mxfusion_amd's own loops use torch.distributed, these mirror what a reference-side
+# binder without PyTorch calls (include/mxf_gp.h) -------------------------------------------------------------
+def comm_unique_id(device=None):
+    """128-byte rendezvous id (rank 0 creates it and hands it to the other ranks)."""
+    import ctypes
+    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    buf = ctypes.create_string_buffer(128)
+    _lib.call('mxf_comm_unique_id', _lib.handle(idx), ctypes.cast(buf, ctypes.c_void_p))
+    return buf.raw
+
+
+def comm_init(nranks, rank, unique_id, device=None):
+    import ctypes
+    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    assert len(unique_id) == 128
+    buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+    _lib.call('mxf_comm_init', _lib.handle(idx), int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p))
+
+
+def comm_destroy(device=None):
+    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    _lib.call('mxf_comm_destroy', _lib.handle(idx))
+
+
+def allreduce_sum_(t):
+    """In-place sum over the ranks of the handle's communicator (mxf_allreduce_sum), ordered on the current stream."""
+    assert t.is_contiguous()
+    _lib.call('mxf_allreduce_sum', _h(t), _dt(t), _p(t), t.numel(), _stream())
+    return t
+
+
+def bcast_(t, root=0):
+    assert t.is_contiguous()
+    _lib.call('mxf_bcast', _h(t), _dt(t), _p(t), t.numel(), int(root), _stream())
+    return t
+
+
 def svgp_logpdf_mat(Kuu, Kuf, Kdiag, Y, noise_var, qU_mean, qU_cov_W, qU_cov_diag, jitter=0.0, scaling=1.0, gscale=1.0, want_grad=False):
     """SVGP bound from materialised Grams: Kuu (M,M) without jitter, Kuf (M,B), Kdiag (B,), Y (B,P) or (S,B,P) [S samples of the outputs over
     the same inputs], noise_var (1,) | (P,) | (B,1) | (B,P).  Returns dict(logL (S,), info, and -- if want_grad -- dKuu, dKuf, dKdiag, dY,

@@ -106,3 +106,36 @@ def test_full_size_svgp_training_call_properties():
     L = lambda rows: call(torch.float64, rows=rows, grad=False)['logL'].cpu().numpy()
     lhs, rhs = L(AB) + L(C), L(A) + L(BC)
     assert np.allclose(lhs, rhs, rtol=1e-11, atol=0)
+
+
+def test_config3_at_all_32_samples():
+    """configs[2] at its full sample count (N = 65 536, Q = 8, M = 1 024, S = 32: 2.1 M columns per call -- what bench.py times): the
+    per-sample bounds of the float32 call agree with float64 to 1e-5 (north_star); the samples are independent, so the S = 32 call equals
+    the two S = 16 calls on its halves sample by sample, and its gradient (weight 1/32 each) is the mean of theirs -- the identity the
+    sample-sharded multi-GPU layout relies on."""
+    from mxfusion_amd import ops
+    N, Q, M, S, P = 65536, 8, 1024, 32, 1
+    rng, X0, Y, Z = _synth(N, Q, M, seed=5)
+    qm, qW, qd = rng.standard_normal((M, P)) * 0.3, rng.standard_normal((M, M)) * 0.02, rng.random(M) + 0.5
+    ls, var, noise = np.ones(Q) + 0.2 * rng.random(Q), np.array([1.2]), np.array([0.02])
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    X64 = torch.as_tensor(X0).cuda()[None] + 0.1 * torch.randn(S, N, Q, generator=gen, device='cuda', dtype=torch.float64)
+
+    def call(dt, sl):
+        d = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+        Xs = X64[sl].to(dt).contiguous()
+        r = ops.svgp_logpdf('rbf', Xs, d(Y[None]), d(Z), d(noise), d(qm), d(qW), d(qd), d(ls), d(var), True, jitter=1e-6, scaling=1.0,
+                            gscale=1.0 / Xs.shape[0], want_grad=True)
+        torch.cuda.synchronize()
+        assert int(r['info'].abs().sum()) == 0
+        return {k: v.double().cpu().numpy() for k, v in r.items() if k != 'dX'}
+    full = call(torch.float32, slice(0, S))
+    lo, hi = call(torch.float32, slice(0, S // 2)), call(torch.float32, slice(S // 2, S))
+    assert np.allclose(full['logL'], np.concatenate([lo['logL'], hi['logL']]), rtol=2e-7, atol=0)
+    for key in ('dZ', 'dW', 'dSdiag', 'dmu', 'dls', 'dvar', 'dnoise'):
+        a, b = full[key], 0.5 * (lo[key] + hi[key])
+        assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(a), (key, np.linalg.norm(a - b) / np.linalg.norm(a))
+    f64 = call(torch.float64, slice(0, S))
+    assert np.allclose(full['logL'], f64['logL'], rtol=1e-5, atol=0), np.abs(full['logL'] / f64['logL'] - 1).max()
+    for key in ('dZ', 'dW', 'dSdiag', 'dmu', 'dls', 'dvar', 'dnoise'):
+        assert np.linalg.norm(full[key] - f64[key]) <= 1e-4 * np.linalg.norm(f64[key]), key
