@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 }
 
 template <typename T>
-int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st) {
+int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper) {
     if (info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
@@ -459,7 +459,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         }
     }
     if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
-    if (n > 1) {
+    if (n > 1 && zero_upper) {      // (internal callers that only ever read the lower triangle skip this pass)
         if (n > 65535) MXF_FAIL(h, -3, "mxf_potrf: n too large");
         hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
     }
@@ -505,10 +505,10 @@ int trsm_typed(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t n
 
 }  // namespace
 
-int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st) {
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper) {
     if (n <= 0 || S <= 0) return 0;
-    if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st);
-    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st);
+    if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st, zero_upper);
+    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper);
     MXF_FAIL(h, -2, "mxf_potrf: bad dtype %d", dtype);
 }
 

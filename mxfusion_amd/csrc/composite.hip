@@ -696,7 +696,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (!h->cond_dev && hipMalloc((void**)&h->cond_dev, 2 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
     MXF_HIP(h, hipMemsetAsync(h->cond_dev, 0, 2 * sizeof(double), st));
     hipLaunchKernelGGL(norm1_sym_kernel, dim3((unsigned)M), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                   // L :83
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false);                            // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
@@ -713,7 +713,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
     MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, s2_));
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_);                                // Ls = chol(Su) :84
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_, false);                         // Ls = chol(Su) :84
     if (rc) return rc;
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, s2_);
     if (rc) return rc;
@@ -736,7 +736,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su formed (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
-    MXF_HIP(h, hipMemcpyAsync(H0, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, H0, MM);     // H0 <- Ki (a plain kernel: the runtime's copy engine path costs ~10x as much next to busy queues)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);

@@ -9,7 +9,8 @@ int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t 
                       const void* A, int64_t lda, int64_t sA, const void* B, int64_t ldb, int64_t sB, double beta,
                       void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus = 0, int k_from_m = 0);
 
-int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st);
+// zero_upper = false: leave the strict upper triangle outside the 64 x 64 diagonal blocks as it was (callers that only read the lower part)
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper = true);
 // rhs_lower: B is block-lower-triangular (trtri); only columns < (k+1)*64 of block row k are touched
 int mxf_trsm_internal(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t nrhs, const void* L, int64_t ldl,
                       int64_t sL, void* B, int64_t ldb, int64_t sB, int rhs_lower, hipStream_t st);
