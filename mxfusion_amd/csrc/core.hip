@@ -23,6 +23,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->flags) (void)hipFree(h->flags);
     if (h->cond_dev) (void)hipFree(h->cond_dev);
+    if (h->bwd_acc) (void)hipFree(h->bwd_acc);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);

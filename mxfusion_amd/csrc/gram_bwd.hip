@@ -341,6 +341,244 @@ __global__ __launch_bounds__(256) void gram_bwd_generic_kernel(GramBwdArgs<T> a)
     if (a.dvar) { const T v = block_sum<T>(gvar, red); if (tid == 0) atomic_add(a.dvar + (int64_t)s * a.svar, v); }
 }
 
+// ---- SVGP-fused reverse pass, float32, P = 1, Q <= 8: distances and all cross-lane sums on the matrix pipe --------------------------
+// The pass above spends its 93 VALU instructions per pair on the distance (16), the sums over rows (dZ, R: reduce-scatter across the
+// wave + an LDS atomic per row) and over columns (dX, dl: 24 multiply-adds).  With W_mn = 2 g w variance (the per-pair weight) and
+// scaled coordinates z_m, x_n every one of them is a skinny matrix product:
+//   r2_mn = |z_m|^2 + |x_n|^2 - 2 (X Z^T)_nm                                            (stationary.py:98-107, the reference's own form)
+//   dZ_mq = (z_mq S_m - B_mq) / l_q,   [B | S] = W   (M x N) . [X | 1] (N x 9)          (S_m = sum_n W_mn)
+//   dX_nq = (x_nq C_n - D_nq) / l_q,   [D | C] = W^T (N x M) . [Z | 1] (M x 9)          (C_n = sum_m W_mn)
+//   dl_q  = -(sum_m z_mq^2 S_m - 2 sum_m z_mq B_mq + sum_n x_nq^2 C_n) / l_q
+// A wave walks 16 (m) x 16 (n) tiles.  Two v_mfma_f32_16x16x4_f32 (true float32) give the tile of dot products in the accumulator layout
+// -- lane = (m = l % 16, columns 4 (l / 16) .. + 3) --, which is at once the layout of the T loads (16 bytes per lane) and the A-operand
+// layout of the product that contracts over n: [B | S] of the tile's 16 rows accumulates in 4 registers per lane over ALL the columns
+// the wave visits.  The tile of W is transposed through 1 KB of LDS (one ds_write_b128 + four ds_read_b32 per lane) and fed to the
+// product that contracts over m: [D | C] of the tile's 16 columns, accumulated over the band's rows and flushed per column tile.
+// ~15 VALU instructions per pair; ten MFMAs per 256 pairs.
+struct BwdMfmaArgs {
+    const float* Zs; const float* Xs;    // coordinates / lengthscale, zero-padded to 8 per point (bwd_prescale_kernel)
+    const float* Xn;                     // |x_n|^2 of the scaled coordinates
+    const float* ls; const float* var; const float* T; const float* U; const float* Y; const float* w;
+    const float* noise;
+    float* dX; float* dY; float* zacc;   // zacc [M][16]: 0..7 B_mq, 8 S_m, 9 R_m (zeroed by the launcher)
+    float* dls3;                         // [8]: sum_n x_nq^2 C_n
+    float* dvar; double* scal;
+    int64_t M, SB, B, sY;
+    int Q, ard, CT, dY_shared;
+    double a1;
+};
+
+constexpr int MF_MT = 8;             // row tiles of 16 per band: 4 accumulator registers each (16 tiles spill: the allocator chains each
+                                     // accumulating MFMA through a second register quad)
+constexpr int MF_RB = 16 * MF_MT;    // rows per band
+
+template <int KIND, bool FULL>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks)
+__global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
+    constexpr int QT = 8;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float za[MF_RB][16];     // [z (scaled, 8) | 1 | 0 ...]: B operand of the column-side product, and of the dots
+    __shared__ __attribute__((aligned(8))) float zw[MF_RB][2];       // [|z|^2, w]
+    __shared__ float rowacc[MF_RB][10];
+    __shared__ __attribute__((aligned(16))) float wt[4][16][16];     // per wave: the W tile, transposed on the way through
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int64_t band0 = (int64_t)blockIdx.y * MF_RB;
+    const int Q = a.Q;
+    const float* __restrict__ Xs = a.Xs;
+    const float* __restrict__ Tm = a.T;
+    const float ilj = (li < Q) ? 1.f / a.ls[a.ard ? li : 0] : 0.f;                 // 1 / l of coordinate j = li (column flush)
+    const float variance = a.var[0];
+    const float c1 = (float)a.a1 / a.noise[0];
+    for (int i = tid; i < MF_RB * 16; i += 256) {
+        const int r = i / 16, j = i % 16;
+        za[r][j] = (band0 + r < a.M) ? ((j < QT) ? a.Zs[(band0 + r) * QT + j] : (j == 8 ? 1.f : 0.f)) : 0.f;
+    }
+    for (int r = tid; r < MF_RB; r += 256) {
+        float n2 = 0.f;
+        if (band0 + r < a.M) {
+#pragma unroll
+            for (int q = 0; q < QT; ++q) { const float v = a.Zs[(band0 + r) * QT + q]; n2 = fmaf(v, v, n2); }
+        }
+        zw[r][0] = n2;
+        zw[r][1] = (band0 + r < a.M) ? a.w[band0 + r] : 0.f;
+    }
+    for (int i = tid; i < MF_RB * 10; i += 256) (&rowacc[0][0])[i] = 0.f;
+    __syncthreads();
+
+    f32x4 C1[MF_MT];
+    float racc[MF_MT];
+#pragma unroll
+    for (int mt = 0; mt < MF_MT; ++mt) { C1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; racc[mt] = 0.f; }
+    float gvar = 0.f, dl3 = 0.f;
+    double qsum = 0.0, esum = 0.0;
+    int64_t cur_s = -1;
+    auto flush_scal = [&]() {       // wave-uniform call: per-sample sums of q_n (and |e_n|^2 from the first band)
+        const double qs = wave_sum(qsum), es = wave_sum(esum);
+        if (lane == 0 && cur_s >= 0) { atomic_add(a.scal + 2 * cur_s, qs); if (blockIdx.y == 0) atomic_add(a.scal + 2 * cur_s + 1, es); }
+        qsum = 0.0; esum = 0.0;
+    };
+    float* wtw = &wt[wave][0][0];
+    // row of T this lane reads in row tile mt: band0 + 16 mt + li (clamped: ragged rows are masked, not skipped -- no branches around loads)
+    const int64_t rowl = band0 + li;
+
+    for (int it = 0; it < a.CT; ++it) {
+        const int64_t nt0 = ((int64_t)blockIdx.x * a.CT + it) * 64 + wave * 16;      // the wave's 16 columns (the block's four waves side by side)
+        if (nt0 >= a.SB) break;
+        const int64_t smp = nt0 / a.B;                                               // B % 16 == 0: a tile lies inside one sample
+        if (smp != cur_s) { flush_scal(); cur_s = smp; }
+        const int64_t n0 = nt0 + 4 * lq;                                             // this lane's 4 consecutive columns
+        const bool cval = FULL || n0 < a.SB;                                         // SB % 4 == 0: all four or none
+        const int64_t n0c = cval ? n0 : a.SB - 4;
+        const int64_t nac = (FULL || nt0 + li < a.SB) ? nt0 + li : a.SB - 1;         // column of the dot product's A operand
+        const float xa0 = Xs[nac * QT + lq], xa1 = Xs[nac * QT + 4 + lq];
+        const f32x4 xx = *reinterpret_cast<const f32x4*>(a.Xn + n0c);
+        const f32x4 uu = *reinterpret_cast<const f32x4*>(a.U + n0c);
+        float e[4], bx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float xv = Xs[(n0c + t) * QT + (li & 7)];
+            bx[t] = cval ? ((li < QT) ? xv : (li == 8 ? 1.f : 0.f)) : 0.f;
+            const float yv = a.Y[smp * a.sY + (n0c + t - smp * a.B)];
+            e[t] = cval ? yv - uu[t] : 0.f;
+        }
+        if (blockIdx.y == 0 && li == 0 && cval) {          // one lane per column, first band only: dY and |e|^2
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                esum += (double)e[t] * (double)e[t];
+                if (a.dY) {
+                    const float g = -c1 * e[t];
+                    const int64_t n = n0 + t;
+                    if (a.dY_shared) atomic_add(a.dY + (n - smp * a.B), g); else a.dY[n] = g;
+                }
+            }
+        }
+        float qn = 0.f;
+        f32x4 C2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // T rows of this lane: band0 + li + 16 mt, walked with a running pointer (the row offsets are column-tile invariant: computed up
+        // front they would sit in 2 registers per row tile); ragged bands clamp to the last row and mask the value instead of branching
+        const float* tp = Tm + n0c + rowl * a.SB;
+        const float* const tlast = Tm + n0c + (a.M - 1) * a.SB;
+        const int64_t tstep = 16 * a.SB;
+        auto tload = [&]() -> f32x4 {
+            const float* q = (FULL || tp <= tlast) ? tp : tlast;
+            tp += tstep;
+            return *reinterpret_cast<const f32x4*>(q);
+        };
+        f32x4 tq0 = tload(), tq1 = tload();
+#pragma unroll
+        for (int mt = 0; mt < MF_MT; ++mt) {
+            const int rl = mt * 16 + li;
+            asm volatile("" ::: "memory");        // the band's LDS tables never change inside the column loop: without this the compiler hoists all their
+                                                 // reads out of it (9 registers per row tile)
+            const f32x4 tq2 = (mt + 2 < MF_MT) ? tload() : tq1;                     // two row tiles ahead
+            f32x4 tv = tq0;
+            if (!FULL) { const bool ok = cval && rowl + 16 * mt < a.M; tv = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const float zb0 = za[rl][lq], zb1 = za[rl][4 + lq];
+            const f32x2 zwv = *reinterpret_cast<const f32x2*>(&zw[rl][0]);
+            f32x4 dot = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0, zb0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1, zb1, dot, 0, 0, 0);      // dot[t] = x_(n0 + t) . z_(row rl)
+            const float wm = zwv[1];
+            f32x4 W;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float r2 = fmaf(-2.f, dot[t], zwv[0] + xx[t]);
+                r2 = r2 > 0.f ? r2 : 0.f;
+                float k, w;
+                cov_and_slope<float, KIND>(r2, k, w);
+                const float kv = k * variance;
+                const float g = c1 * fmaf(wm, e[t], tv[t]);
+                W[t] = 2.f * g * w * variance;
+                gvar = fmaf(g, k, gvar);
+                qn = fmaf(kv, tv[t], qn);
+                racc[mt] = fmaf(kv, e[t], racc[mt]);
+                C1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[t], bx[t], C1[mt], 0, 0, 0);      // [B | S] += W . [X | 1]
+            }
+            // transpose the tile through LDS: written as (m = li, n = 4 lq .. + 3), read as (n = li, m = lq + 4 t)
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<f32x4*>(wtw + li * 16 + 4 * lq) = W;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float wtr = wtw[(lq + 4 * t) * 16 + li];
+                const float zb = za[mt * 16 + lq + 4 * t][li];
+                C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wtr, zb, C2, 0, 0, 0);                   // [D | C] += W^T . [Z | 1]
+            }
+            tq0 = tq1; tq1 = tq2;
+            __builtin_amdgcn_sched_barrier(0);      // keep the unrolled row tiles apart: interleaving them costs > 250 registers
+        }
+        qsum += (double)qn;
+        // column side: C2[r] = [D | C] of column nt0 + 4 lq + r (= this lane's column n0 + r), entry j = li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float Cn = __shfl(C2[r], (lane & 48) | 8, 64);
+            const float pr = bx[r] * Cn;                       // x_nq C_n (q = li; bx is x of column n0 + r at coordinate li)
+            if (li < Q) {
+                dl3 = fmaf(bx[r], pr, dl3);
+                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * ilj);
+            }
+        }
+    }
+    flush_scal();
+    // row side: C1[mt][r] = [B | S] of row band0 + 16 mt + 4 lq + r, column li; the block's four waves are combined in LDS first
+#pragma unroll
+    for (int mt = 0; mt < MF_MT; ++mt) {
+        if (li < 9) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds_add(&rowacc[mt * 16 + 4 * lq + r][li], C1[mt][r]);
+        }
+        float rr = racc[mt];                                   // R partials of row 16 mt + li: fold the four column groups
+        rr += __shfl_xor(rr, 16, 64);
+        rr += __shfl_xor(rr, 32, 64);
+        if (lane < 16) lds_add(&rowacc[mt * 16 + li][9], rr);
+    }
+    __syncthreads();
+    for (int i = tid; i < MF_RB * 10; i += 256) {
+        const int r = i / 10, c = i % 10;
+        if (band0 + r < a.M) atomic_add(a.zacc + (band0 + r) * 16 + c, rowacc[r][c]);
+    }
+    if (a.dvar) { const float v = block_sum<float>(gvar, red); if (tid == 0) atomic_add(a.dvar, v); }
+    {   // sum_n x_nq^2 C_n: lane (q = li) holds its share
+        float v = (li < Q) ? dl3 : 0.f;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16 && li < Q) atomic_add(a.dls3 + li, v);
+    }
+}
+
+// dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one block)
+__global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z, const float* __restrict__ ls,
+                                                              const float* __restrict__ zacc, const float* __restrict__ dls3,
+                                                              float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float g12[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g12[q] = 0.f;
+    for (int64_t m = tid; m < M; m += 256) {
+        const float S = zacc[m * 16 + 8];
+        if (R) R[m] += zacc[m * 16 + 9];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < Q) {
+                const float ilq = 1.f / ls[ard ? q : 0], z = Z[m * Q + q] * ilq, Bq = zacc[m * 16 + q];
+                if (dZ) dZ[m * Q + q] += (z * S - Bq) * ilq;
+                g12[q] += z * (z * S - 2.f * Bq);
+            }
+        }
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float v = block_sum<float>(g12[q], red);
+        if (tid == 0 && q < Q) {
+            const float glq = -(v + dls3[q]);            // sum over pairs of -W d_q^2
+            if (ard) { if (dls) dls[q] += glq / ls[q]; } else tot += glq;
+        }
+    }
+    if (tid == 0 && !ard && dls) dls[0] += tot / ls[0];
+}
+
 template <typename T, int QT, int KIND, int PT>
 int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     constexpr bool FUSED = PT > 0;
@@ -419,6 +657,70 @@ int bwd_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q, const v
     return launch_kind<T, 0>(h, kind, a, S, st);
 }
 
+// dst[i][0..7] = src[i][0..Q-1] / l_q, zero padded (rows i < n); norms[i] = |dst[i]|^2 (optional)
+__global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restrict__ src, int64_t n, int Q, const float* __restrict__ ls, int ard,
+                                                           float* __restrict__ dst, float* __restrict__ norms) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    float v[8], n2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? src[r * Q + q] / ls[ard ? q : 0] : 0.f; n2 = fmaf(v[q], v[q], n2); }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<f32x4*>(dst + r * 8) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + r * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    if (norms) norms[r] = n2;
+}
+
+int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
+                const float* var, const float* Text, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dZ,
+                float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st) {
+    const size_t nacc = (size_t)M * 16 + 16;                                   // zeroed every call
+    const size_t need = (nacc + ((size_t)M + (size_t)SB) * 8 + (size_t)SB) * sizeof(float);  // + the scaled coordinates and |x_n|^2
+    if (need > h->bwd_acc_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) MXF_FAIL(h, -4, "svgp reverse pass: scratch must be allocated before a stream capture (run one eager step first)");
+        if (h->bwd_acc) { (void)hipDeviceSynchronize(); (void)hipFree(h->bwd_acc); h->bwd_acc = nullptr; h->bwd_acc_bytes = 0; ++h->ws_generation; }
+        if (hipMalloc((void**)&h->bwd_acc, need) != hipSuccess) { h->bwd_acc = nullptr; MXF_FAIL(h, -4, "svgp reverse pass: cannot allocate %zu bytes", need); }
+        h->bwd_acc_bytes = need;
+    }
+    MXF_HIP(h, hipMemsetAsync(h->bwd_acc, 0, nacc * sizeof(float), st));
+    float* Zs = h->bwd_acc + nacc;
+    float* Xs = Zs + (size_t)M * 8;
+    float* Xn = Xs + (size_t)SB * 8;
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, X, SB, Q, ls, ard, Xs, Xn);
+    BwdMfmaArgs a;
+    a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
+    a.dX = dX; a.dY = dY; a.zacc = h->bwd_acc; a.dls3 = h->bwd_acc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
+    a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1;
+    const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
+    static const int64_t gt_env = getenv("MXF_BWD_MFMA_GRID") ? atoll(getenv("MXF_BWD_MFMA_GRID")) : 8192;
+    int64_t ct = (quads * bands + gt_env - 1) / gt_env;
+    if (ct < 1) ct = 1;
+    if (ct > 256) ct = 256;
+    a.CT = (int)ct;
+    dim3 g((unsigned)((quads + ct - 1) / ct), (unsigned)bands, 1);
+    if (g.y > 65535u) MXF_FAIL(h, -3, "svgp reverse pass: too many row bands");
+    const bool full = (M % MF_RB == 0) && (SB % 64 == 0);
+#define MF_GO(KIND)                                                                                             \
+    do {                                                                                                        \
+        if (full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, true>), g, dim3(256), 0, st, a);              \
+        else hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, false>), g, dim3(256), 0, st, a);                  \
+    } while (0)
+    switch (kind) {
+        case MXF_K_RBF: MF_GO(MXF_K_RBF); break;
+        case MXF_K_MATERN12: MF_GO(MXF_K_MATERN12); break;
+        case MXF_K_MATERN32: MF_GO(MXF_K_MATERN32); break;
+        case MXF_K_MATERN52: MF_GO(MXF_K_MATERN52); break;
+        default: MXF_FAIL(h, -2, "svgp reverse pass: kind %d has no stationary reverse mode", kind);
+    }
+#undef MF_GO
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3(1), dim3(256), 0, st, M, Q, ard, Z, ls, (const float*)a.zacc, (const float*)a.dls3, dZ, dls, R);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
 template <typename T>
 int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z, const void* Xall, const void* ls,
                 int ard, const void* var, const void* Text, const void* Y, int64_t sY, const void* w, const void* noise, double a1,
@@ -432,6 +734,13 @@ int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, i
     a.N = M; a.N2 = SB; a.Q = Q; a.ard = ard;
     a.U = (const T*)Text + M * SB; a.Y = (const T*)Y; a.sY = sY; a.B = B; a.w = (const T*)w; a.noise = (const T*)noise;
     a.dY = (T*)dY; a.dY_shared = dY_shared; a.R = (T*)R; a.scal = scal; a.a1 = a1; a.P = P;
+    if constexpr (sizeof(T) == 4) {
+        static const int mf_env = getenv("MXF_BWD_MFMA") ? atoi(getenv("MXF_BWD_MFMA")) : 1;
+        if (mf_env && P == 1 && Q <= 8 && SB % 4 == 0 && SB >= 16 && B % 16 == 0 && ((uintptr_t)Text % 16) == 0)
+            return launch_mfma(h, kind, M, SB, B, Q, (const float*)Z, (const float*)Xall, (const float*)ls, ard, (const float*)var, (const float*)Text,
+                               (const float*)Y, sY, (const float*)w, (const float*)noise, a1, (float*)dZ, (float*)dXall, (float*)dls, (float*)dvar,
+                               (float*)dY, dY_shared, (float*)R, scal, st);
+    }
     if (P == 1) return launch_kind<T, 1>(h, kind, a, 1, st);
     return launch_kind<T, PMAX_ALL>(h, kind, a, 1, st);
 }
