@@ -746,6 +746,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
 
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
+    // (training step on the split path whose reverse pass runs on the matrix pipe: T is written in 16-column blocks, so that each 16 x 16
+    //  tile that pass reads is one contiguous KB instead of 16 pieces of 64 bytes, 4 SB bytes apart)
+    const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_is_mfma(dtype, SB, B, Q, P, Text)) ? 1 : 0;
     if (use_split) {
         unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
         if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st); if (rc) return rc; }
@@ -756,7 +759,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
-                                     split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr);
+                                     split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr, nullptr, t_blocked);
     else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
@@ -841,7 +844,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
         rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
-                                         dY, dY_shared, R, scal, st);
+                                         dY, dY_shared, R, scal, st, t_blocked);
         if (rc) return rc;
     }
     if (!het) {

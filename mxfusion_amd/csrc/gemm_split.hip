@@ -129,6 +129,7 @@ struct SplitArgs {
     int64_t pA, pB, ldc;
     float alpha, beta;
     int splitk, lower_only, atomic, nprod, use_dma;
+    int c_blk;                  // C in 16-column blocks: element (row, col) at ((col / 16) * M + row) * 16 + col % 16 (the SVGP reverse pass reads T so)
     int64_t kchunk;             // k blocks per split
     int64_t tm, tn, ntiles, nwg;
     const float* ad0; int pow0;          // alpha *= ad0[0]^pow0 (device scalar, e.g. the kernel variance of Gram planes)
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(SNT, (NP == 2 && !DMA) ? 4 : 3) void gemm_split_ker
                 const int64_t row = m0 + wm + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t col = n0 + wn + y * 32 + (lane & 31);
                 if (row < g.M && col < g.N && !(g.lower_only && col > row)) {
-                    float* p = g.C + row * g.ldc + col;
+                    float* p = g.c_blk ? g.C + ((col >> 4) * g.M + row) * 16 + (col & 15) : g.C + row * g.ldc + col;
                     const float v = alpha * c[x][y][r];
                     if (atomic) atomic_add(p, v);
                     else *p = (beta == 0.f) ? v : v + beta * (*p);
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int64_t col = n0 + 64 * wave + 32 * y + 8 * q + 4 * lk;
-                float* p = g.C + row * g.ldc + col;
+                float* p = g.c_blk ? g.C + ((col >> 4) * g.M + row) * 16 + (col & 15) : g.C + row * g.ldc + col;
                 f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
                 if (g.lower_only && col + 3 > row) {             // tile on the diagonal: element-wise
 #pragma unroll
@@ -531,9 +532,11 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 // [k0, k0+K) of a (R x Ktot) operand is the pointer planes + (k0 / 16) * R * 16 with the FULL operand's plane stride.
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
-                            int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2) {
+                            int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
+    g.c_blk = c_blocked;
+    if (c_blocked && (N % 16 != 0 || beta != 0.0 || lower_only || ldc != N)) MXF_FAIL(h, -2, "mxf_gemm_split: the blocked output layout needs N %% 16 == 0, ldc == N, beta == 0 and a full product");
     g.ad0 = ad0; g.pow0 = pow0; g.maxbits = maxbits; g.maxbits2 = maxbits2;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
     g.pA = pA; g.pB = pB; g.ldc = ldc;

@@ -12,6 +12,7 @@
 // (dX / dZ, R) are wavefront-shuffle reduced per row and accumulated in an LDS band racc[RB][.] across all
 // the block's column tiles, so global atomics are RB*(Q+P) per block instead of per wave-row.
 #include "common.h"
+#include "internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -364,23 +365,54 @@ struct BwdMfmaArgs {
     float* dls3;                         // [8]: sum_n x_nq^2 C_n
     float* dvar; double* scal;
     int64_t M, SB, B, sY;
-    int Q, ard, CT, dY_shared;
+    int Q, ard, CT, dY_shared, tblk;     // tblk: T in 16-column blocks, element (m, n) at ((n / 16) * M + m) * 16 + n % 16
     double a1;
 };
 
-constexpr int MF_MT = 8;             // row tiles of 16 per band: 4 accumulator registers each (16 tiles spill: the allocator chains each
+#ifndef MXF_MF_MT
+#define MXF_MF_MT 8
+#endif
+constexpr int MF_MT = MXF_MF_MT;             // row tiles of 16 per band: 4 accumulator registers each (16 tiles spill: the allocator chains each
                                      // accumulating MFMA through a second register quad)
 constexpr int MF_RB = 16 * MF_MT;    // rows per band
+// MFMA chains as ONE inline-asm statement each.  (1) A chain on one accumulator must issue back to back: a single foreign instruction
+// between two dependent v_mfma_f32_16x16x4_f32 costs ~43 cycles (MI355X_MICROARCH.md), and the scheduler happily puts v_exp_f32 there.
+// (2) In place ("+v"): through the builtin the register allocator chains every accumulation through a second register quad.
+// The hazard recogniser does not see these: their results are read hundreds of cycles later (dots: next row tile) or after explicit s_nops.
+#define MF_DOT2(d, a0, b0, a1, b1)                                                                                      \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0"                         \
+                 : "=&v"(d) : "v"(a0), "v"(b0), "v"(a1), "v"(b1))
+// the ten MFMAs of a pipeline stage in ONE block, the three chains (dots of the next tile, row side of this tile, column side of the
+// previous tile) interleaved so that no two neighbours share an accumulator: they issue every 32 cycles (a dependent neighbour waits 40)
+#define MF_STAGE(d, xa0_, zb0_, xa1_, zb1_, c1, w0, x0, w1, x1, w2, x2, w3, x3, c2, t0, z0, t1, z1, t2, z2, t3, z3)      \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %3, %4, 0\n\t"                                                             \
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %8, %1\n\t"                                                            \
+                 "v_mfma_f32_16x16x4_f32 %2, %15, %16, %2\n\t"                                                          \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\t"                                                            \
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %10, %1\n\t"                                                           \
+                 "v_mfma_f32_16x16x4_f32 %2, %17, %18, %2\n\t"                                                          \
+                 "v_mfma_f32_16x16x4_f32 %1, %11, %12, %1\n\t"                                                          \
+                 "v_mfma_f32_16x16x4_f32 %2, %19, %20, %2\n\t"                                                          \
+                 "v_mfma_f32_16x16x4_f32 %1, %13, %14, %1\n\t"                                                          \
+                 "v_mfma_f32_16x16x4_f32 %2, %21, %22, %2"                                                               \
+                 : "=&v"(d), "+v"(c1), "+v"(c2)                                                                          \
+                 : "v"(xa0_), "v"(zb0_), "v"(xa1_), "v"(zb1_), "v"(w0), "v"(x0), "v"(w1), "v"(x1), "v"(w2), "v"(x2), "v"(w3), "v"(x3),   \
+                   "v"(t0), "v"(z0), "v"(t1), "v"(z1), "v"(t2), "v"(z2), "v"(t3), "v"(z3))
+#define MF_ACC4(c, a0, b0, a1, b1, a2, b2, a3, b3)                                                                      \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0\n\t"                   \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\tv_mfma_f32_16x16x4_f32 %0, %7, %8, %0"                         \
+                 : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3))
 
 template <int KIND, bool FULL>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks)
-__global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
+__global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
     constexpr int QT = 8;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) float za[MF_RB][16];     // [z (scaled, 8) | 1 | 0 ...]: B operand of the column-side product, and of the dots
-    __shared__ __attribute__((aligned(8))) float zw[MF_RB][2];       // [|z|^2, w]
+    // LDS tables of the band (bank-conflict free for the access patterns below: PMC showed half of the LDS cycles in conflicts before)
+    __shared__ __attribute__((aligned(16))) float za[MF_RB][16];     // [z (scaled, 8) | 1 | 0 ...]: B operand of the column-side product (row-contiguous reads)
+    __shared__ __attribute__((aligned(16))) float zd[MF_RB][12];     // [z (8) | |z|^2 | w | - | -]: lanes read (row li, word lq): 12-word rows keep 16 rows x 4 words apart
     __shared__ float rowacc[MF_RB][10];
-    __shared__ __attribute__((aligned(16))) float wt[4][16][16];     // per wave: the W tile, transposed on the way through
+    __shared__ __attribute__((aligned(16))) float wt[4][2][16][20];  // per wave, double-buffered: the W tile, transposed on the way through (20-word rows)
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
     const int64_t band0 = (int64_t)blockIdx.y * MF_RB;
@@ -396,12 +428,12 @@ __global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
     }
     for (int r = tid; r < MF_RB; r += 256) {
         float n2 = 0.f;
-        if (band0 + r < a.M) {
+        const bool ok = band0 + r < a.M;
 #pragma unroll
-            for (int q = 0; q < QT; ++q) { const float v = a.Zs[(band0 + r) * QT + q]; n2 = fmaf(v, v, n2); }
-        }
-        zw[r][0] = n2;
-        zw[r][1] = (band0 + r < a.M) ? a.w[band0 + r] : 0.f;
+        for (int q = 0; q < QT; ++q) { const float v = ok ? a.Zs[(band0 + r) * QT + q] : 0.f; zd[r][q] = v; n2 = fmaf(v, v, n2); }
+        zd[r][8] = n2;
+        zd[r][9] = ok ? a.w[band0 + r] : 0.f;
+        zd[r][10] = 0.f; zd[r][11] = 0.f;
     }
     for (int i = tid; i < MF_RB * 10; i += 256) (&rowacc[0][0])[i] = 0.f;
     __syncthreads();
@@ -418,7 +450,8 @@ __global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
         if (lane == 0 && cur_s >= 0) { atomic_add(a.scal + 2 * cur_s, qs); if (blockIdx.y == 0) atomic_add(a.scal + 2 * cur_s + 1, es); }
         qsum = 0.0; esum = 0.0;
     };
-    float* wtw = &wt[wave][0][0];
+    float* wtw = &wt[wave][0][0][0];
+    constexpr int WTB = 16 * 20;      // words per transpose buffer
     // row of T this lane reads in row tile mt: band0 + 16 mt + li (clamped: ragged rows are masked, not skipped -- no branches around loads)
     const int64_t rowl = band0 + li;
 
@@ -457,32 +490,53 @@ __global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
         f32x4 C2 = f32x4{0.f, 0.f, 0.f, 0.f};
         // T rows of this lane: band0 + li + 16 mt, walked with a running pointer (the row offsets are column-tile invariant: computed up
         // front they would sit in 2 registers per row tile); ragged bands clamp to the last row and mask the value instead of branching
-        const float* tp = Tm + n0c + rowl * a.SB;
-        const float* const tlast = Tm + n0c + (a.M - 1) * a.SB;
-        const int64_t tstep = 16 * a.SB;
+        const float* tp = a.tblk ? Tm + ((nt0 >> 4) * a.M + rowl) * 16 + 4 * lq : Tm + n0c + rowl * a.SB;
+        const float* const tlast = a.tblk ? Tm + ((nt0 >> 4) * a.M + a.M - 1) * 16 + 4 * lq : Tm + n0c + (a.M - 1) * a.SB;
+        const int64_t tstep = a.tblk ? 256 : 16 * a.SB;      // blocked: a wave's 16 x 16 tile is ONE contiguous KB, the next row tile the next KB
         auto tload = [&]() -> f32x4 {
             const float* q = (FULL || tp <= tlast) ? tp : tlast;
             tp += tstep;
             return *reinterpret_cast<const f32x4*>(q);
         };
         f32x4 tq0 = tload(), tq1 = tload();
+        // software pipeline over the row tiles: the dot products of tile mt + 1 are issued BEFORE the arithmetic of tile mt (whose dots were
+        // issued one iteration earlier), and the accumulating products of tile mt / the transposed product of tile mt - 1 AFTER it -- so the
+        // matrix pipe works on ten MFMAs while the VALU does the next tile, instead of the two taking turns
+        // (tile 0's dots through the builtin: their first use follows at once, and only the builtin tells the hazard recogniser)
+        f32x4 dotc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0, zd[li][lq], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dotc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1, zd[li][4 + lq], dotc, 0, 0, 0);
+        f32x2 zwc = *reinterpret_cast<const f32x2*>(&zd[li][8]);
+        float zbn0 = zd[(1 < MF_MT ? 16 : 0) + li][lq], zbn1 = zd[(1 < MF_MT ? 16 : 0) + li][4 + lq];
+        f32x2 zwn = *reinterpret_cast<const f32x2*>(&zd[(1 < MF_MT ? 16 : 0) + li][8]);
 #pragma unroll
         for (int mt = 0; mt < MF_MT; ++mt) {
             const int rl = mt * 16 + li;
-            asm volatile("" ::: "memory");        // the band's LDS tables never change inside the column loop: without this the compiler hoists all their
-                                                 // reads out of it (9 registers per row tile)
+            asm volatile("" ::: "memory");
             const f32x4 tq2 = (mt + 2 < MF_MT) ? tload() : tq1;                     // two row tiles ahead
             f32x4 tv = tq0;
             if (!FULL) { const bool ok = cval && rowl + 16 * mt < a.M; tv = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f}; }
-            const float zb0 = za[rl][lq], zb1 = za[rl][4 + lq];
-            const f32x2 zwv = *reinterpret_cast<const f32x2*>(&zw[rl][0]);
-            f32x4 dot = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0, zb0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            dot = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1, zb1, dot, 0, 0, 0);      // dot[t] = x_(n0 + t) . z_(row rl)
+            f32x4 dotn = dotc;
+            const f32x2 zwv = zwc;
+            zwc = zwn;
+            const float zbc0 = zbn0, zbc1 = zbn1;                   // operands of the NEXT tile's dot products (this stage's MFMA block)
+            if (mt + 2 < MF_MT) {                                   // ... and those two tiles ahead, |z|^2 and w
+                zbn0 = zd[rl + 32][lq]; zbn1 = zd[rl + 32][4 + lq];
+                zwn = *reinterpret_cast<const f32x2*>(&zd[rl + 32][8]);
+            }
+            // the transposed copy of the PREVIOUS row tile (written one iteration ago)
+            float wtr[4], zb2[4];
+            if (mt > 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    wtr[t] = wtw[((mt - 1) & 1) * WTB + (lq + 4 * t) * 20 + li];
+                    zb2[t] = za[(mt - 1) * 16 + lq + 4 * t][li];
+                }
+            }
             const float wm = zwv[1];
             f32x4 W;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float r2 = fmaf(-2.f, dot[t], zwv[0] + xx[t]);
+                float r2 = fmaf(-2.f, dotc[t], zwv[0] + xx[t]);
                 r2 = r2 > 0.f ? r2 : 0.f;
                 float k, w;
                 cov_and_slope<float, KIND>(r2, k, w);
@@ -492,20 +546,34 @@ __global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
                 gvar = fmaf(g, k, gvar);
                 qn = fmaf(kv, tv[t], qn);
                 racc[mt] = fmaf(kv, e[t], racc[mt]);
-                C1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[t], bx[t], C1[mt], 0, 0, 0);      // [B | S] += W . [X | 1]
             }
-            // transpose the tile through LDS: written as (m = li, n = 4 lq .. + 3), read as (n = li, m = lq + 4 t)
+            // this stage's MFMAs: dots of tile mt + 1, [B | S] += W . [X | 1] of tile mt, [D | C] += W^T . [Z | 1] of tile mt - 1
+            if (mt > 0 && mt + 1 < MF_MT) {
+                MF_STAGE(dotn, xa0, zbc0, xa1, zbc1, C1[mt], W[0], bx[0], W[1], bx[1], W[2], bx[2], W[3], bx[3],
+                         C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
+            } else {
+                if (mt + 1 < MF_MT) MF_DOT2(dotn, xa0, zbc0, xa1, zbc1);
+                MF_ACC4(C1[mt], W[0], bx[0], W[1], bx[1], W[2], bx[2], W[3], bx[3]);
+                if (mt > 0) MF_ACC4(C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
+            }
+            // transpose the tile through LDS: written as (m = li, n = 4 lq .. + 3), read (next iteration) as (n = li, m = lq + 4 t)
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<f32x4*>(wtw + li * 16 + 4 * lq) = W;
+            *reinterpret_cast<f32x4*>(wtw + (mt & 1) * WTB + li * 20 + 4 * lq) = W;
             __builtin_amdgcn_wave_barrier();
+            tq0 = tq1; tq1 = tq2;
+            dotc = dotn;
+            __builtin_amdgcn_sched_barrier(0);      // keep the unrolled row tiles apart
+        }
+        {   // the last row tile's transposed product
+            float wtr[4], zb2[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float wtr = wtw[(lq + 4 * t) * 16 + li];
-                const float zb = za[mt * 16 + lq + 4 * t][li];
-                C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wtr, zb, C2, 0, 0, 0);                   // [D | C] += W^T . [Z | 1]
+                wtr[t] = wtw[((MF_MT - 1) & 1) * WTB + (lq + 4 * t) * 20 + li];
+                zb2[t] = za[(MF_MT - 1) * 16 + lq + 4 * t][li];
             }
-            tq0 = tq1; tq1 = tq2;
-            __builtin_amdgcn_sched_barrier(0);      // keep the unrolled row tiles apart: interleaving them costs > 250 registers
+            MF_ACC4(C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMA result -> VALU read: the hazard recogniser does not see it
         }
         qsum += (double)qn;
         // column side: C2[r] = [D | C] of column nt0 + 4 lq + r (= this lane's column n0 + r), entry j = li
@@ -520,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
         }
     }
     flush_scal();
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     // row side: C1[mt][r] = [B | S] of row band0 + 16 mt + 4 lq + r, column li; the block's four waves are combined in LDS first
 #pragma unroll
     for (int mt = 0; mt < MF_MT; ++mt) {
@@ -673,7 +742,7 @@ __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restri
 
 int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
                 const float* var, const float* Text, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dZ,
-                float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st) {
+                float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st, int t_blocked) {
     const size_t nacc = (size_t)M * 16 + 16;                                   // zeroed every call
     const size_t need = (nacc + ((size_t)M + (size_t)SB) * 8 + (size_t)SB) * sizeof(float);  // + the scaled coordinates and |x_n|^2
     if (need > h->bwd_acc_bytes) {
@@ -693,7 +762,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     BwdMfmaArgs a;
     a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
     a.dX = dX; a.dY = dY; a.zacc = h->bwd_acc; a.dls3 = h->bwd_acc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
-    a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1;
+    a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1; a.tblk = t_blocked;
     const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
     static const int64_t gt_env = getenv("MXF_BWD_MFMA_GRID") ? atoll(getenv("MXF_BWD_MFMA_GRID")) : 8192;
     int64_t ct = (quads * bands + gt_env - 1) / gt_env;
@@ -724,7 +793,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
 template <typename T>
 int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z, const void* Xall, const void* ls,
                 int ard, const void* var, const void* Text, const void* Y, int64_t sY, const void* w, const void* noise, double a1,
-                void* dZ, void* dXall, void* dls, void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st) {
+                void* dZ, void* dXall, void* dls, void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked) {
     GramBwdArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.square = 0;
@@ -735,12 +804,12 @@ int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, i
     a.U = (const T*)Text + M * SB; a.Y = (const T*)Y; a.sY = sY; a.B = B; a.w = (const T*)w; a.noise = (const T*)noise;
     a.dY = (T*)dY; a.dY_shared = dY_shared; a.R = (T*)R; a.scal = scal; a.a1 = a1; a.P = P;
     if constexpr (sizeof(T) == 4) {
-        static const int mf_env = getenv("MXF_BWD_MFMA") ? atoi(getenv("MXF_BWD_MFMA")) : 1;
-        if (mf_env && P == 1 && Q <= 8 && SB % 4 == 0 && SB >= 16 && B % 16 == 0 && ((uintptr_t)Text % 16) == 0)
+        if (mxf_svgp_bwd_is_mfma(MXF_F32, SB, B, Q, P, Text))
             return launch_mfma(h, kind, M, SB, B, Q, (const float*)Z, (const float*)Xall, (const float*)ls, ard, (const float*)var, (const float*)Text,
                                (const float*)Y, sY, (const float*)w, (const float*)noise, a1, (float*)dZ, (float*)dXall, (float*)dls, (float*)dvar,
-                               (float*)dY, dY_shared, (float*)R, scal, st);
+                               (float*)dY, dY_shared, (float*)R, scal, st, t_blocked);
     }
+    if (t_blocked) MXF_FAIL(h, -2, "svgp fused reverse pass: only the matrix-pipe pass reads T in blocks");
     if (P == 1) return launch_kind<T, 1>(h, kind, a, 1, st);
     return launch_kind<T, PMAX_ALL>(h, kind, a, 1, st);
 }
@@ -758,13 +827,18 @@ int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int
 
 // SVGP-fused reverse pass over Text = [H0; w^T] Kuf_all (rows 0..M-1: T, rows M..M+P-1: U); column-side output dXall is
 // WRITTEN (not accumulated); dZ, dls, dvar, R, scal are accumulated into (caller zeroes); dY written or (shared) accumulated.
+bool mxf_svgp_bwd_is_mfma(int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text) {
+    static const int mf_env = getenv("MXF_BWD_MFMA") ? atoi(getenv("MXF_BWD_MFMA")) : 1;
+    return mf_env && dtype == MXF_F32 && P == 1 && Q <= 8 && SB % 4 == 0 && SB >= 16 && B % 16 == 0 && ((uintptr_t)Text % 16) == 0;
+}
+
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
-                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st) {
+                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked) {
     if (P > PMAX_ALL) MXF_FAIL(h, -3, "svgp fused reverse pass: P > %d", PMAX_ALL);
-    if (dtype == MXF_F32) return fused_typed<float>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st);
-    if (dtype == MXF_F64) return fused_typed<double>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st);
+    if (dtype == MXF_F32) return fused_typed<float>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked);
+    if (dtype == MXF_F64) return fused_typed<double>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked);
     MXF_FAIL(h, -2, "svgp fused reverse pass: bad dtype %d", dtype);
 }
 

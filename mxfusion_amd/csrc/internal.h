@@ -22,11 +22,14 @@ int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int
                           const void* X2, int64_t sX2, const void* ls, int ard, int64_t sls, const void* var, int64_t svar,
                           const void* dK, int64_t lddk, int64_t sdK, void* dX, void* dX2, void* dls, void* dvar, hipStream_t st);
 
+// true if mxf_svgp_bwd_fused_internal takes the matrix-pipe pass for these arguments; that pass reads T in 16-column blocks
+// (element (m, n) at ((n / 16) * M + m) * 16 + n % 16: mxf_gemm_split_internal's c_blocked output) when called with t_blocked = 1
+bool mxf_svgp_bwd_is_mfma(int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text);
 // SVGP-fused reverse pass over Text = [H0; w^T] Kuf_all (never materialises dKuf); see gram_bwd.hip
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
-                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st);
+                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked = 0);
 
 // f32-accurate GEMM on the bf16 matrix pipe (three-term bf16 splitting, gemm_split.hip)
 size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE plane of an (R x K) operand
@@ -39,7 +42,7 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus = 0, int mode = MXF_SPLIT_BF16X3, const float* ad0 = nullptr, int pow0 = 0,
-                            const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr);
+                            const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr, int c_blocked = 0);
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
                              int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st,
