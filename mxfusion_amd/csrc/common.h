@@ -21,7 +21,7 @@ struct mxf_ctx {
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
     double* cond_dev = nullptr; // [ |Kuu + jitter I|_1, |(Kuu + jitter I)^-1|_1 ] of the last SVGP training call (mxf_svgp_last_cond)
-    float* bwd_acc = nullptr;  // row-side sums of the MFMA reverse pass (gram_bwd.hip): [M][16] + 16 floats
+    void* bwd_acc = nullptr;   // scratch of the MFMA reverse pass (gram_bwd.hip): float64 row-side sums [M][16] + 16, scaled coordinates
     size_t bwd_acc_bytes = 0;
     void* comm = nullptr;      // RCCL communicator of mxf_comm_init (comm.hip); nullptr on single-GPU handles
     int comm_nranks = 0, comm_rank = -1;

@@ -361,8 +361,8 @@ struct BwdMfmaArgs {
     const float* Xn;                     // |x_n|^2 of the scaled coordinates
     const float* ls; const float* var; const float* T; const float* U; const float* Y; const float* w;
     const float* noise;
-    float* dX; float* dY; float* zacc;   // zacc [M][16]: 0..7 B_mq, 8 S_m, 9 R_m (zeroed by the launcher)
-    float* dls3;                         // [8]: sum_n x_nq^2 C_n
+    float* dX; float* dY; double* zacc;  // zacc [M][16]: 0..7 B_mq, 8 S_m, 9 R_m (zeroed by the launcher); float64: ~10^3 workgroups add into it
+    double* dls3;                        // [8]: sum_n x_nq^2 C_n
     float* dvar; double* scal;
     int64_t M, SB, B, sY;
     int Q, ard, CT, dY_shared, tblk;     // tblk: T in 16-column blocks, element (m, n) at ((n / 16) * M + m) * 16 + n % 16
@@ -604,48 +604,49 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     __syncthreads();
     for (int i = tid; i < MF_RB * 10; i += 256) {
         const int r = i / 10, c = i % 10;
-        if (band0 + r < a.M) atomic_add(a.zacc + (band0 + r) * 16 + c, rowacc[r][c]);
+        if (band0 + r < a.M) atomic_add(a.zacc + (band0 + r) * 16 + c, (double)rowacc[r][c]);
     }
     if (a.dvar) { const float v = block_sum<float>(gvar, red); if (tid == 0) atomic_add(a.dvar, v); }
     {   // sum_n x_nq^2 C_n: lane (q = li) holds its share
         float v = (li < Q) ? dl3 : 0.f;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16 && li < Q) atomic_add(a.dls3 + li, v);
+        if (lane < 16 && li < Q) atomic_add(a.dls3 + li, (double)v);
     }
 }
 
-// dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one block)
+// dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one block; float64: z^2 S - 2 z B + x^2 C cancels a digit or two)
 __global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z, const float* __restrict__ ls,
-                                                              const float* __restrict__ zacc, const float* __restrict__ dls3,
+                                                              const double* __restrict__ zacc, const double* __restrict__ dls3,
                                                               float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R) {
-    __shared__ float red[16];
+    __shared__ double red[16];
     const int tid = threadIdx.x;
-    float g12[8];
+    double g12[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) g12[q] = 0.f;
+    for (int q = 0; q < 8; ++q) g12[q] = 0.0;
     for (int64_t m = tid; m < M; m += 256) {
-        const float S = zacc[m * 16 + 8];
-        if (R) R[m] += zacc[m * 16 + 9];
+        const double S = zacc[m * 16 + 8];
+        if (R) R[m] += (float)zacc[m * 16 + 9];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q < Q) {
-                const float ilq = 1.f / ls[ard ? q : 0], z = Z[m * Q + q] * ilq, Bq = zacc[m * 16 + q];
-                if (dZ) dZ[m * Q + q] += (z * S - Bq) * ilq;
-                g12[q] += z * (z * S - 2.f * Bq);
+                const double ilq = 1.0 / (double)ls[ard ? q : 0];
+                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0]), Bq = zacc[m * 16 + q];
+                if (dZ) dZ[m * Q + q] += (float)((z * S - Bq) * ilq);
+                g12[q] += z * (z * S - 2.0 * Bq);
             }
         }
     }
-    float tot = 0.f;
+    double tot = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float v = block_sum<float>(g12[q], red);
+        const double v = block_sum<double>(g12[q], red);
         if (tid == 0 && q < Q) {
-            const float glq = -(v + dls3[q]);            // sum over pairs of -W d_q^2
-            if (ard) { if (dls) dls[q] += glq / ls[q]; } else tot += glq;
+            const double glq = -(v + dls3[q]);            // sum over pairs of -W d_q^2
+            if (ard) { if (dls) dls[q] += (float)(glq / (double)ls[q]); } else tot += glq;
         }
     }
-    if (tid == 0 && !ard && dls) dls[0] += tot / ls[0];
+    if (tid == 0 && !ard && dls) dls[0] += (float)(tot / (double)ls[0]);
 }
 
 template <typename T, int QT, int KIND, int PT>
@@ -743,8 +744,8 @@ __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restri
 int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
                 const float* var, const float* Text, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dZ,
                 float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st, int t_blocked) {
-    const size_t nacc = (size_t)M * 16 + 16;                                   // zeroed every call
-    const size_t need = (nacc + ((size_t)M + (size_t)SB) * 8 + (size_t)SB) * sizeof(float);  // + the scaled coordinates and |x_n|^2
+    const size_t nacc = ((size_t)M * 16 + 16) * sizeof(double);                                    // bytes, zeroed every call
+    const size_t need = nacc + (((size_t)M + (size_t)SB) * 8 + (size_t)SB) * sizeof(float);        // + the scaled coordinates and |x_n|^2
     if (need > h->bwd_acc_bytes) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
@@ -753,15 +754,16 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
         if (hipMalloc((void**)&h->bwd_acc, need) != hipSuccess) { h->bwd_acc = nullptr; MXF_FAIL(h, -4, "svgp reverse pass: cannot allocate %zu bytes", need); }
         h->bwd_acc_bytes = need;
     }
-    MXF_HIP(h, hipMemsetAsync(h->bwd_acc, 0, nacc * sizeof(float), st));
-    float* Zs = h->bwd_acc + nacc;
+    MXF_HIP(h, hipMemsetAsync(h->bwd_acc, 0, nacc, st));
+    double* zacc = reinterpret_cast<double*>(h->bwd_acc);
+    float* Zs = reinterpret_cast<float*>(reinterpret_cast<char*>(h->bwd_acc) + nacc);
     float* Xs = Zs + (size_t)M * 8;
     float* Xn = Xs + (size_t)SB * 8;
     hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr);
     hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, X, SB, Q, ls, ard, Xs, Xn);
     BwdMfmaArgs a;
     a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
-    a.dX = dX; a.dY = dY; a.zacc = h->bwd_acc; a.dls3 = h->bwd_acc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
+    a.dX = dX; a.dY = dY; a.zacc = zacc; a.dls3 = zacc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
     a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1; a.tblk = t_blocked;
     const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
     static const int64_t gt_env = getenv("MXF_BWD_MFMA_GRID") ? atoll(getenv("MXF_BWD_MFMA_GRID")) : 8192;
@@ -785,7 +787,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
         default: MXF_FAIL(h, -2, "svgp reverse pass: kind %d has no stationary reverse mode", kind);
     }
 #undef MF_GO
-    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3(1), dim3(256), 0, st, M, Q, ard, Z, ls, (const float*)a.zacc, (const float*)a.dls3, dZ, dls, R);
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3(1), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
