@@ -615,38 +615,41 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     }
 }
 
-// dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one block; float64: z^2 S - 2 z B + x^2 C cancels a digit or two)
+// dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one row per thread; float64: z^2 S - 2 z B + x^2 C cancels a digit or two)
 __global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z, const float* __restrict__ ls,
                                                               const double* __restrict__ zacc, const double* __restrict__ dls3,
                                                               float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R) {
     __shared__ double red[16];
     const int tid = threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * 256 + tid;
     double g12[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) g12[q] = 0.0;
-    for (int64_t m = tid; m < M; m += 256) {
+    if (m < M) {
         const double S = zacc[m * 16 + 8];
         if (R) R[m] += (float)zacc[m * 16 + 9];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q < Q) {
                 const double ilq = 1.0 / (double)ls[ard ? q : 0];
-                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0]), Bq = zacc[m * 16 + q];
+                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0]), Bq = zacc[m * 16 + q];      // the pass's own scaled coordinate (float32 quotient)
                 if (dZ) dZ[m * Q + q] += (float)((z * S - Bq) * ilq);
-                g12[q] += z * (z * S - 2.0 * Bq);
+                g12[q] = z * (z * S - 2.0 * Bq);
             }
         }
     }
+    if (!dls) return;
     double tot = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
+        if (q >= Q) break;
         const double v = block_sum<double>(g12[q], red);
-        if (tid == 0 && q < Q) {
-            const double glq = -(v + dls3[q]);            // sum over pairs of -W d_q^2
-            if (ard) { if (dls) dls[q] += (float)(glq / (double)ls[q]); } else tot += glq;
+        if (tid == 0) {
+            const double glq = -(v + (blockIdx.x == 0 ? dls3[q] : 0.0));            // sum over pairs of -W d_q^2 (this block's rows; block 0 adds the column term)
+            if (ard) atomic_add(dls + q, (float)(glq / (double)ls[q])); else tot += glq;
         }
     }
-    if (tid == 0 && !ard && dls) dls[0] += (float)(tot / (double)ls[0]);
+    if (tid == 0 && !ard) atomic_add(dls, (float)(tot / (double)ls[0]));
 }
 
 template <typename T, int QT, int KIND, int PT>
@@ -787,7 +790,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
         default: MXF_FAIL(h, -2, "svgp reverse pass: kind %d has no stationary reverse mode", kind);
     }
 #undef MF_GO
-    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3(1), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R);
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }

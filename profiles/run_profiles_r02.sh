@@ -28,4 +28,9 @@ for w in t psi2; do
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $O/pmc_${w}_lds -o g -- python $R/tests/probes/split_pmc.py $w > $O/pmc_${w}_lds.log 2>&1
   python $R/profiles/pmc_summary.py gemm_ $O/gemm_${w}_pmc.json $O/pmc_${w}_fetch $O/pmc_${w}_write $O/pmc_${w}_sq $O/pmc_${w}_lds > $O/gemm_${w}_pmc.txt 2>&1
 done
+# 5. PMC passes of the matrix-pipe reverse pass (inside the bench step)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_bwd_sq -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_bwd_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $O/pmc_bwd_lds -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_bwd_lds.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_bwd_fetch -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_bwd_fetch.log 2>&1
+python $R/profiles/pmc_summary.py svgp_bwd_mfma $O/bwd_pmc.json $O/pmc_bwd_sq $O/pmc_bwd_lds $O/pmc_bwd_fetch > $O/bwd_pmc.txt 2>&1
 ls -R $O | head -60
