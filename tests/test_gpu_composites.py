@@ -18,6 +18,9 @@ def _dev(a, dtype=torch.float64):
 
 
 _REPORT = {}
+# float32 gradients against the float64 oracle, normwise (|error| <= tol * (|ref| + max|ref|)): the worst case over this file is 6e-4
+# (MXF_TEST_REPORT=1 prints the worst error / bound ratio per quantity); it was 5e-3 in round 1
+F32_GTOL = 1.5e-3
 
 
 def _close(got, ref, rtol, name='', floor=None):
@@ -47,7 +50,7 @@ if os.environ.get('MXF_TEST_REPORT'):
     @atexit.register
     def _print_report():
         for (name, rtol), r in sorted(_REPORT.items(), key=lambda kv: -kv[1]):
-            print('CLOSE-REPORT %-18s rtol %.1e  worst error / bound = %.3f' % (name, rtol, r))
+            print('CLOSE-REPORT %-18s rtol %.1e  worst error / bound = %.2e' % (name, rtol, r))
 
 
 def test_gp_logpdf_golden(golden_dir):
@@ -65,7 +68,7 @@ def test_gp_logpdf_golden(golden_dir):
 
 
 @pytest.mark.parametrize('kind', ['rbf', 'matern52', 'matern32'])
-@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])     # float32: worst observed 6e-8 (value), 6e-5 (gradients)
 @pytest.mark.parametrize('N,Q,P,S', [(200, 4, 2, 1), (700, 8, 1, 2), (2240, 5, 2, 1)])     # N >= 2048: L^-1 Y through the explicit inverse
 def test_gp_logpdf_vs_oracle(kind, dtype, tol, N, Q, P, S):
     if N > 2000 and kind not in ('rbf', 'matern32'):
@@ -85,11 +88,11 @@ def test_gp_logpdf_vs_oracle(kind, dtype, tol, N, Q, P, S):
     _close(r['logL'], logL, tol, 'logL')
     for s in range(S):
         grads = torch.autograd.grad(logL[s], [leaves[n] for n in ('X', 'Y', 'noise', 'ls', 'var')], retain_graph=True)
-        _close(r['dX'][s], grads[0][s], tol * 20, 'dX')
-        _close(r['dY'][s], grads[1][0], tol * 20, 'dY')
-        _close(r['dnoise'][s], grads[2][0], tol * 20, 'dnoise')
-        _close(r['dls'][s], grads[3][0], tol * 20, 'dls')
-        _close(r['dvar'][s], grads[4][0], tol * 20, 'dvar')
+        _close(r['dX'][s], grads[0][s], tol * 30, 'dX')
+        _close(r['dY'][s], grads[1][0], tol * 30, 'dY')
+        _close(r['dnoise'][s], grads[2][0], tol * 30, 'dnoise')
+        _close(r['dls'][s], grads[3][0], tol * 30, 'dls')
+        _close(r['dvar'][s], grads[4][0], tol * 30, 'dvar')
 
 
 def test_svgp_logpdf_golden(golden_dir):
@@ -137,7 +140,7 @@ def test_svgp_logpdf_vs_oracle(kind, dtype, tol, B, M, Q, P, S):
                         _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=2.0, gscale=1.0 / S, want_grad=True)
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, tol, 'logL')          # north_star: 1e-5 relative on the ELBO
-    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    gtol = tol * 50 if dtype == torch.float64 else F32_GTOL
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
 
@@ -169,7 +172,7 @@ def test_svgp_logpdf_heteroscedastic_vs_oracle(dtype, tol, nshape, B, M, Q, P, S
                         _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=1.5, gscale=1.0 / S, want_grad=True)
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, tol, 'logL')
-    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    gtol = tol * 50 if dtype == torch.float64 else F32_GTOL
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
 
@@ -213,7 +216,7 @@ def test_svgp_logpdf_mat_vs_oracle(dtype, tol, nshape):
     r = ops.svgp_logpdf_mat(*[_dev(vals[n], dtype) for n in names], jitter=1e-6, scaling=3.0, gscale=1.0, want_grad=True)
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, tol, 'logL')
-    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    gtol = tol * 50 if dtype == torch.float64 else F32_GTOL
     for n, key in zip(names, ('dKuu', 'dKuf', 'dKdiag', 'dY', 'dnoise', 'dmu', 'dW', 'dSdiag')):
         got, ref = r[key], grads[names.index(n)]
         if key == 'dKuu':      # autograd of the oracle gives the gradient w.r.t. an unconstrained (non-symmetric) Kuu: compare symmetrised
@@ -248,7 +251,7 @@ def test_svgp_logpdf_f32_split_path_vs_oracle(kind, B, M, Q, P, S):
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, 1e-5, 'logL')
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
-        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], 5e-3, key)
+        _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], F32_GTOL, key)
     # and the forward-only call (plain f32 kernels) agrees with the training call's value
     r0 = ops.svgp_logpdf(kind, _dev(X, dt), _dev(Y[None], dt), _dev(Z, dt), _dev(noise, dt), _dev(qm, dt), _dev(qW, dt), _dev(qd, dt),
                          _dev(ls, dt), _dev(var, dt), True, jitter=1e-6, scaling=1.0, gscale=1.0 / S, want_grad=False)
@@ -287,7 +290,7 @@ def test_svgp_logpdf_input_and_output_widths(dtype, tol, Q, P):
                         _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-5, gscale=1.0 / S, want_grad=True)
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, tol, 'logL')
-    gtol = tol * 1000 if dtype == torch.float64 else 5e-3
+    gtol = tol * 1000 if dtype == torch.float64 else F32_GTOL
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
 
@@ -319,7 +322,7 @@ def test_svgp_logpdf_sampled_outputs_over_shared_inputs(dtype, tol, B, M, Q, P, 
                         _dev(qd, dtype), _dev(ls, dtype), _dev(var, dtype), True, jitter=1e-6, scaling=2.0, gscale=1.0 / S, want_grad=True)
     assert int(r['info'].abs().sum()) == 0
     _close(r['logL'], logL, tol, 'logL')
-    gtol = tol * 50 if dtype == torch.float64 else 5e-3
+    gtol = tol * 50 if dtype == torch.float64 else F32_GTOL
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):
         _close(r[key].reshape(grads[names.index(n)].shape), grads[names.index(n)], gtol, key)
     # the same through the materialised-Gram entry point
