@@ -572,6 +572,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.force_dist and world == 1:          # stand-alone run of the RCCL code path: supply what the launcher would
+            for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0'), ('MASTER_PORT', '29517')):
+                os.environ.setdefault(k, v)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if args.samples % world:
         raise SystemExit('--samples must be divisible by the number of GPUs')
