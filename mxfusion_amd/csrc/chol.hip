@@ -228,6 +228,249 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     }
 }
 
+// ---- persistent tile-dataflow Cholesky (float64, n a multiple of 64, n <= 1024): ONE launch, one workgroup per 64-row block row --------
+// The launch-per-panel form above costs 16 x (panel kernel ~45 us + left-looking GEMM + two dependent-launch gaps) at n = 1024: 0.86 ms,
+// every one of them on the critical path of the SVGP step when few samples are left per GPU.  Here workgroup i owns
+// block row i and walks its tiles j = 0 .. i left-looking:
+//     C = A[i][j] - sum_{k<j} L[i][k] L[j][k]^T      (ONE k loop of length 64 j over two contiguous row panels, f64 MFMA)
+//     j < i :  L[i][j] = C L[j][j]^-T                 (row solve against block row j's diagonal factor)
+//     j = i :  L[i][i] = chol(C)
+// and hands tiles on through a progress counter per block row (release store after the tile is in memory; readers acquire): tile (i, j)
+// needs progress[j] >= j before its k loop and progress[j] == j + 1 before its solve.  The diagonal tile's update is accumulated
+// incrementally (one 64^3 product after every solve), so the critical path per block column is factor (19 us) -> solve of the next row's
+// tile -> one product -> factor.  Every workgroup must be resident at once (<= 32 workgroups); spins are bounded (a lost hand-off reports
+// info = -1 instead of hanging the queue).
+constexpr int PT_SLD = 66;      // LDS row stride of the staged k chunks (as the small GEMM)
+typedef double pt_f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t n, int* __restrict__ info,
+                                                          int* __restrict__ progress_all) {
+    __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
+    __shared__ double invd[NB];
+    __shared__ double t[NB][NB + 1];          // the tile being solved
+    __shared__ double sm[2][2][16 * PT_SLD];  // k chunks of the two row panels
+    __shared__ int sflag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int i = blockIdx.x, b = blockIdx.y, nbk = (int)(n / NB);
+    double* Ab = A + (int64_t)b * sA;
+    int* progress = progress_all + (int64_t)b * nbk;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    bool lost = false;
+
+    auto wait_for = [&](int row, int need) {          // all threads: block until progress[row] >= need
+        if (tid == 0) {
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(progress + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 26)) { ok = 0; break; }
+            }
+            sflag = ok;
+        }
+        __syncthreads();
+        if (!sflag) lost = true;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);         // every wave: drop stale lines before reading the published tiles
+    };
+    // C (this wave's 32 x 32 quadrant, accumulator layout) += P[rows r0 ..][k0 .. k1) . Q[rows q0 ..][k0 .. k1)^T, both row panels of A
+    auto panel_product = [&](pt_f64x4 (&c)[2][2], int64_t r0, int64_t q0, int64_t k0, int64_t k1, int gate_row) {
+        const int qmn = tid >> 2, qk0 = (tid & 3) * 4;
+        double ra[4], rb[4];
+        auto load = [&](int64_t k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[j] = Ab[(r0 + qmn) * lda + k + qk0 + j]; rb[j] = Ab[(q0 + qmn) * lda + k + qk0 + j]; }
+        };
+        auto store = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sm[buf][0][(qk0 + j) * PT_SLD + qmn] = ra[j]; sm[buf][1][(qk0 + j) * PT_SLD + qmn] = rb[j]; }
+        };
+        if (k0 >= k1) return;
+        if (gate_row >= 0) wait_for(gate_row, (int)(k0 / NB) + 1);
+        load(k0); store(0);
+        __syncthreads();
+        int cur = 0;
+        for (int64_t k = k0; k < k1; k += 16) {
+            const bool more = k + 16 < k1;
+            if (more) {
+                if (gate_row >= 0 && ((k + 16) % NB) == 0) wait_for(gate_row, (int)((k + 16) / NB) + 1);   // the next 64-column tile of row gate_row
+                load(k + 16);
+            }
+            const double* As = sm[cur][0];
+            const double* Bs = sm[cur][1];
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 4) {
+                double av[2], bv[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { av[x] = As[(ks + lq) * PT_SLD + wm + 16 * x + li]; bv[x] = Bs[(ks + lq) * PT_SLD + wn + 16 * x + li]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], c[x][y], 0, 0, 0);
+            }
+            if (more) store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    auto zero = [&](pt_f64x4 (&c)[2][2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) c[x][y] = pt_f64x4{0.0, 0.0, 0.0, 0.0};
+    };
+    // accumulator element (x, y, r) <-> tile element (row wm + 16 x + lq + 4 r, column wn + 16 y + li)
+    const int64_t ri = (int64_t)i * NB;
+    pt_f64x4 cd[2][2];          // running sum_k L[i][k] L[i][k]^T of the diagonal tile
+    zero(cd);
+
+    for (int j = 0; j < i; ++j) {
+        const int64_t rj = (int64_t)j * NB;
+        pt_f64x4 c[2][2];
+        zero(c);
+        panel_product(c, ri, rj, 0, rj, j);                       // sum_{k<j} L[i][k] L[j][k]^T  (row j's tiles k < j: gated on progress[j])
+        wait_for(j, j + 1);                                        // L[j][j]
+        for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; a[r][cc] = (cc <= r) ? Ab[(rj + r) * lda + rj + cc] : 0.0; }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = wm + 16 * x + lq + 4 * r, cc = wn + 16 * y + li;
+                    t[rr][cc] = Ab[(ri + rr) * lda + rj + cc] - c[x][y][r];
+                }
+        __syncthreads();
+        if (tid < NB) invd[tid] = 1.0 / a[tid][tid];
+        __syncthreads();
+        // X L[j][j]^T = T: 16 columns at a time by substitution (one row per lane of wave 0), the remaining columns by MFMA (one 16-row tile per wave)
+        for (int blk = 0; blk < NB; blk += 16) {
+            if (wave == 0) {
+                double x[16];
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    double s0 = t[lane][blk + c2], s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k + 1 < c2; k += 2) { s0 = fma(-x[k], a[blk + c2][blk + k], s0); s1 = fma(-x[k + 1], a[blk + c2][blk + k + 1], s1); }
+                    if (c2 & 1) s0 = fma(-x[c2 - 1], a[blk + c2][blk + c2 - 1], s0);
+                    x[c2] = (s0 + s1) * invd[blk + c2];
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) t[lane][blk + c2] = x[c2];
+            }
+            __syncthreads();
+            if (blk + 16 < NB) {
+                const int rr = wave * 16;
+                double af[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) af[q] = -t[rr + li][blk + 4 * q + lq];
+                for (int J0 = blk + 16; J0 < NB; J0 += 16) {
+                    pt_f64x4 cf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cf[r] = t[rr + lq + 4 * r][J0 + li];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], a[J0 + li][blk + 4 * q + lq], cf, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[rr + lq + 4 * r][J0 + li] = cf[r];
+                }
+                __syncthreads();
+            }
+        }
+        for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + rj + cc] = t[r][cc]; }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // the diagonal tile's share of this column, straight from the solved tile in LDS: cd += L[i][j] L[i][j]^T
+#pragma unroll 4
+        for (int ks = 0; ks < NB; ks += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { av[x] = t[wm + 16 * x + li][ks + lq]; bv[x] = t[wn + 16 * x + li][ks + lq]; }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) cd[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], cd[x][y], 0, 0, 0);
+        }
+        __syncthreads();                                           // t is rewritten by the next tile
+    }
+    // diagonal tile: factor A[i][i] - cd
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = wm + 16 * x + lq + 4 * r, cc = wn + 16 * y + li;
+                a[rr][cc] = (cc <= rr) ? Ab[(ri + rr) * lda + ri + cc] - cd[x][y][r] : 0.0;
+            }
+    __syncthreads();
+    for (int blk = 0; blk < NB; blk += 16) {
+        if (wave == 0) {                                   // 16 x 16 sub-block, a row per lane in registers
+            double r[16];
+#pragma unroll
+            for (int c2 = 0; c2 < 16; ++c2) r[c2] = a[blk + li][blk + c2];
+            int bad = -1;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                double d = readlane_t(r[jj], jj);
+                if (!(d > 0.0)) { if (bad < 0) bad = jj; d = 1.0; }
+                const double inv = inv_sqrt(d);
+                const double l = (li == jj) ? d * inv : r[jj] * inv;
+                r[jj] = l;
+                if (lane == 0) invd[blk + jj] = inv;
+#pragma unroll
+                for (int c2 = jj + 1; c2 < 16; ++c2) r[c2] = fma(-l, readlane_t(l, c2), r[c2]);
+            }
+            if (bad >= 0 && lane == 0 && info && info[b] == 0) info[b] = (int)(ri + blk + bad + 1);
+            if (lane < 16) {
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) a[blk + lane][blk + c2] = (c2 <= lane) ? r[c2] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (blk + 16 < NB) {
+            const int rr = blk + 16 + tid;                 // rows below the sub-block: X L_bb^T = A_ib
+            if (rr < NB) {
+                double x[16];
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) {
+                    double s0 = a[rr][blk + c2], s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k + 1 < c2; k += 2) { s0 = fma(-x[k], a[blk + c2][blk + k], s0); s1 = fma(-x[k + 1], a[blk + c2][blk + k + 1], s1); }
+                    if (c2 & 1) s0 = fma(-x[c2 - 1], a[blk + c2][blk + c2 - 1], s0);
+                    x[c2] = (s0 + s1) * invd[blk + c2];
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < 16; ++c2) a[rr][blk + c2] = x[c2];
+            }
+            __syncthreads();
+            int tix = 0;                                   // trailing lower tiles of 16 x 16, dealt to the four waves
+            for (int I0 = blk + 16; I0 < NB; I0 += 16)
+                for (int J0 = blk + 16; J0 <= I0; J0 += 16, ++tix) {
+                    if ((tix & 3) != wave) continue;
+                    double af[4], bf[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { af[q] = -a[I0 + li][blk + 4 * q + lq]; bf[q] = a[J0 + li][blk + 4 * q + lq]; }
+                    pt_f64x4 cf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cf[r] = a[I0 + lq + 4 * r][J0 + li];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[q], cf, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[I0 + lq + 4 * r][J0 + li] = cf[r];
+                }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + ri + cc] = (cc <= r) ? a[r][cc] : 0.0; }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lost && info) info[b] = -1;
+        if (i == nbk - 1) {            // the last block row finishes last (its every step waits for the row above): leave the counters at zero
+            for (int r = 0; r < nbk; ++r) __hip_atomic_store(progress + r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- op(L_kk) X = B_k (X overwrites B_k): one right-hand-side column per lane ------------------------------
 // TRANS: solve L_kk^T X = B_k by index reversal (P L^T P is lower triangular)
 template <typename T, bool TRANS>
@@ -411,6 +654,18 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
+    if constexpr (sizeof(T) == 8) {
+        static const int tiles_env = getenv("MXF_POTRF_TILES") ? atoi(getenv("MXF_POTRF_TILES")) : 1;
+        if (tiles_env && n % NB == 0 && n >= 2 * NB && n <= 1024 && S <= 64) {    // n = 2048: 2.6 ms vs 1.9 ms (the last block rows carry 32 i^2 columns of products each)
+            const unsigned nbk = (unsigned)(n / NB);
+            int* progress = mxf_flags(h, nbk * (unsigned)S);
+            if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
+            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, n, info, progress);
+            if (zero_upper) hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
+            MXF_LAUNCH_CHECK(h);
+            return 0;
+        }
+    }
     static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
