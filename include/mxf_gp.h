@@ -134,7 +134,9 @@ int mxf_gemm_f32x3(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, 
 int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
                    double beta, void* C, int64_t ldc, int lower_only, void* stream);
 /* Its two halves: mxf_f16x2_split writes the two planes of an (R x K) operand (2 * mxf_f32x3_plane_elems(R, K) 16-bit elements) and
- * the 32-bit word holding the bit pattern of max |X| (the operand's scale); mxf_gemm_f16x2_planes multiplies two split operands.      */
+ * the 32-bit word holding the bit pattern of max |X| (the operand's scale); mxf_gemm_f16x2_planes multiplies two split operands.
+ * mxf_gemm_f16x2_planes only: lower_only = 2 writes the FULL product with C in 16-column blocks -- element (m, n) at
+ * ((n / 16) * M + m) * 16 + n % 16, ldc ignored, N % 16 == 0, beta == 0 -- the layout the SVGP training step keeps T = H0 Kuf in.         */
 int mxf_f16x2_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* maxword, void* stream);
 int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
                           const void* B_planes, const void* B_maxword, double beta, void* C, int64_t ldc, int lower_only, void* stream);

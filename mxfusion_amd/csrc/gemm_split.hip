@@ -342,7 +342,11 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
     __shared__ u32x4 smem[3][2][256];              // [ring slot][plane][16-byte unit]: 3 x 8 KB (A only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int64_t wid = blockIdx.x;
+    // Persistent over the (tile, k split) work items: workgroup b takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so its items
+    // stay on its XCD's run of tiles).  The epilogue's stores of one item drain while the next item's first loads are in flight; with one
+    // item per workgroup every tile paid a dispatch + an un-overlapped pipeline fill + a store burst (~30 % of a K = 1024 tile).
+    for (int64_t wid0 = blockIdx.x; wid0 < g.nwg; wid0 += gridDim.x) {
+    int64_t wid = wid0;
     {   // XCD-aware mapping: every XCD owns a contiguous run of tiles
         const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -491,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
                 }
             }
     }
+    }   // work items
 }
 
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
@@ -545,9 +550,13 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     g.nprod = nprod;
     static const int use_dma = getenv("MXF_SPLIT_DMA") ? atoi(getenv("MXF_SPLIT_DMA")) : 1;
     g.use_dma = use_dma;
-    static const int wide_env = getenv("MXF_SPLIT_WIDE") ? atoi(getenv("MXF_SPLIT_WIDE")) : 2;
-    // MXF_SPLIT_WIDE: 0 = never, 1 = whenever the shape allows, 2 (default) = only for the long-K lower-triangle products (Psi2)
-    const bool wide = wide_env && (wide_env != 2 || lower_only) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % WBM) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
+    static const int wide_env = getenv("MXF_SPLIT_WIDE") ? atoi(getenv("MXF_SPLIT_WIDE")) : 3;
+    // MXF_SPLIT_WIDE: 0 = never, 1 = whenever the shape allows, 2 = only the long-K lower-triangle products (Psi2), 3 (default) = those and
+    // products written in 16-column blocks (T of the training step).  The kernel's epilogue puts ROWS on lanes: fine for a blocked C
+    // (rows are 64 bytes apart) and for the small square Psi2, 16-byte pieces 4 N bytes apart for a wide row-major C -- the T shape then
+    // takes 16.7 ms instead of 13.4 on the 128 x 128 kernel, blocked it takes 12.3.  (Before the kernel walked its work items persistently
+    // the blocked T lost 1.9 ms on it as well.)
+    const bool wide = wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % WBM) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
                       (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N);
     int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
@@ -585,7 +594,10 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     }
     const bool dma = g.use_dma && (M % SBM) == 0 && (N % SBN) == 0;
     if (wide) {
-        hipLaunchKernelGGL(gemm_f16x2_wide_kernel, dim3((unsigned)g.nwg), dim3(256), 0, st, g);
+        // persistent: two workgroups per CU (the kernel's occupancy) walk the work items; fewer items than that: one each
+        static const int64_t wide_grid = getenv("MXF_SPLIT_WIDE_GRID") ? atoll(getenv("MXF_SPLIT_WIDE_GRID")) : 512;
+        const int64_t grid = (wide_grid >= 8 && g.nwg > wide_grid) ? wide_grid / 8 * 8 : g.nwg;
+        hipLaunchKernelGGL(gemm_f16x2_wide_kernel, dim3((unsigned)grid), dim3(256), 0, st, g);
         MXF_LAUNCH_CHECK(h);
         return 0;
     }
@@ -662,9 +674,11 @@ extern "C" int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t
                                      const void* B_planes, const void* B_maxword, double beta, void* C, int64_t ldc, int lower_only, void* stream) {
     if (!h) return -1;
     if (M <= 0 || N <= 0 || K <= 0 || !A_planes || !B_planes || !A_maxword || !B_maxword || !C) MXF_FAIL(h, -2, "mxf_gemm_f16x2_planes: bad argument");
+    const int blocked = lower_only == 2;            // lower_only = 2: full product, C in 16-column blocks (include/mxf_gp.h)
     return mxf_gemm_split_internal(h, M, N, K, alpha, (const unsigned short*)A_planes, (int64_t)mxf_split_plane_elems(M, K),
-                                   (const unsigned short*)B_planes, (int64_t)mxf_split_plane_elems(N, K), beta, (float*)C, ldc, lower_only,
-                                   (hipStream_t)stream, 0, MXF_SPLIT_F16X2, nullptr, 0, (const unsigned*)A_maxword, (const unsigned*)B_maxword);
+                                   (const unsigned short*)B_planes, (int64_t)mxf_split_plane_elems(N, K), beta, (float*)C, blocked ? N : ldc,
+                                   blocked ? 0 : lower_only, (hipStream_t)stream, 0, MXF_SPLIT_F16X2, nullptr, 0, (const unsigned*)A_maxword,
+                                   (const unsigned*)B_maxword, blocked);
 }
 
 // the two halves of mxf_gemm_f32x3 for callers that reuse split operands: planes = 3 * mxf_f32x3_plane_elems(R, K) bf16 (uint16) elements

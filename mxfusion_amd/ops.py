@@ -125,13 +125,14 @@ def f16x2_split(X):
     return planes, word
 
 
-def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, lower_only=False):
-    """C = alpha A B^T + beta C from operands already split by f16x2_split (reuse across products)."""
+def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, lower_only=False, blocked=False):
+    """C = alpha A B^T + beta C from operands already split by f16x2_split (reuse across products).  blocked: the full product with C in
+    16-column blocks, element (m, n) at ((n // 16) * M + m) * 16 + n % 16 of `out` (the layout the SVGP training step keeps T in)."""
     (pa, wa), (pb, wb) = A_split, B_split
     if out is None:
         out = torch.zeros((M, N), dtype=torch.float32, device=pa.device) if lower_only else torch.empty((M, N), dtype=torch.float32, device=pa.device)
     _lib.call('mxf_gemm_f16x2_planes', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), float(beta), _p(out), out.stride(0),
-              int(bool(lower_only)), _stream())
+              2 if blocked else int(bool(lower_only)), _stream())
     return out
 
 

@@ -88,6 +88,27 @@ def test_gemm_f16x2_is_f32_accurate(M, N, K, lower, mag):
     assert torch.equal(Cp * msk, C2 * msk) or float((((Cp.double() - ref).abs() / scale) * msk).max()) < 6e-7
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 256, 16), (256, 512, 1040), (1024, 8192, 1024), (130, 48, 50), (384, 65536, 64)])
+def test_gemm_f16x2_planes_blocked_output_is_the_row_major_product_reordered(M, N, K):
+    """lower_only = 2 of mxf_gemm_f16x2_planes: the full product with C in 16-column blocks, element (m, n) at ((n / 16) * M + m) * 16 + n % 16
+    -- the layout the SVGP training step keeps T = H0 Kuf in (both GEMM kernels; the persistent 128 x 256 one walks several work items per
+    workgroup at the larger shapes).  Must equal the row-major product bit for bit where the same kernel computes both, to rounding otherwise."""
+    from mxfusion_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    B = torch.rand(N, K, device='cuda', generator=g) - 0.3
+    pa, pb = ops.f16x2_split(A), ops.f16x2_split(B)
+    C = ops.gemm_f16x2_planes(pa, pb, M, N, K)
+    out = torch.full((M * N,), float('nan'), device='cuda')
+    ops.gemm_f16x2_planes(pa, pb, M, N, K, out=out.view(M, N), blocked=True)
+    Cb = out.view(N // 16, M, 16).permute(1, 0, 2).reshape(M, N)
+    assert not torch.isnan(Cb).any()
+    ref = A.double() @ B.double().T
+    scale = A.double().abs() @ B.double().abs().T
+    assert float(((Cb.double() - ref).abs() / scale).max()) < 6e-7
+    assert float(((Cb - C).abs() / scale.float()).max()) < 3e-7
+
+
 def test_gemm_f16x2_zero_operand():
     from mxfusion_amd import ops
     A = torch.zeros(128, 64, device='cuda')
