@@ -59,6 +59,16 @@ int64_t mxf_workspace_generation(mxf_handle h);
  * no such call.  (No reference counterpart: svgp_regression.py:83-92 solves with the Cholesky factor, in whatever dtype the model has.) */
 int mxf_svgp_last_cond(mxf_handle h, double* cond1_out);
 
+/* out[0] = sum_i g[i] if the n values agree to 1e-6 relative, NaN otherwise.  The fused composites return the gradients of
+ * gscale * sum_s logL[s] with ONE weight: the reverse-mode bridge uses this to scale them by the upstream gradient of mean_S(logL)
+ * (factor_graph.py:233) and to poison the result -- on the device, no host sync -- if a caller weights the samples unequally.            */
+int mxf_uniform_sum(mxf_handle h, int dtype, int64_t n, const void* g, void* out, void* stream);
+
+/* MXNet SGD as driven by gluon.Trainer.step with optimizer='sgd' (the `optimizer` argument of batch_loop.py:29-44 is handed to the Trainer
+ * by name): g = rescale_grad * grad + wd * w;  mom == NULL: w -= lr g;  else mom = momentum * mom - lr * g, w += mom.                     */
+int mxf_sgd_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* mom, double lr, double momentum, double wd,
+                 double rescale_grad, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU gradient exchange (RCCL over xGMI), SURVEY.md section 8(b)/(e).  The reference has no multi-device path (one MXNet context
  * per Inference object); north_star shards the Monte-Carlo samples of StochasticVariationalInference.compute

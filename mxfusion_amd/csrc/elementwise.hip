@@ -230,6 +230,49 @@ extern "C" int mxf_adam_step(mxf_handle h, int dtype, int64_t n, void* w, const 
              hipLaunchKernelGGL((adam_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)m, (double*)v, lr_t, beta1, beta2, epsilon, rescale_grad));
 }
 
+// out[0] = sum_i g[i] if all g[i] agree to 1e-6 relative, NaN otherwise (n small: the upstream gradient of the per-sample log-pdfs)
+template <typename T>
+__global__ __launch_bounds__(64) void uniform_sum_kernel(int64_t n, const T* __restrict__ g, T* __restrict__ out) {
+    T s = 0, lo = g[0], hi = g[0];
+    for (int64_t i = threadIdx.x; i < n; i += 64) { const T v = g[i]; s += v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const T l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64); lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+    if (threadIdx.x == 0) {
+        const T mean = s / (T)n, a = mean < 0 ? -mean : mean;
+        out[0] = (hi - lo <= (T)1e-6 * a) ? s : (T)NAN;
+    }
+}
+
+extern "C" int mxf_uniform_sum(mxf_handle h, int dtype, int64_t n, const void* g, void* out, void* stream) {
+    if (!h) return -1;
+    if (n <= 0 || !g || !out) MXF_FAIL(h, -2, "mxf_uniform_sum: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_uniform_sum",
+             hipLaunchKernelGGL((uniform_sum_kernel<float>), dim3(1), dim3(64), 0, st, n, (const float*)g, (float*)out),
+             hipLaunchKernelGGL((uniform_sum_kernel<double>), dim3(1), dim3(64), 0, st, n, (const double*)g, (double*)out));
+}
+
+// MXNet SGD (optimizer 'sgd' of gluon.Trainer): g = rescale * grad + wd * w; momentum == 0: w -= lr g; else mom = momentum mom - lr g, w += mom
+template <typename T>
+__global__ void sgd_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ g, T* __restrict__ mom, T lr, T momentum, T wd, T rescale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T gi = g[i] * rescale + wd * w[i];
+        if (mom) { const T mi = momentum * mom[i] - lr * gi; mom[i] = mi; w[i] += mi; }
+        else w[i] -= lr * gi;
+    }
+}
+
+extern "C" int mxf_sgd_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* mom, double lr, double momentum, double wd,
+                            double rescale_grad, void* stream) {
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(h, dtype, "mxf_sgd_step",
+             hipLaunchKernelGGL((sgd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, n, (float*)w, (const float*)g, (float*)mom, (float)lr, (float)momentum, (float)wd, (float)rescale_grad),
+             hipLaunchKernelGGL((sgd_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)mom, lr, momentum, wd, rescale_grad));
+}
+
 extern "C" int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, const void* A, int64_t lda, int64_t strideS_A,
                           const void* B, int64_t ldb, int64_t strideS_B, void* out, void* stream) {
     if (!h) return -1;

@@ -10,19 +10,33 @@ from .grad_loop import GradLoop
 
 
 class _Adam(object):
-    """MXNet Adam as driven by gluon.Trainer.step(batch_size): rescale_grad = 1/batch_size."""
+    """gluon.Trainer.step(batch_size) for the optimizers the reference's loops are called with by name (batch_loop.py:29-44 passes
+    `optimizer` and {'learning_rate': lr} to the Trainer): MXNet 'adam' (the default) and 'sgd' (plain, or
+    optimizer=('sgd', {'momentum': 0.9, 'wd': 0.0})); rescale_grad = 1/batch_size.  One fused kernel over the flat parameter buffer."""
 
     def __init__(self, params, learning_rate, optimizer='adam'):
-        if optimizer != 'adam':
-            raise NotImplementedError("only optimizer='adam' (the reference default) is implemented")
+        opts = {}
+        if isinstance(optimizer, (tuple, list)):
+            optimizer, opts = optimizer[0], dict(optimizer[1])
+        if optimizer not in ('adam', 'sgd'):
+            raise NotImplementedError("optimizer %r: 'adam' (the reference default) and 'sgd' are implemented" % (optimizer,))
+        self.kind, self.opts = optimizer, opts
         self.params, self.lr, self.t = params, learning_rate, 0
-        self.m = torch.zeros_like(params.flat.detach())
-        self.v = torch.zeros_like(params.flat.detach())
+        flat = params.flat.detach()
+        if optimizer == 'adam':
+            self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        else:
+            self.m = torch.zeros_like(flat) if opts.get('momentum', 0.0) != 0.0 else None
 
     def step(self, batch_size=1):
         self.t += 1
         flat = self.params.flat
-        ops.adam_step_(flat.detach(), flat.grad, self.m, self.v, self.lr, self.t, rescale_grad=1.0 / batch_size)
+        if self.kind == 'adam':
+            ops.adam_step_(flat.detach(), flat.grad, self.m, self.v, self.lr, self.t, beta1=self.opts.get('beta1', 0.9),
+                           beta2=self.opts.get('beta2', 0.999), epsilon=self.opts.get('epsilon', 1e-8), rescale_grad=1.0 / batch_size)
+        else:
+            ops.sgd_step_(flat.detach(), flat.grad, self.m, self.lr, momentum=self.opts.get('momentum', 0.0), wd=self.opts.get('wd', 0.0),
+                          rescale_grad=1.0 / batch_size)
         self.params.zero_grad()
 
 

@@ -277,6 +277,20 @@ def adam_step_(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, epsilon=1e-8, rescale_
               float(epsilon), float(rescale_grad), int(t), _stream())
 
 
+def uniform_sum(g):
+    """sum(g) if all entries of the (small) vector g agree to 1e-6 relative, NaN otherwise -- one launch, no host sync (mxf_uniform_sum)."""
+    g = _c(g)
+    out = torch.empty((), dtype=g.dtype, device=g.device)
+    _lib.call('mxf_uniform_sum', _h(g), _dt(g), g.numel(), _p(g), _p(out), _stream())
+    return out
+
+
+def sgd_step_(w, g, mom, lr, momentum=0.0, wd=0.0, rescale_grad=1.0):
+    """MXNet SGD on a flat buffer (mxf_sgd_step); mom = None for plain SGD."""
+    _lib.call('mxf_sgd_step', _h(w), _dt(w), w.numel(), _p(w), _p(g), None if mom is None else _p(mom), float(lr), float(momentum), float(wd),
+              float(rescale_grad), _stream())
+
+
 def gp_logpdf(kind, X, Y, noise_var, lengthscale, variance, ard, jitter=0.0, want_grad=False):
     """GPRegressionLogPdf.compute (gp_regression.py:42-76).  X (S|1,N,Q), Y (S|1,N,P) [minus mean], noise_var (S|1,1),
     lengthscale (S|1,Q|1), variance (S|1,1).  Returns dict(logL (S,), L (S,N,N), LinvY (S,N,P), info, grads...)."""

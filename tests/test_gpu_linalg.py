@@ -141,6 +141,22 @@ def test_elementwise_kernels(dtype, tol):
         p = opt.step(p, {'w': O.T(g)}, batch_size=4)
         ops.adam_step_(wd, _dev(g, dtype), m, v, 0.05, t, rescale_grad=0.25)
     assert np.allclose(wd.cpu().numpy(), p['w'].numpy(), rtol=tol * 10, atol=tol * 10)
+    # MXNet SGD (python/mxnet/optimizer: sgd_update / sgd_mom_update), plain and with momentum + weight decay, 3 steps in numpy float64
+    for momentum, wdecay in ((0.0, 0.0), (0.9, 1e-2)):
+        w0 = rng.randn(300)
+        wr, mr = w0.copy(), np.zeros(300)
+        wdev = _dev(w0, dtype)
+        mdev = torch.zeros(300, dtype=dtype).cuda() if momentum else None
+        for t in range(3):
+            g = rng.randn(300)
+            gi = 0.25 * g + wdecay * wr
+            if momentum:
+                mr = momentum * mr - 0.05 * gi
+                wr = wr + mr
+            else:
+                wr = wr - 0.05 * gi
+            ops.sgd_step_(wdev, _dev(g, dtype), mdev, 0.05, momentum=momentum, wd=wdecay, rescale_grad=0.25)
+        assert np.allclose(wdev.cpu().numpy(), wr, rtol=tol * 10, atol=tol * 10)
 
 
 def test_potrf_is_race_free_under_cu_contention():
