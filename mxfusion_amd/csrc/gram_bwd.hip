@@ -378,14 +378,17 @@ constexpr int MF_RB = 16 * MF_MT;    // rows per band
 // MFMA chains as ONE inline-asm statement each.  (1) A chain on one accumulator must issue back to back: a single foreign instruction
 // between two dependent v_mfma_f32_16x16x4_f32 costs ~43 cycles (MI355X_MICROARCH.md), and the scheduler happily puts v_exp_f32 there.
 // (2) In place ("+v"): through the builtin the register allocator chains every accumulation through a second register quad.
-// The hazard recogniser does not see these: their results are read hundreds of cycles later (dots: next row tile) or after explicit s_nops.
+// The hazard recogniser does not see these, so every block is hazard-complete by itself: s_nop 4 in front (VALU write -> MFMA read of a
+// source register) and s_nop 11 behind (12 wait states >= the 10 an 8-pass MFMA result needs before ANY instruction may touch it -- the
+// compiler is free to spill or copy an accumulator right after the block, and did so in the Matern-5/2 instance: wrong dZ until this).
 #define MF_DOT2(d, a0, b0, a1, b1)                                                                                      \
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0"                         \
+    asm volatile("s_nop 4\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0\n\ts_nop 11"       \
                  : "=&v"(d) : "v"(a0), "v"(b0), "v"(a1), "v"(b1))
 // the ten MFMAs of a pipeline stage in ONE block, the three chains (dots of the next tile, row side of this tile, column side of the
 // previous tile) interleaved so that no two neighbours share an accumulator: they issue every 32 cycles (a dependent neighbour waits 40)
 #define MF_STAGE(d, xa0_, zb0_, xa1_, zb1_, c1, w0, x0, w1, x1, w2, x2, w3, x3, c2, t0, z0, t1, z1, t2, z2, t3, z3)      \
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %3, %4, 0\n\t"                                                             \
+    asm volatile("s_nop 4\n\t"          /* VALU write -> MFMA read of the same VGPR needs wait states the compiler only inserts for builtins */ \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %4, 0\n\t"                                                             \
                  "v_mfma_f32_16x16x4_f32 %1, %7, %8, %1\n\t"                                                            \
                  "v_mfma_f32_16x16x4_f32 %2, %15, %16, %2\n\t"                                                          \
                  "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\t"                                                            \
@@ -394,13 +397,13 @@ constexpr int MF_RB = 16 * MF_MT;    // rows per band
                  "v_mfma_f32_16x16x4_f32 %1, %11, %12, %1\n\t"                                                          \
                  "v_mfma_f32_16x16x4_f32 %2, %19, %20, %2\n\t"                                                          \
                  "v_mfma_f32_16x16x4_f32 %1, %13, %14, %1\n\t"                                                          \
-                 "v_mfma_f32_16x16x4_f32 %2, %21, %22, %2"                                                               \
+                 "v_mfma_f32_16x16x4_f32 %2, %21, %22, %2\n\ts_nop 11"                                                    \
                  : "=&v"(d), "+v"(c1), "+v"(c2)                                                                          \
                  : "v"(xa0_), "v"(zb0_), "v"(xa1_), "v"(zb1_), "v"(w0), "v"(x0), "v"(w1), "v"(x1), "v"(w2), "v"(x2), "v"(w3), "v"(x3),   \
                    "v"(t0), "v"(z0), "v"(t1), "v"(z1), "v"(t2), "v"(z2), "v"(t3), "v"(z3))
 #define MF_ACC4(c, a0, b0, a1, b1, a2, b2, a3, b3)                                                                      \
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0\n\t"                   \
-                 "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\tv_mfma_f32_16x16x4_f32 %0, %7, %8, %0"                         \
+    asm volatile("s_nop 4\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\tv_mfma_f32_16x16x4_f32 %0, %3, %4, %0\n\t"           \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\tv_mfma_f32_16x16x4_f32 %0, %7, %8, %0\n\ts_nop 11"               \
                  : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3))
 
 template <int KIND, bool FULL>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks)

@@ -110,9 +110,12 @@ def test_svgp_logpdf_golden(golden_dir):
         _close(r[n].reshape(g[k].shape), g[k], 1e-8, n)
 
 
-@pytest.mark.parametrize('kind', ['rbf', 'matern52'])
+@pytest.mark.parametrize('kind', ['rbf', 'matern52', 'matern12'])
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
-@pytest.mark.parametrize('B,M,Q,P,S', [(300, 20, 3, 1, 1), (1000, 130, 8, 2, 3)])
+@pytest.mark.parametrize('B,M,Q,P,S', [(300, 20, 3, 1, 1), (1000, 130, 8, 2, 3),
+                                       # float32, one output column, B % 16 == 0: the matrix-pipe reverse pass with ragged row bands (M % 128 != 0),
+                                       # ragged column tiles (S B % 64 != 0) and padded coordinates (Q < 8)
+                                       (208, 20, 3, 1, 2), (1040, 130, 8, 1, 3), (48, 200, 5, 1, 1)])
 def test_svgp_logpdf_vs_oracle(kind, dtype, tol, B, M, Q, P, S):
     """sampled inputs X (S,B,Q) (the latent-input model of svgpregression_test.py:357-385), shared Y."""
     from mxfusion_amd import ops
