@@ -19,7 +19,9 @@ def _dev(a, dtype=torch.float64):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float32, 2e-4)])
-@pytest.mark.parametrize('S,n', [(1, 1), (2, 5), (1, 64), (3, 65), (1, 200), (2, 513), (1, 1100)])
+@pytest.mark.parametrize('S,n', [(1, 1), (2, 5), (1, 64), (3, 65), (1, 200), (2, 513), (1, 1100),
+                                 # n % 64 == 0, 128 <= n <= 1024 in float64: the one-launch tile-dataflow kernel (batched)
+                                 (3, 128), (2, 192), (1, 640), (2, 1024)])
 def test_potrf_trsm_trtri_logdet(dtype, tol, S, n):
     from mxfusion_amd import ops
     rng = np.random.RandomState(n)
@@ -45,6 +47,22 @@ def test_potrf_trsm_trtri_logdet(dtype, tol, S, n):
     B = rng.randn(2, n, 4)
     X = ops.trsm_(_dev(Lref[:1], dtype), _dev(B, dtype)).cpu().numpy()
     assert np.allclose(X, np.linalg.solve(Lref[:1], B), rtol=tol * 10, atol=tol * 10 * np.abs(X).max())
+
+
+def test_potrf_tiles_not_positive_definite_reports_info():
+    """the one-launch kernel (float64, n = 256): a negative pivot in the third block row of batch item 1 is reported (first failing index,
+    1-based), the factor stays finite, item 0 is untouched; and a launch right behind it starts from clean hand-off counters."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(5)
+    A = _spd(rng, 2, 256)
+    A[1, 150, 150] = -5.0
+    L, info = ops.potrf_(_dev(A, torch.float64))
+    L2, info2 = ops.potrf_(_dev(A[:1], torch.float64))
+    info = info.cpu().numpy()
+    assert info[0] == 0 and info[1] == 151, info
+    assert torch.isfinite(L).all()
+    assert np.allclose(L[0].cpu().numpy(), np.linalg.cholesky(A[0]), rtol=1e-11, atol=1e-11)
+    assert int(info2[0]) == 0 and np.allclose(L2[0].cpu().numpy(), np.linalg.cholesky(A[0]), rtol=1e-11, atol=1e-11)
 
 
 def test_potrf_not_positive_definite_reports_info():
