@@ -243,7 +243,10 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
 constexpr int PT_SLD = 66;      // LDS row stride of the staged k chunks (as the small GEMM)
 typedef double pt_f64x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t n, int* __restrict__ info,
+// Panel mode (large n): the same kernel factors ONE outer panel -- columns [c0, c0 + 64 npt), rows c0 .. n, one workgroup per block row
+// below c0 -- left-looking INSIDE the panel (columns left of c0 were applied by the trailing updates of the earlier panels): block rows
+// i < npt end with their diagonal tile, the others only solve.  nbr = block rows, counters: nbr progress words + one completion word.
+__global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int* __restrict__ info,
                                                           int* __restrict__ progress_all) {
     __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
     __shared__ double invd[NB];
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     __shared__ double sm[2][2][16 * PT_SLD];  // k chunks of the two row panels
     __shared__ int sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    const int i = blockIdx.x, b = blockIdx.y, nbk = (int)(n / NB);
+    const int i = blockIdx.x, b = blockIdx.y, nbk = (int)gridDim.x;
     double* Ab = A + (int64_t)b * sA;
-    int* progress = progress_all + (int64_t)b * nbk;
+    int* progress = progress_all + (int64_t)b * (nbk + 1);
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     bool lost = false;
 
@@ -283,14 +286,14 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
             for (int j = 0; j < 4; ++j) { sm[buf][0][(qk0 + j) * PT_SLD + qmn] = ra[j]; sm[buf][1][(qk0 + j) * PT_SLD + qmn] = rb[j]; }
         };
         if (k0 >= k1) return;
-        if (gate_row >= 0) wait_for(gate_row, (int)(k0 / NB) + 1);
+        if (gate_row >= 0) wait_for(gate_row, (int)((k0 - c0) / NB) + 1);
         load(k0); store(0);
         __syncthreads();
         int cur = 0;
         for (int64_t k = k0; k < k1; k += 16) {
             const bool more = k + 16 < k1;
             if (more) {
-                if (gate_row >= 0 && ((k + 16) % NB) == 0) wait_for(gate_row, (int)((k + 16) / NB) + 1);   // the next 64-column tile of row gate_row
+                if (gate_row >= 0 && ((k + 16 - c0) % NB) == 0) wait_for(gate_row, (int)((k + 16 - c0) / NB) + 1);   // the next 64-column tile of row gate_row
                 load(k + 16);
             }
             const double* As = sm[cur][0];
@@ -317,15 +320,16 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
             for (int y = 0; y < 2; ++y) c[x][y] = pt_f64x4{0.0, 0.0, 0.0, 0.0};
     };
     // accumulator element (x, y, r) <-> tile element (row wm + 16 x + lq + 4 r, column wn + 16 y + li)
-    const int64_t ri = (int64_t)i * NB;
+    const int64_t ri = c0 + (int64_t)i * NB;
     pt_f64x4 cd[2][2];          // running sum_k L[i][k] L[i][k]^T of the diagonal tile
     zero(cd);
+    const int jend = i < npt ? i : npt;
 
-    for (int j = 0; j < i; ++j) {
-        const int64_t rj = (int64_t)j * NB;
+    for (int j = 0; j < jend; ++j) {
+        const int64_t rj = c0 + (int64_t)j * NB;
         pt_f64x4 c[2][2];
         zero(c);
-        panel_product(c, ri, rj, 0, rj, j);                       // sum_{k<j} L[i][k] L[j][k]^T  (row j's tiles k < j: gated on progress[j])
+        panel_product(c, ri, rj, c0, rj, j);                      // sum_{k<j} L[i][k] L[j][k]^T  (row j's tiles k < j: gated on progress[j])
         wait_for(j, j + 1);                                        // L[j][j]
         for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; a[r][cc] = (cc <= r) ? Ab[(rj + r) * lda + rj + cc] : 0.0; }
 #pragma unroll
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         }
         __syncthreads();                                           // t is rewritten by the next tile
     }
+    if (i < npt) {
     // diagonal tile: factor A[i][i] - cd
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -462,12 +467,13 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + ri + cc] = (cc <= r) ? a[r][cc] : 0.0; }
     __threadfence();
     __syncthreads();
+    if (tid == 0) __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0) {
-        __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (lost && info) info[b] = -1;
-        if (i == nbk - 1) {            // the last block row finishes last (its every step waits for the row above): leave the counters at zero
-            for (int r = 0; r < nbk; ++r) __hip_atomic_store(progress + r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // the workgroup that completes last leaves the counters at zero for the next launch (every poll of a counter precedes the poller's own completion)
+        if (__hip_atomic_fetch_add(progress + nbk, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nbk - 1)
+            for (int r = 0; r <= nbk; ++r) __hip_atomic_store(progress + r, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -654,18 +660,21 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
+    static const int tiles_env = getenv("MXF_POTRF_TILES") ? atoi(getenv("MXF_POTRF_TILES")) : 1;
+    // tiles_env: 0 = launch-per-panel form everywhere, 1 = the one-launch kernel for n <= 1024 and per outer panel for larger n, 2 = only n <= 1024
+    const bool tiles_ok = sizeof(T) == 8 && tiles_env && n % NB == 0 && n >= 2 * NB && S <= 64;
     if constexpr (sizeof(T) == 8) {
-        static const int tiles_env = getenv("MXF_POTRF_TILES") ? atoi(getenv("MXF_POTRF_TILES")) : 1;
-        if (tiles_env && n % NB == 0 && n >= 2 * NB && n <= 1024 && S <= 64) {    // n = 2048: 2.6 ms vs 1.9 ms (the last block rows carry 32 i^2 columns of products each)
+        if (tiles_ok && n <= 1024) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
             const unsigned nbk = (unsigned)(n / NB);
-            int* progress = mxf_flags(h, nbk * (unsigned)S);
+            int* progress = mxf_flags(h, (nbk + 1) * (unsigned)S);
             if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
-            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, n, info, progress);
+            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, (int64_t)0, (int)nbk, info, progress);
             if (zero_upper) hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
             MXF_LAUNCH_CHECK(h);
             return 0;
         }
     }
+    const bool panel_tiles = tiles_ok && tiles_env == 1 && n > 1024 && n / NB <= 256;      // every block row's workgroup must be resident at once
     static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
@@ -674,7 +683,15 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     bool pending_b = false;
     for (int64_t c0 = 0; c0 < n; c0 += NBO) {
         const int64_t pe = (c0 + NBO < n) ? c0 + NBO : n;   // panel end
-        for (int64_t j0 = c0; j0 < pe; j0 += NB) {
+        if constexpr (sizeof(T) == 8) {
+            if (panel_tiles) {       // the whole outer panel in ONE launch (8 dependent panel steps + 7 left-looking GEMMs before)
+                const unsigned nbr = (unsigned)((n - c0) / NB);
+                int* progress = mxf_flags(h, (nbr + 1) * (unsigned)S);
+                if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
+                hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)((pe - c0) / NB), info, progress);
+            }
+        }
+        for (int64_t j0 = c0; j0 < pe && !panel_tiles; j0 += NB) {
             const int nb = (int)((j0 + NB < n) ? NB : n - j0);
             if (j0 > c0) {   // left-looking update of block column j0 with the panel's previous block columns
                 int rc = mxf_gemm_internal(h, dtype, 0, 1, n - j0, nb, j0 - c0, -1.0, A + j0 * lda + c0, lda, sA,

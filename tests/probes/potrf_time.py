@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
-    for v in ('1', '0'):
+    for v in ('1', '2', '0'):
         out = subprocess.run([sys.executable, __file__], env=dict(os.environ, MXF_POTRF_TILES=v), capture_output=True, text=True).stdout
         print('MXF_POTRF_TILES=%s | %s' % (v, ' | '.join(l.strip() for l in out.strip().splitlines())), flush=True)
     sys.exit(0)
@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mxfusion_amd import ops
 torch.manual_seed(0)
-for n in (512, 1024, 2048):
+for n in (512, 1024, 2048, 4096, 8192):
     X = torch.randn(n, 8, device='cuda', dtype=torch.float64)
     K = torch.exp(-0.5 * torch.cdist(X, X) ** 2) + 1e-3 * torch.eye(n, device='cuda', dtype=torch.float64)
     A = K[None].clone()

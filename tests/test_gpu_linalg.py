@@ -21,7 +21,9 @@ def _dev(a, dtype=torch.float64):
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float32, 2e-4)])
 @pytest.mark.parametrize('S,n', [(1, 1), (2, 5), (1, 64), (3, 65), (1, 200), (2, 513), (1, 1100),
                                  # n % 64 == 0, 128 <= n <= 1024 in float64: the one-launch tile-dataflow kernel (batched)
-                                 (3, 128), (2, 192), (1, 640), (2, 1024)])
+                                 (3, 128), (2, 192), (1, 640), (2, 1024),
+                                 # larger n % 64 == 0 in float64: the same kernel once per 512-column outer panel
+                                 (1, 1536), (2, 2048)])
 def test_potrf_trsm_trtri_logdet(dtype, tol, S, n):
     from mxfusion_amd import ops
     rng = np.random.RandomState(n)
