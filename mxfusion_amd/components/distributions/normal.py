@@ -15,12 +15,18 @@ class _NormalLogPdfSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, var, scaling):
         S = x.shape[0]
-        out = torch.zeros(1, dtype=x.dtype, device=x.device)
         need = [ctx.needs_input_grad[i] for i in range(3)]
-        dx = torch.zeros_like(x) if need[0] else None
         m1, v1 = mean.reshape(-1), var.reshape(-1)
-        dm = torch.zeros_like(m1) if need[1] else None
-        dv = torch.zeros_like(v1) if need[2] else None
+        # the kernel accumulates into its outputs: ONE zero-filled buffer carved into (out, dm, dv, dx) instead of four fills per call
+        # (the step's head and tail are paced by the number of launches, ~5 us each)
+        sizes = [1, m1.numel() if need[1] else 0, v1.numel() if need[2] else 0, x.numel() if need[0] else 0]
+        buf = torch.zeros(sum(sizes) + 12, dtype=x.dtype, device=x.device)
+        off = [0, 4, 4 + (sizes[1] + 3) // 4 * 4]                       # 16-byte aligned starts
+        off.append(off[2] + (sizes[2] + 3) // 4 * 4)
+        out = buf[0:1]
+        dm = buf[off[1]:off[1] + sizes[1]] if need[1] else None
+        dv = buf[off[2]:off[2] + sizes[2]] if need[2] else None
+        dx = buf[off[3]:off[3] + sizes[3]].view(x.shape) if need[0] else None
         ops.normal_logpdf_(x, m1, v1, float(scaling) / S, out, dx, dm, dv)
         ctx.grads = (dx, dm, dv, mean.shape, var.shape)
         return out.reshape(())
@@ -43,8 +49,9 @@ class _NormalReparamFn(torch.autograd.Function):
     def backward(ctx, dx):
         var, eps = ctx.saved_tensors
         ms, vs = ctx.shapes
-        dm = torch.zeros(var.numel(), dtype=var.dtype, device=var.device)
-        dv = torch.zeros_like(dm)
+        n = var.numel()
+        buf = torch.zeros(2 * ((n + 3) // 4 * 4), dtype=var.dtype, device=var.device)
+        dm, dv = buf[:n], buf[(n + 3) // 4 * 4:(n + 3) // 4 * 4 + n]
         ops.normal_reparam_bwd_(var.reshape(-1), eps, dx.contiguous(), dm, dv)
         return dm.reshape(ms), dv.reshape(vs), None
 
