@@ -423,8 +423,11 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     const float* __restrict__ Xs = a.Xs;
     const float* __restrict__ Tm = a.T;
     const float ilj = (li < Q) ? 1.f / a.ls[a.ard ? li : 0] : 0.f;                 // 1 / l of coordinate j = li (column flush)
+    constexpr bool RX = KIND == MXF_K_RBF;
+    constexpr float CS = RX ? 0.84932180028801904272f : 1.f;        // the coordinates' extra scale (bwd_prescale_kernel): sqrt(log2(e) / 2) for RBF
     const float variance = a.var[0];
     const float c1 = (float)a.a1 / a.noise[0];
+    const float kc = -c1 * variance;
     for (int i = tid; i < MF_RB * 16; i += 256) {
         const int r = i / 16, j = i % 16;
         za[r][j] = (band0 + r < a.M) ? ((j < QT) ? a.Zs[(band0 + r) * QT + j] : (j == 8 ? 1.f : 0.f)) : 0.f;
@@ -540,15 +543,25 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float r2 = fmaf(-2.f, dotc[t], zwv[0] + xx[t]);
-                r2 = r2 > 0.f ? r2 : 0.f;
-                float k, w;
-                cov_and_slope<float, KIND>(r2, k, w);
-                const float kv = k * variance;
-                const float g = c1 * fmaf(wm, e[t], tv[t]);
-                W[t] = 2.f * g * w * variance;
-                gvar = fmaf(g, k, gvar);
-                qn = fmaf(kv, tv[t], qn);
-                racc[mt] = fmaf(kv, e[t], racc[mt]);
+                if constexpr (RX) {
+                    // RBF: coordinates carry sqrt(log2(e) / 2) (as the forward Gram kernels'), so k = 2^-r2 is the bare v_exp_f32; the weight is
+                    // W = 2 g w variance = -(c1 variance) (T + w e) k; variance and the sum over pairs of g k are applied once, at the flush
+                    const float k = __builtin_amdgcn_exp2f(-r2);          // (r2 may round a few ulps below 0 for coincident points: k = 1 + O(1e-6))
+                    const float u = fmaf(wm, e[t], tv[t]);
+                    W[t] = kc * (u * k);
+                    qn = fmaf(k, tv[t], qn);
+                    racc[mt] = fmaf(k, e[t], racc[mt]);
+                } else {
+                    r2 = r2 > 0.f ? r2 : 0.f;
+                    float k, w;
+                    cov_and_slope<float, KIND>(r2, k, w);
+                    const float kv = k * variance;
+                    const float g = c1 * fmaf(wm, e[t], tv[t]);
+                    W[t] = 2.f * g * w * variance;
+                    gvar = fmaf(g, k, gvar);
+                    qn = fmaf(kv, tv[t], qn);
+                    racc[mt] = fmaf(kv, e[t], racc[mt]);
+                }
             }
             // this stage's MFMAs: dots of tile mt + 1, [B | S] += W . [X | 1] of tile mt, [D | C] += W^T . [Z | 1] of tile mt - 1
             if (mt > 0 && mt + 1 < MF_MT) {
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMA result -> VALU read: the hazard recogniser does not see it
         }
-        qsum += (double)qn;
+        qsum += (double)(RX ? qn * variance : qn);
         // column side: C2[r] = [D | C] of column nt0 + 4 lq + r (= this lane's column n0 + r), entry j = li
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             const float pr = bx[r] * Cn;                       // x_nq C_n (q = li; bx is x of column n0 + r at coordinate li)
             if (li < Q) {
                 dl3 = fmaf(bx[r], pr, dl3);
-                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * ilj);
+                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * (ilj * (1.f / CS)));
             }
         }
     }
@@ -602,45 +615,50 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
         float rr = racc[mt];                                   // R partials of row 16 mt + li: fold the four column groups
         rr += __shfl_xor(rr, 16, 64);
         rr += __shfl_xor(rr, 32, 64);
-        if (lane < 16) lds_add(&rowacc[mt * 16 + li][9], rr);
+        if (lane < 16) lds_add(&rowacc[mt * 16 + li][9], RX ? rr * variance : rr);
     }
     __syncthreads();
     for (int i = tid; i < MF_RB * 10; i += 256) {
         const int r = i / 10, c = i % 10;
         if (band0 + r < a.M) atomic_add(a.zacc + (band0 + r) * 16 + c, (double)rowacc[r][c]);
     }
-    if (a.dvar) { const float v = block_sum<float>(gvar, red); if (tid == 0) atomic_add(a.dvar, v); }
+    if (a.dvar && !RX) { const float v = block_sum<float>(gvar, red); if (tid == 0) atomic_add(a.dvar, v); }     // RBF: -(sum of S) / variance, by the finishing kernel
     {   // sum_n x_nq^2 C_n: lane (q = li) holds its share
         float v = (li < Q) ? dl3 : 0.f;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16 && li < Q) atomic_add(a.dls3 + li, (double)v);
+        if (lane < 16 && li < Q) atomic_add(a.dls3 + li, (double)v);       // in the kernel's coordinates: the finishing kernel divides by CS^2
     }
 }
 
 // dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one row per thread; float64: z^2 S - 2 z B + x^2 C cancels a digit or two)
+// cs: the extra scale of the pass's coordinates (sqrt(log2(e) / 2) for RBF, whose pass also leaves dvar = -(sum_m S_m) / variance to this kernel)
 __global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z, const float* __restrict__ ls,
                                                               const double* __restrict__ zacc, const double* __restrict__ dls3,
-                                                              float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R) {
+                                                              float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R, double cs,
+                                                              const float* __restrict__ var, float* __restrict__ dvar_from_S) {
     __shared__ double red[16];
     const int tid = threadIdx.x;
     const int64_t m = (int64_t)blockIdx.x * 256 + tid;
     double g12[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) g12[q] = 0.0;
+    double Srow = 0.0;
     if (m < M) {
         const double S = zacc[m * 16 + 8];
+        Srow = S;
         if (R) R[m] += (float)zacc[m * 16 + 9];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q < Q) {
                 const double ilq = 1.0 / (double)ls[ard ? q : 0];
-                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0]), Bq = zacc[m * 16 + q];      // the pass's own scaled coordinate (float32 quotient)
-                if (dZ) dZ[m * Q + q] += (float)((z * S - Bq) * ilq);
+                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0] * (float)cs), Bq = zacc[m * 16 + q];      // the pass's own scaled coordinate (float32)
+                if (dZ) dZ[m * Q + q] += (float)((z * S - Bq) * ilq / cs);
                 g12[q] = z * (z * S - 2.0 * Bq);
             }
         }
     }
+    if (dvar_from_S) { const double v = block_sum<double>(Srow, red); if (tid == 0) atomic_add(dvar_from_S, (float)(-v / (double)var[0])); }
     if (!dls) return;
     double tot = 0.0;
 #pragma unroll
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, 
         if (q >= Q) break;
         const double v = block_sum<double>(g12[q], red);
         if (tid == 0) {
-            const double glq = -(v + (blockIdx.x == 0 ? dls3[q] : 0.0));            // sum over pairs of -W d_q^2 (this block's rows; block 0 adds the column term)
+            const double glq = -(v + (blockIdx.x == 0 ? dls3[q] : 0.0)) / (cs * cs);   // sum over pairs of -W d_q^2 (this block's rows; block 0 adds the column term)
             if (ard) atomic_add(dls + q, (float)(glq / (double)ls[q])); else tot += glq;
         }
     }
@@ -733,14 +751,14 @@ int bwd_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q, const v
     return launch_kind<T, 0>(h, kind, a, S, st);
 }
 
-// dst[i][0..7] = src[i][0..Q-1] / l_q, zero padded (rows i < n); norms[i] = |dst[i]|^2 (optional)
+// dst[i][0..7] = cs * src[i][0..Q-1] / l_q, zero padded (rows i < n); norms[i] = |dst[i]|^2 (optional)
 __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restrict__ src, int64_t n, int Q, const float* __restrict__ ls, int ard,
-                                                           float* __restrict__ dst, float* __restrict__ norms) {
+                                                           float* __restrict__ dst, float* __restrict__ norms, float cs) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     float v[8], n2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? src[r * Q + q] / ls[ard ? q : 0] : 0.f; n2 = fmaf(v[q], v[q], n2); }
+    for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? src[r * Q + q] / ls[ard ? q : 0] * cs : 0.f; n2 = fmaf(v[q], v[q], n2); }
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     *reinterpret_cast<f32x4*>(dst + r * 8) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(dst + r * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -765,8 +783,9 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     float* Zs = reinterpret_cast<float*>(reinterpret_cast<char*>(h->bwd_acc) + nacc);
     float* Xs = Zs + (size_t)M * 8;
     float* Xn = Xs + (size_t)SB * 8;
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr);
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, X, SB, Q, ls, ard, Xs, Xn);
+    const float cs = kind == MXF_K_RBF ? 0.84932180028801904272f : 1.f;      // RBF: exp(-r2 / 2) = 2^-(cs^2 r2), the bare v_exp_f32 in the pass
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr, cs);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, X, SB, Q, ls, ard, Xs, Xn, cs);
     BwdMfmaArgs a;
     a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
     a.dX = dX; a.dY = dY; a.zacc = zacc; a.dls3 = zacc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
@@ -793,7 +812,8 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
         default: MXF_FAIL(h, -2, "svgp reverse pass: kind %d has no stationary reverse mode", kind);
     }
 #undef MF_GO
-    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R);
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R,
+                       (double)cs, var, kind == MXF_K_RBF ? dvar : (float*)nullptr);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
