@@ -18,6 +18,17 @@ def _uniform_weight(g):
     return torch.where(spread <= 1e-6 * c.abs() / g.numel(), c, torch.full_like(c, float('nan')))
 
 
+def _scaled(grads, shapes, needs, c):
+    """(grad.reshape(shape) * c for the inputs that need a gradient, None for the others) -- all products in ONE multi-tensor launch
+    (the step's tail is paced by its number of launches)."""
+    idx = [i for i, n in enumerate(needs) if n]
+    prod = torch._foreach_mul([grads[i] for i in idx], c) if idx else []
+    out = [None] * len(needs)
+    for i, p in zip(idx, prod):
+        out[i] = p.reshape(shapes[i])
+    return tuple(out)
+
+
 class GPLogPdfFn(torch.autograd.Function):
     """mxf_gp_logpdf: logL (S,), and the posterior side products L, LinvY (gp_regression.py:72-75)."""
 
@@ -65,10 +76,7 @@ class SVGPLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = _uniform_weight(g)
-        out = []
-        for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:]):
-            out.append((grad.reshape(shp) * c) if need else None)
-        return (None, None, None, None) + tuple(out)
+        return (None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:], c)
 
 
 class SVGPMatLogPdfFn(torch.autograd.Function):
@@ -91,8 +99,7 @@ class SVGPMatLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = _uniform_weight(g)          # gradients were produced for mean_S(logL) (gscale = 1/S): scale by sum(grad_output), as SVGPLogPdfFn does
-        out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:])]
-        return (None, None) + tuple(out)
+        return (None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:], c)
 
 
 class SGPLogPdfFn(torch.autograd.Function):
