@@ -190,6 +190,31 @@ int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, const void*
                const void* B, int64_t ldb, int64_t strideS_B, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Prediction composites (for a binder with no module code of its own; the Python mirror composes the same kernels).           */
+
+/* Kernel.Kdiag: out (S, N) = diagonal of K(X[s], X[s]).  Stationary kinds, Bias, White: the variance (stationary.py:123-124,
+ * static.py:76-86,152-162); Linear: sum_q variances_q x_q^2 with `lengthscale` carrying the variances (linear.py:91-104).           */
+int mxf_kdiag(mxf_handle h, int kind, int dtype, int S, int64_t N, int Q, const void* X, int64_t strideS_X,
+              const void* lengthscale, int ard, int64_t strideS_ls, const void* variance, int64_t strideS_var,
+              void* out, void* stream);
+
+/* GPRegressionMeanVariancePrediction.compute (gp_regression.py:146-196) for ONE posterior (L (N,N) lower, LinvY (N,P) as the inference
+ * stored them, :203-234) and S samples of the test inputs X_test (S, Nt, Q): mean_out (S, Nt, P); var_out (S, Nt) -- the reference
+ * broadcasts it over P -- or, full_cov, (S, Nt, Nt).  noise_free = 0 adds noise_var (1,).  Stationary kinds.                          */
+int mxf_gp_predict(mxf_handle h, int kind, int dtype, int S, int64_t N, int64_t Nt, int Q, int P,
+                   const void* X_cond, const void* X_test, const void* lengthscale, int ard, const void* variance,
+                   const void* L, int64_t ldl, const void* LinvY, const void* noise_var, int noise_free, int full_cov,
+                   void* mean_out, void* var_out, void* stream);
+
+/* SVGPRegressionMeanVariancePrediction.compute (svgp_regression.py:121-189) from the variational parameters themselves: Z (M,Q),
+ * qU_mean (M,P), qU_cov_W (M,M), qU_cov_diag (M,) (constrained values), S samples of X_test (S, Nt, Q).  Outputs as mxf_gp_predict;
+ * info (2 ints, may be null): potrf status of Kuu + jitter I and of S = W W^T + diag.                                                */
+int mxf_svgp_predict(mxf_handle h, int kind, int dtype, int S, int64_t M, int64_t Nt, int Q, int P,
+                     const void* Z, const void* X_test, const void* lengthscale, int ard, const void* variance,
+                     const void* qU_mean, const void* qU_cov_W, const void* qU_cov_diag, const void* noise_var,
+                     double jitter, int noise_free, int full_cov, void* mean_out, void* var_out, void* info, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Elementwise / reduction pieces of the MC-ELBO loop.                                             */
 
 /* y = log(1+exp(x)) and its reverse mode -- PositiveTransformation (var_trans.py:63-91)             */

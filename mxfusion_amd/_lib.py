@@ -26,6 +26,9 @@ SIGNATURES = {
     'mxf_trtri': [_i, _i, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp],
     'mxf_sumlogdiag': [_i, _i, _i64, _vp, _i64, _i64, _vp, _vp],
     'mxf_coldot': [_i, _i, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp],
+    'mxf_kdiag': [_i, _i, _i, _i64, _i, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _vp],
+    'mxf_gp_predict': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    'mxf_svgp_predict': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp],
     'mxf_softplus_fwd': [_i, _i64, _vp, _vp, _vp],
     'mxf_softplus_bwd': [_i, _i64, _vp, _vp, _vp, _vp],
     'mxf_normal_reparam': [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp],

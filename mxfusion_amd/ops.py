@@ -429,6 +429,50 @@ def coldot(A, B):
     return out
 
 
+def kdiag(kind, X, lengthscale, variance, ard):
+    """Kernel.Kdiag through the C ABI (mxf_kdiag): X (S,N,Q) -> (S,N).  For 'linear', `lengthscale` carries the variances."""
+    X = _c(X)
+    S, N, Q = X.shape
+    ls = None if lengthscale is None else _c(lengthscale).reshape(-1, _c(lengthscale).shape[-1])
+    var = None if variance is None else _c(variance).reshape(-1)
+    out = torch.empty((S, N), dtype=X.dtype, device=X.device)
+    sls = 0 if ls is None or ls.shape[0] == 1 else ls.shape[-1]
+    svar = 0 if var is None or var.numel() == 1 else 1
+    _lib.call('mxf_kdiag', _h(X), KIND[kind], _dt(X), S, N, Q, _p(X), N * Q, _p(ls), int(bool(ard)), sls, _p(var), svar, _p(out), _stream())
+    return out
+
+
+def gp_predict(kind, X_cond, X_test, lengthscale, variance, ard, L, LinvY, noise_var, noise_free=False, full_cov=False):
+    """GPRegressionMeanVariancePrediction.compute (gp_regression.py:146-196) as one C-ABI call (mxf_gp_predict): one posterior
+    (L (N,N), LinvY (N,P)), X_test (S,Nt,Q) -> mean (S,Nt,P), var (S,Nt) or (S,Nt,Nt)."""
+    X_cond, X_test, lengthscale, variance, L, LinvY = [_c(t) for t in (X_cond, X_test, lengthscale, variance, L, LinvY)]
+    S, Nt, Q = X_test.shape
+    N, P = X_cond.shape[-2], LinvY.shape[-1]
+    mean = torch.empty((S, Nt, P), dtype=X_test.dtype, device=X_test.device)
+    var = torch.empty((S, Nt, Nt) if full_cov else (S, Nt), dtype=X_test.dtype, device=X_test.device)
+    _lib.call('mxf_gp_predict', _h(X_test), KIND[kind], _dt(X_test), S, N, Nt, Q, P, _p(X_cond), _p(X_test), _p(lengthscale), int(bool(ard)),
+              _p(variance), _p(L), L.stride(-2), _p(LinvY), None if noise_var is None else _p(_c(noise_var)), int(bool(noise_free)),
+              int(bool(full_cov)), _p(mean), _p(var), _stream())
+    return mean, var
+
+
+def svgp_predict(kind, Z, X_test, lengthscale, variance, ard, qU_mean, qU_cov_W, qU_cov_diag, noise_var, jitter=0.0, noise_free=False,
+                 full_cov=False):
+    """SVGPRegressionMeanVariancePrediction.compute (svgp_regression.py:121-189) as one C-ABI call (mxf_svgp_predict).
+    Returns mean (S,Nt,P), var (S,Nt) or (S,Nt,Nt), info (2,) int32."""
+    Z, X_test, lengthscale, variance, qU_mean, qU_cov_W, qU_cov_diag = [_c(t) for t in (Z, X_test, lengthscale, variance, qU_mean, qU_cov_W,
+                                                                                        qU_cov_diag)]
+    S, Nt, Q = X_test.shape
+    M, P = Z.shape[-2], qU_mean.shape[-1]
+    mean = torch.empty((S, Nt, P), dtype=X_test.dtype, device=X_test.device)
+    var = torch.empty((S, Nt, Nt) if full_cov else (S, Nt), dtype=X_test.dtype, device=X_test.device)
+    info = torch.zeros(2, dtype=torch.int32, device=X_test.device)
+    _lib.call('mxf_svgp_predict', _h(X_test), KIND[kind], _dt(X_test), S, M, Nt, Q, P, _p(Z), _p(X_test), _p(lengthscale), int(bool(ard)),
+              _p(variance), _p(qU_mean), _p(qU_cov_W), _p(qU_cov_diag), None if noise_var is None else _p(_c(noise_var)), float(jitter),
+              int(bool(noise_free)), int(bool(full_cov)), _p(mean), _p(var), _p(info), _stream())
+    return mean, var, info
+
+
 def sgp_logpdf(kind, X, Y, Z, noise_var, lengthscale, variance, ard, jitter=0.0, gscale=1.0, want_grad=False):
     """SparseGPRegressionLogPdf.compute (sparsegp_regression.py:42-108) for ONE sample: X (B,Q), Y (B,P), Z (M,Q), noise_var (1,),
     lengthscale (Q|1,), variance (1,).  Returns dict(logL (1,), wv (M,P), L (M,M), LA (M,M), info, gradients...)."""
