@@ -49,6 +49,7 @@ struct GemmArgs {
                       //                 2 = op(A) lower triangular (A itself, not transposed): they only need k < m0 + tile rows
     int64_t kchunk;
     int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
+    int64_t xc_max;                // > 0: balanced triangular mapping (lower_only with k_from_m == 1), 8 * xc_max workgroups per batch entry
 };
 
 constexpr int EPT = BK * 128 / NT;    // elements of one operand tile per thread
@@ -233,14 +234,25 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
     // each XCD a CONTIGUOUS range of work ids so that tiles sharing an operand panel hit the same private L2, and
     // enumerate only the tiles that exist (lower_only: compact triangular decode) so every XCD gets the same load.
     int64_t wid = blockIdx.x;
-    {
+    if (!g.xc_max) {
         const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int64_t zs = wid / g.ntiles;            // (batch, split) slowest
+    int64_t zs = wid / g.ntiles;                  // (batch, split) slowest
     int64_t t = wid % g.ntiles;
     int64_t tile_m, tile_n;
-    if (g.lower_only) {                           // t -> (row, col), col <= row
+    if (g.xc_max) {
+        // Lower tiles of a product whose tile row r only needs k >= r BM (K^-1 = L^-T L^-1): row r has r + 1 tiles of (tm - r) k blocks
+        // each, so contiguous tile ranges per XCD are badly unbalanced (the first eighth of the tiles carries 2.4x its share at tm = 64).
+        // XCD x takes the rows r = x (mod 8) -- equal work to 1 % -- longest k loops first; the tile counts differ per XCD, so the grid
+        // holds 8 * xc_max workgroups per batch entry and the surplus ones leave.
+        const int64_t per = 8 * g.xc_max, rem = (int64_t)blockIdx.x % per;
+        zs = (int64_t)blockIdx.x / per;
+        int64_t row = rem & 7, j = rem >> 3;
+        while (row < g.tm && j >= row + 1) { j -= row + 1; row += 8; }
+        if (row >= g.tm) return;
+        tile_m = row; tile_n = j;
+    } else if (g.lower_only) {                    // t -> (row, col), col <= row
         int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while (row * (row + 1) / 2 > t) --row;
         while ((row + 1) * (row + 2) / 2 <= t) ++row;
@@ -432,6 +444,7 @@ bool gemm_small_launch<double>(mxf_ctx* h, GemmArgs<double>& g, int ta, int tb, 
     if (K > 0) { kchunk = (K + splitk - 1) / splitk; kchunk = (kchunk + SBK_ - 1) / SBK_ * SBK_; splitk = (K + kchunk - 1) / kchunk; } else splitk = 1;
     g.splitk = (int)splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
     g.tm = tm; g.tn = tn; g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn; g.nwg = g.ntiles * batch * splitk;
+    g.xc_max = 0;
     rc = 0;
     if (g.atomic && beta != 1.0) {
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
@@ -502,6 +515,16 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     g.tm = tm; g.tn = tn;
     g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     g.nwg = g.ntiles * batch * splitk;
+    g.xc_max = 0;
+    static const int tri_balance = getenv("MXF_GEMM_TRI_BALANCE") ? atoi(getenv("MXF_GEMM_TRI_BALANCE")) : 1;
+    if (tri_balance && lower_only && g.k_from_m == 1 && splitk == 1 && tm >= 16) {
+        for (int64_t x = 0; x < 8; ++x) {
+            int64_t cnt = 0;
+            for (int64_t r = x; r < tm; r += 8) cnt += r + 1;
+            if (cnt > g.xc_max) g.xc_max = cnt;
+        }
+        g.nwg = 8 * g.xc_max * batch;
+    }
     if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm: grid too large");
     if (g.atomic && beta != 1.0) {     // beta == 1 (the potrf / trsm updates): C is accumulated into as is, nothing to pre-scale
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);

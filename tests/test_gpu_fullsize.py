@@ -65,6 +65,14 @@ def test_full_size_exact_gp_factorisation_reconstructs():
     a = ops.trsm_(L, torch.as_tensor(Y, dtype=dt).cuda()[None].clone())
     ref = -float(ops.sumlogdiag(L)[0]) - 0.5 * float((a ** 2).sum()) - 0.5 * N * np.log(2 * np.pi)
     assert abs(float(r['logL'][0]) - ref) <= 1e-10 * abs(ref)
+    # reverse mode at full size: dlogL/dK = 1/2 (alpha alpha^T - K^-1) formed with torch from the same L^-1, pushed through mxf_gram_bwd --
+    # every lower tile of the library's triangular K^-1 product (balanced tile mapping, gemm.hip) has to be there
+    alpha = Linv[0].T @ a[0]
+    dK = 0.5 * (alpha @ alpha.T - Linv[0].T @ Linv[0])
+    gx, _, gls, gvar = ops.gram_bwd('rbf', Xd, None, one(np.ones(Q)), one(1.0), True, dK[None])
+    for k, g in (('dX', gx), ('dls', gls), ('dvar', gvar)):
+        assert float((r[k] - g).abs().max()) <= 1e-9 * float(g.abs().max()), k
+    assert abs(float(r['dnoise'].sum()) - float(torch.trace(dK))) <= 1e-10 * abs(float(torch.trace(dK)))
 
 
 def test_full_size_svgp_training_call_properties():
