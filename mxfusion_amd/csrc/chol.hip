@@ -19,9 +19,12 @@ constexpr int NB = 64;     // inner block
 // 1/sqrt(d) to full precision: hardware v_rsq estimate + Newton steps (cheaper than a correctly-rounded sqrt AND a division)
 __device__ __forceinline__ float inv_sqrt(float d) { float r = rsqrtf(d); r = r * (1.5f - 0.5f * d * r * r); return r; }
 __device__ __forceinline__ double inv_sqrt(double d) {
-    double r = rsqrt(d);
-    r = r * (1.5 - 0.5 * d * r * r);
-    return r;
+    // (the pivots of a positive-definite matrix that is worth factoring are normal numbers: no scaling of the argument; the hardware
+    //  estimate is good to ~2^-26, one third-order correction y (1 + e/2 + 3 e^2/8), e = 1 - d y^2, leaves < 1 ulp -- five dependent
+    //  operations on the critical path of every column instead of the library routine's special-case handling plus a Newton step)
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 constexpr int NBO = 512;   // outer panel
 constexpr int TRI_MIN = 1024;   // trtri merge levels from this block size on use the triangular-aware GEMM k ranges
@@ -240,6 +243,14 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
 // incrementally (one 64^3 product after every solve), so the critical path per block column is factor (19 us) -> solve of the next row's
 // tile -> one product -> factor.  Every workgroup must be resident at once (<= 32 workgroups); spins are bounded (a lost hand-off reports
 // info = -1 instead of hanging the queue).
+#ifdef MXF_POTRF_TRACE
+// probe build only (tests/probes/potrf_trace.py): 100 MHz timestamps of the stages of block rows 0 .. 15, [row][column j][stage]
+__device__ long long potrf_trace_buf[16 * 17 * 16];
+#define PT_STAMP(k) do { if (tid == 0 && i < 16) potrf_trace_buf[(i * 17 + jt) * 16 + (k)] = wall_clock64(); } while (0)
+extern "C" int mxf_debug_potrf_trace(long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(potrf_trace_buf), sizeof(long long) * 16 * 17 * 16); }
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
 constexpr int PT_SLD = 66;      // LDS row stride of the staged k chunks (as the small GEMM)
 typedef double pt_f64x4 __attribute__((ext_vector_type(4)));
 
@@ -260,58 +271,73 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     bool lost = false;
 
-    auto wait_for = [&](int row, int need) {          // all threads: block until progress[row] >= need
+    // all threads: block until progress[row] >= need; returns the value seen (progress only grows: the caller skips later waits it covers)
+    auto wait_for = [&](int row, int need) -> int {
         if (tid == 0) {
-            int spins = 0, ok = 1;
-            while (__hip_atomic_load(progress + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            int spins = 0, v;
+            while ((v = __hip_atomic_load(progress + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 26)) { ok = 0; break; }
+                if (++spins > (1 << 26)) { v = -1; break; }
             }
-            sflag = ok;
+            sflag = v;
         }
         __syncthreads();
-        if (!sflag) lost = true;
+        const int v = sflag;
+        if (v < 0) lost = true;
         __atomic_thread_fence(__ATOMIC_ACQUIRE);         // every wave: drop stale lines before reading the published tiles
+        __syncthreads();                                  // (sflag is rewritten by the next wait)
+        return v < 0 ? (1 << 30) : v;
     };
-    // C (this wave's 32 x 32 quadrant, accumulator layout) += P[rows r0 ..][k0 .. k1) . Q[rows q0 ..][k0 .. k1)^T, both row panels of A
+    // C (this wave's 32 x 32 quadrant, accumulator layout) += P[rows r0 ..][k0 .. k1) . Q[rows q0 ..][k0 .. k1)^T, both row panels of A;
+    // k0, k1 multiples of 64.  One wave per SIMD: nothing hides a latency unless the code does.  Chunks of 16 columns; FOUR chunks of
+    // global loads in flight (the tiles come from other CUs' stores, ~2 us away); two LDS buffers and two operand register sets: while
+    // the 16 MFMAs of chunk c issue, chunk c + 1 goes registers -> LDS -> barrier -> operand registers in between them.
     auto panel_product = [&](pt_f64x4 (&c)[2][2], int64_t r0, int64_t q0, int64_t k0, int64_t k1, int gate_row) {
         const int qmn = tid >> 2, qk0 = (tid & 3) * 4;
-        double ra[4], rb[4];
-        auto load = [&](int64_t k) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ra[j] = Ab[(r0 + qmn) * lda + k + qk0 + j]; rb[j] = Ab[(q0 + qmn) * lda + k + qk0 + j]; }
-        };
-        auto store = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sm[buf][0][(qk0 + j) * PT_SLD + qmn] = ra[j]; sm[buf][1][(qk0 + j) * PT_SLD + qmn] = rb[j]; }
-        };
+        double ra[4][4], rb[4][4], oa[2][4][2], ob[2][4][2];
         if (k0 >= k1) return;
-        if (gate_row >= 0) wait_for(gate_row, (int)((k0 - c0) / NB) + 1);
-        load(k0); store(0);
+        int seen = 0;
+        auto gate = [&](int64_t k) {                       // the 64-column tile of row gate_row that starts at column k
+            if (gate_row < 0 || k >= k1) return;
+            const int need = (int)((k - c0) / NB) + 1;
+            if (seen < need) seen = wait_for(gate_row, need);
+        };
+        const double* pa = Ab + (r0 + qmn) * lda + qk0;
+        const double* pb = Ab + (q0 + qmn) * lda + qk0;
+        const int64_t C = (k1 - k0) / 16;
+#define PT_LOAD(s, k) do { _Pragma("unroll") for (int j = 0; j < 4; ++j) { ra[s][j] = pa[(k) + j]; rb[s][j] = pb[(k) + j]; } } while (0)
+#define PT_STORE(s, b) do { _Pragma("unroll") for (int j = 0; j < 4; ++j) { sm[b][0][(qk0 + j) * PT_SLD + qmn] = ra[s][j]; sm[b][1][(qk0 + j) * PT_SLD + qmn] = rb[s][j]; } } while (0)
+#define PT_READ(b, o) do { _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int x = 0; x < 2; ++x) {                     \
+            oa[o][q][x] = sm[b][0][(4 * q + lq) * PT_SLD + wm + 16 * x + li]; ob[o][q][x] = sm[b][1][(4 * q + lq) * PT_SLD + wn + 16 * x + li]; } } while (0)
+#define PT_MMA(o, q0_, q1_) do { _Pragma("unroll") for (int q = (q0_); q < (q1_); ++q) _Pragma("unroll") for (int x = 0; x < 2; ++x)          \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[o][q][x], ob[o][q][y], c[x][y], 0, 0, 0); } while (0)
+        gate(k0);
+        PT_LOAD(0, k0); PT_LOAD(1, k0 + 16); PT_LOAD(2, k0 + 32); PT_LOAD(3, k0 + 48);
+        gate(k0 + 64);
+        PT_STORE(0, 0);
         __syncthreads();
-        int cur = 0;
-        for (int64_t k = k0; k < k1; k += 16) {
-            const bool more = k + 16 < k1;
-            if (more) {
-                if (gate_row >= 0 && ((k + 16 - c0) % NB) == 0) wait_for(gate_row, (int)((k + 16 - c0) / NB) + 1);   // the next 64-column tile of row gate_row
-                load(k + 16);
+        if (C > 4) PT_LOAD(0, k0 + 64);
+        PT_READ(0, 0);
+        for (int64_t m = 0; m < C; m += 4) {
+            gate(k0 + 16 * (m + 8));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int64_t cc = m + s;
+                const bool nxt = cc + 1 < C;
+                if (nxt) PT_STORE((s + 1) & 3, (s + 1) & 1);
+                PT_MMA(s & 1, 0, 2);
+                if (nxt) {
+                    __syncthreads();
+                    if (cc + 5 < C) PT_LOAD((s + 1) & 3, k0 + 16 * (cc + 5));
+                    PT_READ((s + 1) & 1, (s + 1) & 1);
+                }
+                PT_MMA(s & 1, 2, 4);
             }
-            const double* As = sm[cur][0];
-            const double* Bs = sm[cur][1];
-#pragma unroll
-            for (int ks = 0; ks < 16; ks += 4) {
-                double av[2], bv[2];
-#pragma unroll
-                for (int x = 0; x < 2; ++x) { av[x] = As[(ks + lq) * PT_SLD + wm + 16 * x + li]; bv[x] = Bs[(ks + lq) * PT_SLD + wn + 16 * x + li]; }
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], c[x][y], 0, 0, 0);
-            }
-            if (more) store(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
         }
+#undef PT_LOAD
+#undef PT_STORE
+#undef PT_READ
+#undef PT_MMA
     };
     auto zero = [&](pt_f64x4 (&c)[2][2]) {
 #pragma unroll
@@ -324,14 +350,25 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     pt_f64x4 cd[2][2];          // running sum_k L[i][k] L[i][k]^T of the diagonal tile
     zero(cd);
     const int jend = i < npt ? i : npt;
+    pt_f64x4 dg[2][2];          // A[i][i] itself, fetched now: the factorisation of the diagonal tile is the critical path of its block column
+    if (i < npt) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dg[x][y][r] = Ab[(ri + wm + 16 * x + lq + 4 * r) * lda + ri + wn + 16 * y + li];
+    }
 
     for (int j = 0; j < jend; ++j) {
         const int64_t rj = c0 + (int64_t)j * NB;
         pt_f64x4 c[2][2];
         zero(c);
+        [[maybe_unused]] const int jt = j;
+        PT_STAMP(0);
         panel_product(c, ri, rj, c0, rj, j);                      // sum_{k<j} L[i][k] L[j][k]^T  (row j's tiles k < j: gated on progress[j])
-        wait_for(j, j + 1);                                        // L[j][j]
-        for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; a[r][cc] = (cc <= r) ? Ab[(rj + r) * lda + rj + cc] : 0.0; }
+        PT_STAMP(1);
+        // (the tile's own entries do not depend on L[j][j]: they are in LDS before it arrives)
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -341,9 +378,21 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                     const int rr = wm + 16 * x + lq + 4 * r, cc = wn + 16 * y + li;
                     t[rr][cc] = Ab[(ri + rr) * lda + rj + cc] - c[x][y][r];
                 }
+        wait_for(j, j + 1);                                        // L[j][j]
+        PT_STAMP(2);
+        {
+            double lv[16];                                         // 16 independent loads in flight, then LDS
+            const int r0 = tid >> 6, cc = tid & 63;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) lv[u] = Ab[(rj + r0 + 4 * u) * lda + rj + cc];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a[r0 + 4 * u][cc] = (cc <= r0 + 4 * u) ? lv[u] : 0.0;
+                if (cc == r0 + 4 * u) invd[cc] = 1.0 / lv[u];
+            }
+        }
         __syncthreads();
-        if (tid < NB) invd[tid] = 1.0 / a[tid][tid];
-        __syncthreads();
+        PT_STAMP(3);
         // X L[j][j]^T = T: 16 columns at a time by substitution (one row per lane of wave 0), the remaining columns by MFMA (one 16-row tile per wave)
         for (int blk = 0; blk < NB; blk += 16) {
             if (wave == 0) {
@@ -377,24 +426,35 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                 __syncthreads();
             }
         }
-        for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + rj + cc] = t[r][cc]; }
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        // the diagonal tile's share of this column, straight from the solved tile in LDS: cd += L[i][j] L[i][j]^T
-#pragma unroll 4
-        for (int ks = 0; ks < NB; ks += 4) {
-            double av[2], bv[2];
+        PT_STAMP(4);
+        {
+            const int r0 = tid >> 6, cc = tid & 63;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) { av[x] = t[wm + 16 * x + li][ks + lq]; bv[x] = t[wn + 16 * x + li][ks + lq]; }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) cd[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], cd[x][y], 0, 0, 0);
+            for (int u = 0; u < 16; ++u) Ab[(ri + r0 + 4 * u) * lda + rj + cc] = t[r0 + 4 * u][cc];
         }
-        __syncthreads();                                           // t is rewritten by the next tile
+        // the diagonal tile's share of this column, straight from the solved tile in LDS: cd += L[i][j] L[i][j]^T (the stores above drain
+        // meanwhile; the tile is published after it -- the rows below need it for their NEXT column's product only)
+        if (i < npt) {
+#pragma unroll 4
+            for (int ks = 0; ks < NB; ks += 4) {
+                double av[2], bv[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { av[x] = t[wm + 16 * x + li][ks + lq]; bv[x] = t[wn + 16 * x + li][ks + lq]; }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) cd[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], cd[x][y], 0, 0, 0);
+            }
+        }
+        PT_STAMP(5);
+        __threadfence();
+        __syncthreads();                                           // (also: t is rewritten by the next tile)
+        if (tid == 0) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        PT_STAMP(6);
     }
     if (i < npt) {
+    [[maybe_unused]] const int jt = i;
+    PT_STAMP(7);
     // diagonal tile: factor A[i][i] - cd
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -403,33 +463,42 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = wm + 16 * x + lq + 4 * r, cc = wn + 16 * y + li;
-                a[rr][cc] = (cc <= rr) ? Ab[(ri + rr) * lda + ri + cc] - cd[x][y][r] : 0.0;
+                a[rr][cc] = (cc <= rr) ? dg[x][y][r] - cd[x][y][r] : 0.0;
             }
     __syncthreads();
+    PT_STAMP(8);
     for (int blk = 0; blk < NB; blk += 16) {
-        if (wave == 0) {                                   // 16 x 16 sub-block, a row per lane in registers
-            double r[16];
+        if (wave == 0) {
+            // 16 x 16 sub-block on the matrix pipe: the block sits in ONE MFMA accumulator (lane (li, lq), register r = element
+            // (row li, column lq + 4 r), valid for column <= row), and every column step is d -> 1/sqrt(d) -> scale -> ONE rank-1 MFMA
+            // (operand: the scaled column in the lanes lq == c % 4, zero elsewhere) instead of 15 readlane + FMA column updates:
+            // ~15 instructions on the serial chain of a column instead of ~55.
+            pt_f64x4 cv, lv = pt_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c2 = 0; c2 < 16; ++c2) r[c2] = a[blk + li][blk + c2];
-            int bad = -1;
+            for (int r = 0; r < 4; ++r) cv[r] = a[blk + li][blk + lq + 4 * r];
+            int bad = 99;
+            double myinv = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                double d = readlane_t(r[jj], jj);
-                if (!(d > 0.0)) { if (bad < 0) bad = jj; d = 1.0; }
-                const double inv = inv_sqrt(d);
-                const double l = (li == jj) ? d * inv : r[jj] * inv;
-                r[jj] = l;
-                if (lane == 0) invd[blk + jj] = inv;
-#pragma unroll
-                for (int c2 = jj + 1; c2 < 16; ++c2) r[c2] = fma(-l, readlane_t(l, c2), r[c2]);
+            for (int c = 0; c < 16; ++c) {
+                const int p = c >> 2, sg = c & 3;
+                // (branch-free; a non-positive pivot is reported below and its column left unscaled: the factor stays finite)
+                const double d = readlane_t(cv[p], sg * 16 + c);
+                bad = (!(d > 0.0) && bad > c) ? c : bad;
+                const double rs = inv_sqrt(d);
+                const double inv = (d > 0.0) ? rs : 1.0;
+                const double m = (lq == sg && li >= c) ? 1.0 : 0.0;       // this column's lanes: rows c .. 15 in lane group c % 4
+                const double l = (cv[p] * inv) * m;
+                lv[p] += l;                                                // (exactly one non-zero contribution per lane and register)
+                myinv = (lane == c) ? inv : myinv;
+                if (c < 15) cv = __builtin_amdgcn_mfma_f64_16x16x4f64(-l, l, cv, 0, 0, 0);
             }
-            if (bad >= 0 && lane == 0 && info && info[b] == 0) info[b] = (int)(ri + blk + bad + 1);
-            if (lane < 16) {
+            if (bad < 16 && lane == 0 && info && info[b] == 0) info[b] = (int)(ri + blk + bad + 1);
+            if (lane < 16) invd[blk + lane] = myinv;
 #pragma unroll
-                for (int c2 = 0; c2 < 16; ++c2) a[blk + lane][blk + c2] = (c2 <= lane) ? r[c2] : 0.0;
-            }
+            for (int r = 0; r < 4; ++r) a[blk + li][blk + lq + 4 * r] = (lq + 4 * r <= li) ? lv[r] : 0.0;
         }
         __syncthreads();
+        if (blk == 0) PT_STAMP(11);
         if (blk + 16 < NB) {
             const int rr = blk + 16 + tid;                 // rows below the sub-block: X L_bb^T = A_ib
             if (rr < NB) {
@@ -446,6 +515,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                 for (int c2 = 0; c2 < 16; ++c2) a[rr][blk + c2] = x[c2];
             }
             __syncthreads();
+            if (blk == 0) PT_STAMP(12);
             int tix = 0;                                   // trailing lower tiles of 16 x 16, dealt to the four waves
             for (int I0 = blk + 16; I0 < NB; I0 += 16)
                 for (int J0 = blk + 16; J0 <= I0; J0 += 16, ++tix) {
@@ -462,12 +532,15 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                     for (int r = 0; r < 4; ++r) a[I0 + lq + 4 * r][J0 + li] = cf[r];
                 }
             __syncthreads();
+            if (blk == 0) PT_STAMP(13);
         }
     }
+    PT_STAMP(9);
     for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + ri + cc] = (cc <= r) ? a[r][cc] : 0.0; }
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    PT_STAMP(10);
     }
     if (tid == 0) {
         if (lost && info) info[b] = -1;
@@ -675,7 +748,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         }
     }
     const bool panel_tiles = tiles_ok && tiles_env == 1 && n > 1024 && n / NB <= 256;      // every block row's workgroup must be resident at once
-    static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 1;
+    static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 2;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
@@ -712,7 +785,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
                 if (rc) return rc;
             } else {
-                MXF_HIP(h, hipEventRecord(h->ev_pa, st));                     // the panel's columns (L21) are final
+                if (look_env != 2) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // the panel's columns (L21) are final
                 // next outer panel's columns on the caller's stream: its diagonal block (lower) and the rows below it
                 int rc = mxf_gemm_internal(h, dtype, 0, 1, pe2 - pe, pe2 - pe, K, -1.0, A + pe * lda + c0, lda, sA,
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
@@ -720,6 +793,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
                                        A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, st);
                 if (rc) return rc;
+                if (look_env == 2) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // (2: the rest-update only starts once the head products are done)
                 // the rest on the auxiliary stream, next to the next panel's factorisation
                 MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_pa, 0));
                 rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, n - pe2, K, -1.0, A + pe2 * lda + c0, lda, sA,

@@ -49,6 +49,7 @@ struct GemmArgs {
                       //                 2 = op(A) lower triangular (A itself, not transposed): they only need k < m0 + tile rows
     int64_t kchunk;
     int64_t tm, tn, ntiles, nwg;   // tile grid, tiles per (batch,split), total workgroups
+    int rev_m;
     int64_t xc_max;                // > 0: balanced triangular mapping (lower_only with k_from_m == 1), 8 * xc_max workgroups per batch entry
 };
 
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
         tile_m = row; tile_n = t - row * (row + 1) / 2;
     } else {                                      // row tiles fastest: consecutive ids share the B (column) panel
         tile_m = t % g.tm; tile_n = t / g.tm;
+        if (g.k_from_m == 2 && g.rev_m) tile_m = g.tm - 1 - tile_m;      // k < m0 + BM: the long k loops first
     }
     const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
     const int batch = (int)(zs / g.splitk), split = (int)(zs % g.splitk);
@@ -444,7 +446,7 @@ bool gemm_small_launch<double>(mxf_ctx* h, GemmArgs<double>& g, int ta, int tb, 
     if (K > 0) { kchunk = (K + splitk - 1) / splitk; kchunk = (kchunk + SBK_ - 1) / SBK_ * SBK_; splitk = (K + kchunk - 1) / kchunk; } else splitk = 1;
     g.splitk = (int)splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
     g.tm = tm; g.tn = tn; g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn; g.nwg = g.ntiles * batch * splitk;
-    g.xc_max = 0;
+    g.xc_max = 0; g.rev_m = 0;
     rc = 0;
     if (g.atomic && beta != 1.0) {
         dim3 gs((unsigned)((N + 255) / 256), (unsigned)M, (unsigned)batch);
@@ -516,6 +518,8 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     g.nwg = g.ntiles * batch * splitk;
     g.xc_max = 0;
+    static const int rev_env = getenv("MXF_GEMM_REV_M") ? atoi(getenv("MXF_GEMM_REV_M")) : 1;
+    g.rev_m = rev_env;
     static const int tri_balance = getenv("MXF_GEMM_TRI_BALANCE") ? atoi(getenv("MXF_GEMM_TRI_BALANCE")) : 1;
     if (tri_balance && lower_only && g.k_from_m == 1 && splitk == 1 && tm >= 16) {
         for (int64_t x = 0; x < 8; ++x) {
