@@ -258,7 +258,7 @@ typedef double pt_f64x4 __attribute__((ext_vector_type(4)));
 // below c0 -- left-looking INSIDE the panel (columns left of c0 were applied by the trailing updates of the earlier panels): block rows
 // i < npt end with their diagonal tile, the others only solve.  nbr = block rows, counters: nbr progress words + one completion word.
 __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int* __restrict__ info,
-                                                          int* __restrict__ progress_all) {
+                                                          int* __restrict__ progress_all, double* __restrict__ inv_all) {
     __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
     __shared__ double invd[NB];
     __shared__ double t[NB][NB + 1];          // the tile being solved
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     const int i = blockIdx.x, b = blockIdx.y, nbk = (int)gridDim.x;
     double* Ab = A + (int64_t)b * sA;
     int* progress = progress_all + (int64_t)b * (nbk + 1);
+    double* invs = inv_all + (int64_t)b * nbk * 1024;     // [block row][16-column block][row][column] inverses of the diagonal factors' 16 x 16 diagonal blocks
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     bool lost = false;
 
@@ -378,54 +379,49 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                     const int rr = wm + 16 * x + lq + 4 * r, cc = wn + 16 * y + li;
                     t[rr][cc] = Ab[(ri + rr) * lda + rj + cc] - c[x][y][r];
                 }
-        wait_for(j, j + 1);                                        // L[j][j]
+        wait_for(j, j + 1);                                        // L[j][j] and the inverses of its four 16 x 16 diagonal blocks
         PT_STAMP(2);
+        pt_f64x4 mreg[4];                                          // this lane's entries of the inverses, as MFMA A operands: M_b[li][4 r + lq]
         {
             double lv[16];                                         // 16 independent loads in flight, then LDS
             const int r0 = tid >> 6, cc = tid & 63;
 #pragma unroll
             for (int u = 0; u < 16; ++u) lv[u] = Ab[(rj + r0 + 4 * u) * lda + rj + cc];
+            const double* mj = invs + (int64_t)j * 1024 + li * 16 + lq;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                a[r0 + 4 * u][cc] = (cc <= r0 + 4 * u) ? lv[u] : 0.0;
-                if (cc == r0 + 4 * u) invd[cc] = 1.0 / lv[u];
-            }
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mreg[bb][r] = mj[bb * 256 + 4 * r];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[r0 + 4 * u][cc] = (cc <= r0 + 4 * u) ? lv[u] : 0.0;
         }
         __syncthreads();
         PT_STAMP(3);
-        // X L[j][j]^T = T: 16 columns at a time by substitution (one row per lane of wave 0), the remaining columns by MFMA (one 16-row tile per wave)
-        for (int blk = 0; blk < NB; blk += 16) {
-            if (wave == 0) {
-                double x[16];
+        // X L[j][j]^T = T, one 16-row tile per wave, entirely in registers (accumulator layout of the TRANSPOSED tile: lane (li, lq),
+        // register r = element (row li, column lq + 4 r) of a 16 x 16 block): X_b = Y_b M_b^T with the published inverse M_b of the
+        // diagonal block (4 MFMAs) instead of 16 dependent substitution steps, then Y_b'' -= X_b L_b''b^T for the blocks to the right.
+        {
+            pt_f64x4 tacc[4];
+            const int rw = wave * 16;
 #pragma unroll
-                for (int c2 = 0; c2 < 16; ++c2) {
-                    double s0 = t[lane][blk + c2], s1 = 0.0;
+            for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-                    for (int k = 0; k + 1 < c2; k += 2) { s0 = fma(-x[k], a[blk + c2][blk + k], s0); s1 = fma(-x[k + 1], a[blk + c2][blk + k + 1], s1); }
-                    if (c2 & 1) s0 = fma(-x[c2 - 1], a[blk + c2][blk + c2 - 1], s0);
-                    x[c2] = (s0 + s1) * invd[blk + c2];
-                }
+                for (int r = 0; r < 4; ++r) tacc[bb][r] = t[rw + li][16 * bb + lq + 4 * r];
 #pragma unroll
-                for (int c2 = 0; c2 < 16; ++c2) t[lane][blk + c2] = x[c2];
-            }
-            __syncthreads();
-            if (blk + 16 < NB) {
-                const int rr = wave * 16;
-                double af[4];
+            for (int bb = 0; bb < 4; ++bb) {
+                pt_f64x4 xs = pt_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) af[q] = -t[rr + li][blk + 4 * q + lq];
-                for (int J0 = blk + 16; J0 < NB; J0 += 16) {
-                    pt_f64x4 cf;
+                for (int r = 0; r < 4; ++r) xs = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[bb][r], tacc[bb][r], xs, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cf[r] = t[rr + lq + 4 * r][J0 + li];
+                for (int b2 = bb + 1; b2 < 4; ++b2)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cf = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], a[J0 + li][blk + 4 * q + lq], cf, 0, 0, 0);
+                    for (int r = 0; r < 4; ++r)
+                        tacc[b2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[16 * b2 + li][16 * bb + 4 * r + lq], xs[r], tacc[b2], 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[rr + lq + 4 * r][J0 + li] = cf[r];
-                }
-                __syncthreads();
+                for (int r = 0; r < 4; ++r) t[rw + li][16 * bb + lq + 4 * r] = xs[r];
             }
         }
+        __syncthreads();
         PT_STAMP(4);
         {
             const int r0 = tid >> 6, cc = tid & 63;
@@ -452,6 +448,27 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         if (tid == 0) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         PT_STAMP(6);
     }
+    // M_b = L_bb^-1 of the 16 x 16 block at a[blk ..][blk ..] (one wave; straight to the hand-off scratch): row by row, M[c][:] = W[c][:] / l_cc,
+    // then W[R][:] -= L[R][c] M[c][:] for the rows below as ONE rank-1 MFMA; accumulator lane (li, lq), register r = element (lq + 4 r, li).
+    auto inverse16 = [&](int blk) {
+        pt_f64x4 lb, wv, mv = pt_f64x4{0.0, 0.0, 0.0, 0.0};
+        double iv[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { lb[r] = a[blk + li][blk + lq + 4 * r]; wv[r] = (lq + 4 * r == li) ? 1.0 : 0.0; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) iv[c] = invd[blk + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int p = c >> 2, sg = c & 3;
+            const double msel = (lq == sg) ? 1.0 : 0.0;
+            const double mrow = (wv[p] * iv[c]) * msel;
+            mv[p] += mrow;
+            if (c < 15) wv = __builtin_amdgcn_mfma_f64_16x16x4f64(-lb[p] * msel, mrow, wv, 0, 0, 0);
+        }
+        double* dst = invs + (int64_t)i * 1024 + (blk >> 4) * 256 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 16] = mv[r];
+    };
     if (i < npt) {
     [[maybe_unused]] const int jt = i;
     PT_STAMP(7);
@@ -499,6 +516,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         }
         __syncthreads();
         if (blk == 0) PT_STAMP(11);
+        if (wave == 1) inverse16(blk);                     // M_b for the solving workgroups, next to wave 0's substitution below
         if (blk + 16 < NB) {
             const int rr = blk + 16 + tid;                 // rows below the sub-block: X L_bb^T = A_ib
             if (rr < NB) {
@@ -536,7 +554,10 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         }
     }
     PT_STAMP(9);
-    for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, cc = e % NB; Ab[(ri + r) * lda + ri + cc] = (cc <= r) ? a[r][cc] : 0.0; }
+    if (wave != 1) {                                       // (wave 1 is still busy with the last block's inverse)
+        const int t3 = (wave == 0 ? 0 : wave - 1) * 64 + lane;
+        for (int e = t3; e < NB * NB; e += 192) { const int r = e >> 6, cc = e & 63; Ab[(ri + r) * lda + ri + cc] = (cc <= r) ? a[r][cc] : 0.0; }
+    }
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -741,7 +762,9 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
             const unsigned nbk = (unsigned)(n / NB);
             int* progress = mxf_flags(h, (nbk + 1) * (unsigned)S);
             if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
-            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, (int64_t)0, (int)nbk, info, progress);
+            double* pinv = mxf_potrf_inv(h, (size_t)nbk * S * 1024);
+            if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
+            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, (int64_t)0, (int)nbk, info, progress, pinv);
             if (zero_upper) hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
             MXF_LAUNCH_CHECK(h);
             return 0;
@@ -761,7 +784,9 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 const unsigned nbr = (unsigned)((n - c0) / NB);
                 int* progress = mxf_flags(h, (nbr + 1) * (unsigned)S);
                 if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
-                hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)((pe - c0) / NB), info, progress);
+                double* pinv = mxf_potrf_inv(h, (size_t)nbr * S * 1024);
+                if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
+                hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)((pe - c0) / NB), info, progress, pinv);
             }
         }
         for (int64_t j0 = c0; j0 < pe && !panel_tiles; j0 += NB) {

@@ -25,6 +25,8 @@ struct mxf_ctx {
     size_t bwd_acc_bytes = 0;
     void* comm = nullptr;      // RCCL communicator of mxf_comm_init (comm.hip); nullptr on single-GPU handles
     int comm_nranks = 0, comm_rank = -1;
+    double* pinv = nullptr;    // ring of 16 x 16 diagonal-block inverses handed from the factoring to the solving workgroups of potrf_tiles_kernel
+    size_t pinv_elems = 0, pinv_cursor = 0;
     int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
     unsigned flag_cursor = 0;
 };
@@ -39,6 +41,21 @@ static inline int* mxf_flags(mxf_ctx* h, unsigned count) {
     if (h->flag_cursor + count > MXF_NFLAGS) h->flag_cursor = 0;
     int* p = h->flags + h->flag_cursor;
     h->flag_cursor += count;
+    return p;
+}
+
+// ring allocator of the Cholesky tile kernel's inverse blocks (a region is reused only after the ring wrapped: >= 32 launches later)
+static inline double* mxf_potrf_inv(mxf_ctx* h, size_t elems) {
+    if (elems * 2 > h->pinv_elems) {
+        if (h->pinv) { (void)hipDeviceSynchronize(); (void)hipFree(h->pinv); h->pinv = nullptr; h->pinv_elems = 0; }
+        size_t want = elems * 4 > ((size_t)4 << 20) ? elems * 4 : ((size_t)4 << 20);      // >= 32 MB
+        if (hipMalloc((void**)&h->pinv, want * sizeof(double)) != hipSuccess) { h->pinv = nullptr; return nullptr; }
+        h->pinv_elems = want; h->pinv_cursor = 0;
+        ++h->ws_generation;
+    }
+    if (h->pinv_cursor + elems > h->pinv_elems) h->pinv_cursor = 0;
+    double* p = h->pinv + h->pinv_cursor;
+    h->pinv_cursor += elems;
     return p;
 }
 

@@ -22,6 +22,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->flags) (void)hipFree(h->flags);
+    if (h->pinv) (void)hipFree(h->pinv);
     if (h->cond_dev) (void)hipFree(h->cond_dev);
     if (h->bwd_acc) (void)hipFree(h->bwd_acc);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
