@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
                                                           int* __restrict__ progress_all, double* __restrict__ inv_all) {
     __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
     __shared__ double invd[NB];
+    __shared__ double minv[4][16][17];       // the arrived diagonal factor's four inverse blocks
     __shared__ double t[NB][NB + 1];          // the tile being solved
     __shared__ double sm[2][2][16 * PT_SLD];  // k chunks of the two row panels
     __shared__ int sflag;
@@ -387,15 +388,19 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
             const int r0 = tid >> 6, cc = tid & 63;
 #pragma unroll
             for (int u = 0; u < 16; ++u) lv[u] = Ab[(rj + r0 + 4 * u) * lda + rj + cc];
-            const double* mj = invs + (int64_t)j * 1024 + li * 16 + lq;
+            double mvv[4];                                         // the four inverses: 1024 contiguous values, through LDS as well
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mreg[bb][r] = mj[bb * 256 + 4 * r];
+            for (int u = 0; u < 4; ++u) mvv[u] = invs[(int64_t)j * 1024 + tid + 256 * u];
 #pragma unroll
             for (int u = 0; u < 16; ++u) a[r0 + 4 * u][cc] = (cc <= r0 + 4 * u) ? lv[u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) minv[u][tid >> 4][tid & 15] = mvv[u];
         }
         __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mreg[bb][r] = minv[bb][li][4 * r + lq];
         PT_STAMP(3);
         // X L[j][j]^T = T, one 16-row tile per wave, entirely in registers (accumulator layout of the TRANSPOSED tile: lane (li, lq),
         // register r = element (row li, column lq + 4 r) of a 16 x 16 block): X_b = Y_b M_b^T with the published inverse M_b of the
