@@ -262,8 +262,11 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
     __shared__ double invd[NB];
     __shared__ double minv[4][16][17];       // the arrived diagonal factor's four inverse blocks
-    __shared__ double t[NB][NB + 1];          // the tile being solved
-    __shared__ double sm[2][2][16 * PT_SLD];  // k chunks of the two row panels
+    // the tile being solved, and (never at the same time) the k chunks of the two row panels of the left-looking product: 70 KB of LDS in
+    // all, so that a 64 KB float64 GEMM workgroup of the look-ahead trailing update still fits on the same CU
+    __shared__ double tsm[(2 * 2 * 16 * PT_SLD > NB * (NB + 1)) ? 2 * 2 * 16 * PT_SLD : NB * (NB + 1)];
+    double (*t)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(tsm);
+    double (*sm)[2][16 * PT_SLD] = reinterpret_cast<double (*)[2][16 * PT_SLD]>(tsm);
     __shared__ int sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
     const int i = blockIdx.x, b = blockIdx.y, nbk = (int)gridDim.x;
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         PT_STAMP(0);
         panel_product(c, ri, rj, c0, rj, j);                      // sum_{k<j} L[i][k] L[j][k]^T  (row j's tiles k < j: gated on progress[j])
         PT_STAMP(1);
+        __syncthreads();                                           // (the product's last chunk has been read: its LDS becomes the tile)
         // (the tile's own entries do not depend on L[j][j]: they are in LDS before it arrives)
 #pragma unroll
         for (int x = 0; x < 2; ++x)
