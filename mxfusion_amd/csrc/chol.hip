@@ -767,7 +767,8 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // tiles_env: 0 = launch-per-panel form everywhere, 1 = the one-launch kernel for n <= 1024 and per outer panel for larger n, 2 = only n <= 1024
     const bool tiles_ok = sizeof(T) == 8 && tiles_env && n % NB == 0 && n >= 2 * NB && S <= 64;
     if constexpr (sizeof(T) == 8) {
-        if (tiles_ok && n <= 1024) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
+        static const int one_max = getenv("MXF_POTRF_ONE_MAX") ? atoi(getenv("MXF_POTRF_ONE_MAX")) : 512;
+        if (tiles_ok && n <= one_max) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
             const unsigned nbk = (unsigned)(n / NB);
             int* progress = mxf_flags(h, (nbk + 1) * (unsigned)S);
             if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
@@ -779,7 +780,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
             return 0;
         }
     }
-    const bool panel_tiles = tiles_ok && tiles_env == 1 && n > 1024 && n / NB <= 256;      // every block row's workgroup must be resident at once
+    const bool panel_tiles = tiles_ok && tiles_env == 1 && n / NB <= 256;      // every block row's workgroup must be resident at once
     static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 2;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
