@@ -659,7 +659,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // Two launches: phase A covers the first KA = 128 M columns (about as long as the core chains run) with ONE workgroup per CU on
         // ~216 CUs, so that the core chains' f64 workgroups (a whole CU's LDS / registers each) still find free CUs; phase B (the rest)
         // fills the chip.  Same-box A/B at 4 samples per GPU: 13.65 -> 12.95 ms per step; neutral at 32 samples.
-        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split ? 192 : 128) * M;
+        // (few samples per GPU: the whole product runs in the reduced-occupancy form -- the core chains are the critical path there and
+        //  Psi2 is short; same-box at 4 samples: 5.46 -> 5.20 ms per step; at 32 samples a longer first phase costs 0.1-0.4 ms)
+        const int64_t ka_dflt = (use_split ? 192 : 128) * M;
+        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split && SB <= 2 * ka_dflt ? SB : ka_dflt);
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         if (use_split) {
             if (KA > 0) {
