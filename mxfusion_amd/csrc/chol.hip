@@ -258,7 +258,7 @@ typedef double pt_f64x4 __attribute__((ext_vector_type(4)));
 // below c0 -- left-looking INSIDE the panel (columns left of c0 were applied by the trailing updates of the earlier panels): block rows
 // i < npt end with their diagonal tile, the others only solve.  nbr = block rows, counters: nbr progress words + one completion word.
 __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int* __restrict__ info,
-                                                          int* __restrict__ progress_all, double* __restrict__ inv_all) {
+                                                          int* __restrict__ progress_all, double* __restrict__ inv_all, int row0, int nowait) {
     __shared__ double a[NB][NB + 1];          // diagonal factor L[j][j] (or, for j == i, the tile being factored)
     __shared__ double invd[NB];
     __shared__ double minv[4][16][17];       // the arrived diagonal factor's four inverse blocks
@@ -269,15 +269,18 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     double (*sm)[2][16 * PT_SLD] = reinterpret_cast<double (*)[2][16 * PT_SLD]>(tsm);
     __shared__ int sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    const int i = blockIdx.x, b = blockIdx.y, nbk = (int)gridDim.x;
+    // row0 / nowait: the SECOND launch of a split outer panel -- block rows row0 .. below an already factored diagonal block: every tile
+    // they need is final (stream order), nothing is waited for or published
+    const int i = row0 + (int)blockIdx.x, b = blockIdx.y, nbk = (int)gridDim.x;
     double* Ab = A + (int64_t)b * sA;
     int* progress = progress_all + (int64_t)b * (nbk + 1);
-    double* invs = inv_all + (int64_t)b * nbk * 1024;     // [block row][16-column block][row][column] inverses of the diagonal factors' 16 x 16 diagonal blocks
+    double* invs = inv_all + (int64_t)b * npt * 1024;     // [block row][16-column block][row][column] inverses of the diagonal factors' 16 x 16 diagonal blocks
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     bool lost = false;
 
     // all threads: block until progress[row] >= need; returns the value seen (progress only grows: the caller skips later waits it covers)
     auto wait_for = [&](int row, int need) -> int {
+        if (nowait) return 1 << 30;
         if (tid == 0) {
             int spins = 0, v;
             while ((v = __hip_atomic_load(progress + row, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need) {
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
         PT_STAMP(5);
         __threadfence();
         __syncthreads();                                           // (also: t is rewritten by the next tile)
-        if (tid == 0) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !nowait) __hip_atomic_store(progress + i, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         PT_STAMP(6);
     }
     // M_b = L_bb^-1 of the 16 x 16 block at a[blk ..][blk ..] (one wave; straight to the hand-off scratch): row by row, M[c][:] = W[c][:] / l_cc,
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void potrf_tiles_kernel(double* __restrict__ A
     if (tid == 0) __hip_atomic_store(progress + i, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     PT_STAMP(10);
     }
-    if (tid == 0) {
+    if (tid == 0 && !nowait) {
         if (lost && info) info[b] = -1;
         // the workgroup that completes last leaves the counters at zero for the next launch (every poll of a counter precedes the poller's own completion)
         if (__hip_atomic_fetch_add(progress + nbk, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nbk - 1)
@@ -774,7 +777,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
             if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
             double* pinv = mxf_potrf_inv(h, (size_t)nbk * S * 1024);
             if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
-            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, (int64_t)0, (int)nbk, info, progress, pinv);
+            hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbk, (unsigned)S), dim3(256), 0, st, A, lda, sA, (int64_t)0, (int)nbk, info, progress, pinv, 0, 0);
             if (zero_upper) hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
             MXF_LAUNCH_CHECK(h);
             return 0;
@@ -791,12 +794,21 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         const int64_t pe = (c0 + NBO < n) ? c0 + NBO : n;   // panel end
         if constexpr (sizeof(T) == 8) {
             if (panel_tiles) {       // the whole outer panel in ONE launch (8 dependent panel steps + 7 left-looking GEMMs before)
-                const unsigned nbr = (unsigned)((n - c0) / NB);
-                int* progress = mxf_flags(h, (nbr + 1) * (unsigned)S);
+                const unsigned nbr = (unsigned)((n - c0) / NB), npt = (unsigned)((pe - c0) / NB);
+                // Many block rows below the panel: two launches -- the panel's own block rows (the latency chain, npt workgroups), then the
+                // rows below against the finished diagonal block, nothing to wait for (~90 us of MFMA work each).  In one launch those rows
+                // sit resident and mostly idle for the whole chain, one CU each, and the look-ahead GEMM next to them (whose 133 KB of LDS
+                // cannot share a CU with a tile workgroup) runs on what is left.
+                static const int split_rows = getenv("MXF_POTRF_SPLIT_ROWS") ? atoi(getenv("MXF_POTRF_SPLIT_ROWS")) : 64;
+                const bool split = split_rows > 0 && nbr - npt >= (unsigned)split_rows;
+                const unsigned na = split ? npt : nbr;
+                int* progress = mxf_flags(h, (na + 1) * (unsigned)S);
                 if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
-                double* pinv = mxf_potrf_inv(h, (size_t)nbr * S * 1024);
+                double* pinv = mxf_potrf_inv(h, (size_t)npt * S * 1024);
                 if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
-                hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)((pe - c0) / NB), info, progress, pinv);
+                hipLaunchKernelGGL(potrf_tiles_kernel, dim3(na, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, 0, 0);
+                if (split)
+                    hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr - npt, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, (int)npt, 1);
             }
         }
         for (int64_t j0 = c0; j0 < pe && !panel_tiles; j0 += NB) {
