@@ -67,6 +67,41 @@ def test_potrf_tiles_not_positive_definite_reports_info():
     assert int(info2[0]) == 0 and np.allclose(L2[0].cpu().numpy(), np.linalg.cholesky(A[0]), rtol=1e-11, atol=1e-11)
 
 
+def test_potrf_tiles_scratch_rings_wrap_and_streams_do_not_collide():
+    """The tile kernel hands tiles on through two per-handle rings (progress counters, inverse blocks of the diagonal factors): 400
+    back-to-back factorisations wrap both; two streams factoring at the same time (as the SVGP step does with Kuu and Su) use disjoint
+    regions.  Every result is checked against the first one / against LAPACK."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(11)
+    A = _spd(rng, 1, 1024)
+    ref = np.linalg.cholesky(A[0])
+    Ad = _dev(A)
+    first = ops.potrf_(Ad.clone())[0]
+    assert np.allclose(first[0].cpu().numpy(), ref, rtol=1e-11, atol=1e-11)
+    last = None
+    for _ in range(400):
+        last, info = ops.potrf_(Ad.clone())
+    # (not bit-identical run to run: the trailing update between the two outer panels is a split-K product with float64 atomics)
+    assert int(info[0]) == 0 and torch.allclose(last, first, rtol=1e-12, atol=1e-13)
+    B = _dev(_spd(rng, 1, 768))
+    refB = np.linalg.cholesky(B[0].cpu().numpy())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(20):
+        a, b2 = Ad.clone(), B.clone()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            la, _ = ops.potrf_(a)
+        with torch.cuda.stream(s2):
+            lb, _ = ops.potrf_(b2)
+        outs.append((la, lb))
+    torch.cuda.synchronize()
+    for la, lb in outs:
+        assert torch.allclose(la, first, rtol=1e-12, atol=1e-13)
+        assert np.allclose(lb[0].cpu().numpy(), refB, rtol=1e-11, atol=1e-11)
+
+
 def test_potrf_not_positive_definite_reports_info():
     from mxfusion_amd import ops, _lib
     A = np.eye(70)[None].repeat(2, 0)
