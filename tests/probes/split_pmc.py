@@ -1,5 +1,5 @@
 """One-kernel workloads for the PMC passes of the split GEMMs.  usage: split_pmc.py t|psi2 [SB]
-t: T = H0 Kuf shape (1024 x SB x 1024, 128 x 128 kernel); psi2: Kuf Kuf^T, lower blocks (1024 x 1024 x SB, 128 x 256 kernel).  3 launches."""
+t: T = H0 Kuf shape (1024 x SB x 1024) with the output in 16-column blocks as the training step writes it (persistent 128 x 256 kernel); psi2: Kuf Kuf^T, lower blocks (1024 x 1024 x SB, 128 x 256 kernel).  3 launches."""
 import os
 import sys
 import torch
@@ -14,7 +14,7 @@ if which == 't':
     del B
     out = torch.empty(M, SB, device='cuda')
     for _ in range(3):
-        ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out)
+        ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out, blocked=True)
 else:
     C = torch.rand(M, SB, device='cuda')
     pc = ops.f16x2_split(C)
