@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomic_add(p + e, v[e]);
                 } else if (beta == 0.f) {
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+                    *reinterpret_cast<f32x4*>(p) = v;      // (plain, not non-temporal: T of the SVGP step 12.7 -> 11.9 ms, same box)
                 } else {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(p);
                     *reinterpret_cast<f32x4*>(p) = v + beta * o;
