@@ -509,6 +509,10 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
         }
         __syncthreads();
         const int nkb = (int)((K16 - kb0) < CH ? (K16 - kb0) : CH);
+        // (FULL: every major point of the chunk exists -- always, when Kn is a multiple of 16 -- so the per-element range test, a 64-bit
+        //  compare + select per covariance, 8 % of the kernel's instructions, is compiled out)
+        auto chunk_body = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         for (int kbl = 0; kbl < nkb; ++kbl) {
             gp_u32x4 uh, um, ul;
 #pragma unroll
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
                         acc2 = __builtin_elementwise_fma(d, d, acc2);
                     }
                     const float red = acc2.x + acc2.y;
-                    kv[e] = (kb0 * 16 + nl < Kn) ? cov_from<float, KIND>(red, variance) : 0.f;
+                    kv[e] = (FULL || kb0 * 16 + nl < Kn) ? cov_from<float, KIND>(red, variance) : 0.f;
                     if (PT > 0) {
 #pragma unroll
                         for (int p = 0; p < PT; ++p) uacc[p] = fmaf(ws[nl * PT + p], kv[e], uacc[p]);
@@ -561,6 +565,8 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
                 if (NP == 3) __builtin_nontemporal_store(ul, reinterpret_cast<gp_u32x4*>(dst + 2 * pstride));
             }
         }
+        };
+        if ((kb0 + nkb) * 16 <= Kn) chunk_body(std::true_type{}); else chunk_body(std::false_type{});
     }
     if (PT > 0) {      // the two threads of a row hold the two k halves: fold them, undo the plane scaling, one store per (row, p)
         const float sc = NP == 2 ? var[0] * (1.f / 16384.f) : 1.f;
