@@ -388,9 +388,10 @@ def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     return dt, float(loss.detach())
 
 
-def gram_roofline(N, Q, dtype, reps=10):
+def gram_roofline(N, Q, dtype, reps=40):
     """RBF Gram at N x N, Q: algorithmic bytes = N*N*sizeof written + 2*N*Q*sizeof read, timed with HIP
-    events on the stream the kernel is launched on (torch's current stream)."""
+    events on the stream the kernel is launched on (torch's current stream).  40 timed launches behind 2 untimed ones: the first launch
+    of a process runs ~20 % longer (cold TLB / clocks), and a rocprofv3 --stats average of the same command should not be moved by it."""
     from mxfusion_amd import ops
     td = torch.float32 if dtype == 'float32' else torch.float64
     X = torch.rand(1, N, Q, device='cuda', dtype=td) * 6 - 3
