@@ -317,6 +317,136 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
     });
 }
 
+// ---- float64 C = alpha A B^T + beta C (A: M x K, B: N x K, both with k contiguous), interior tiles only: LDS-DMA, three buffers ----------
+// The generic kernel stages every operand block through registers (global -> VGPR -> ds_write with a transposition -> barrier); with one
+// 133 KB workgroup per CU nothing covers that phase and the matrix pipe stands at 57-61 %.  Here the blocks go
+// global -> LDS by DMA (global_load_lds_dwordx4, no staging registers, no store phase), two blocks ahead into a three-slot ring, and stay
+// in their [row][k] form: a 16-wide k block of a row is 128 bytes = eight 16-byte units, unit u of row r stored at position u ^ ((r >> 1) & 7)
+// (the swizzle is applied to the SOURCE address, the DMA writes lane-contiguously), which makes the MFMA operand reads -- lane (li, lk)
+// reads element (row li, k = ks + lk) -- conflict-free: 16 rows x 2 halves of a unit cover the 64 banks exactly once per half wave.
+// Tile 128 x 128, BK = 16, eight waves of 64 x 32 (as the generic kernel), 96 KB of LDS.  Requirements (checked by the launcher):
+// M, N multiples of 128, every k range a multiple of 16, 16-byte aligned rows.
+constexpr int DBK = 16;
+__global__ __launch_bounds__(512, 2) void gemm_f64_nt_dma_kernel(GemmArgs<double> g) {
+    __shared__ __attribute__((aligned(16))) double smem[3][2][128 * DBK];      // [slot][A|B][row][k] (swizzled units)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+    int64_t wid = blockIdx.x;
+    {
+        const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t zs = wid / g.ntiles;
+    int64_t t = wid % g.ntiles;
+    int64_t tile_m, tile_n;
+    if (g.lower_only) {
+        int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > t) --row;
+        while ((row + 1) * (row + 2) / 2 <= t) ++row;
+        tile_m = row; tile_n = t - row * (row + 1) / 2;
+    } else {
+        tile_m = t % g.tm; tile_n = t / g.tm;
+        if (g.k_from_m == 2 && g.rev_m) tile_m = g.tm - 1 - tile_m;
+    }
+    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const int batch = (int)(zs / g.splitk), split = (int)(zs % g.splitk);
+    const double* __restrict__ A = g.A + (int64_t)batch * g.sA;
+    const double* __restrict__ B = g.B + (int64_t)batch * g.sB;
+    double* __restrict__ C = g.C + (int64_t)batch * g.sC;
+    int64_t kbeg = (int64_t)split * g.kchunk;
+    int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m == 2) { const int64_t kl = m0 + BM; if (kl < kend) kend = kl; }
+    const int64_t nk = (kend - kbeg) / DBK;
+
+    Acc<double> acc;
+    acc.zero();
+    // DMA: one wave instruction fills 1 KB = 8 rows x 128 B; wave w, instruction j (0, 1) of an operand: rows 16 w + 8 j .. + 8.
+    // lane l -> row (l >> 3), position (l & 7); it fetches the unit that belongs at that position: u = pos ^ ((row >> 1) & 7)
+    const double* srcA[2];
+    const double* srcB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * wave + 8 * j + (lane >> 3);
+        const int u = (lane & 7) ^ ((row >> 1) & 7);
+        srcA[j] = A + (m0 + row) * g.lda + kbeg + 2 * u;
+        srcB[j] = B + (n0 + row) * g.ldb + kbeg + 2 * u;
+    }
+#define D_ISSUE(kb, SLOT)                                                                                                           \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (kb) * DBK),                 \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][0][(16 * wave + 8 * j) * DBK]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (kb) * DBK),                 \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][1][(16 * wave + 8 * j) * DBK]), 16, 0, 0); \
+        }                                                                                                                           \
+    } while (0)
+#define D_WAIT(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+    const int li = lane & 15, lk = lane >> 4;
+    // operand element (row, k = 4 q + lk) of a slab: unit (4 q + lk) >> 1 at its swizzled position, half (lk & 1)
+    int offA[4][4], offB[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const int row = wm + 16 * x + li; offA[x][q] = row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1); }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) { const int row = wn + 16 * y + li; offB[y][q] = row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1); }
+    }
+#define D_COMPUTE(SLOT)                                                                                                             \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                             \
+            double a_[4], b_[2];                                                                                                    \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) a_[x] = smem[SLOT][0][offA[x][q]];                                        \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) b_[y] = smem[SLOT][1][offB[y][q]];                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
+                _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
+                    acc.c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[x], b_[y], acc.c[x][y], 0, 0, 0);                         \
+        }                                                                                                                           \
+    } while (0)
+    // block kk in SLOT; block kk + 2 (clamped to the last block: its surplus copies are never read) is requested into the slot block
+    // kk - 1 left at the last barrier; then the MFMAs; then the wait for block kk + 1 with block kk + 2 in flight (4 requests per block)
+#define D_STEP(kk, SLOT, SLOT2)                                                                                                     \
+    do {                                                                                                                            \
+        const int64_t k2_ = (kk) + 2 < nk ? (kk) + 2 : nk - 1;                                                                      \
+        D_ISSUE(k2_, SLOT2);                                                                                                        \
+        D_COMPUTE(SLOT);                                                                                                            \
+        D_WAIT(4);                                                                                                                  \
+    } while (0)
+    if (nk > 0) {
+        int64_t kb = 0;
+        for (int i = (int)(nk % 3); i > 0; --i, ++kb) {        // the remainder first, unpipelined
+            D_ISSUE(kb, 0);
+            D_WAIT(0);
+            D_COMPUTE(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (kb < nk) {
+            D_ISSUE(kb, 0);
+            D_ISSUE(kb + 1, 1);
+            D_WAIT(4);
+            for (; kb < nk; kb += 3) {
+                D_STEP(kb, 0, 2);
+                D_STEP(kb + 1, 1, 0);
+                D_STEP(kb + 2, 2, 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+#undef D_STEP
+#undef D_COMPUTE
+#undef D_WAIT
+#undef D_ISSUE
+    const double alpha = g.alpha, beta = g.beta;
+    const bool atomic = g.atomic != 0;
+    acc.for_each(wm, wn, lane, [&](int r, int c, double v) {
+        const int64_t row = m0 + r, col = n0 + c;
+        if (!(g.lower_only && col > row)) {
+            double* p = C + row * g.ldc + col;
+            if (atomic) atomic_add(p, alpha * v);
+            else *p = (beta == 0.0) ? alpha * v : alpha * v + beta * (*p);
+        }
+    });
+}
+
 // C *= beta (or C = 0) ahead of a split-K launch whose epilogue is atomicAdd
 template <typename T>
 __global__ void scale_kernel(T* C, int64_t M, int64_t N, int64_t ldc, int64_t sC, T beta, int lower_only) {
@@ -536,6 +666,15 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         hipLaunchKernelGGL((scale_kernel<T>), gs, dim3(256), 0, st, (T*)C, M, N, ldc, sC, (T)beta, lower_only);
     }
     dim3 grid((unsigned)g.nwg, 1, 1);
+    if constexpr (sizeof(T) == 8) {
+        static const int dma_env = getenv("MXF_GEMM_F64_DMA") ? atoi(getenv("MXF_GEMM_F64_DMA")) : 1;
+        if (dma_env && !ta && tb && g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % DBK == 0 && kchunk % DBK == 0 && g.k_from_m != 1 &&
+            !g.xc_max && NWAVE == 8) {
+            hipLaunchKernelGGL(gemm_f64_nt_dma_kernel, grid, dim3(512), 0, st, g);
+            MXF_LAUNCH_CHECK(h);
+            return 0;
+        }
+    }
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(NT), 0, st, g);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(NT), 0, st, g);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(NT), 0, st, g);
