@@ -326,20 +326,32 @@ __global__ __launch_bounds__(NT, (NWAVE == 8 ? (sizeof(T) == 4 ? 4 : 2) : (sizeo
 // reads element (row li, k = ks + lk) -- conflict-free: 16 rows x 2 halves of a unit cover the 64 banks exactly once per half wave.
 // Tile 128 x 128, BK = 16, eight waves of 64 x 32 (as the generic kernel), 96 KB of LDS.  Requirements (checked by the launcher):
 // M, N multiples of 128, every k range a multiple of 16, 16-byte aligned rows.
-constexpr int DBK = 16;
-__global__ __launch_bounds__(512, 2) void gemm_f64_nt_dma_kernel(GemmArgs<double> g) {
-    __shared__ __attribute__((aligned(16))) double smem[3][2][128 * DBK];      // [slot][A|B][row][k] (swizzled units)
+// An operand stored the other way round (K x M with the rows of the tile contiguous: A of a transposed-A product, B of a plain-B one) comes
+// in as its 16 k rows of 1 KB, one DMA instruction each, at an LDS row stride of 144 doubles (1 KB + 128 B: the two k values a half wave
+// reads fall on the two halves of the banks).  AKM / BKM: operand stored as (k, m).
+constexpr int DBK = 16, DKM_LD = 144;
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_f64_dma_kernel(GemmArgs<double> g) {
+    constexpr int ASZ = AKM ? DBK * DKM_LD : 128 * DBK, BSZ = BKM ? DBK * DKM_LD : 128 * DBK;
+    __shared__ __attribute__((aligned(16))) double smem[3][ASZ + BSZ];      // [slot][A slab | B slab]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
     int64_t wid = blockIdx.x;
-    {
+    if (!g.xc_max) {
         const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int64_t zs = wid / g.ntiles;
+    int64_t zs = wid / g.ntiles;
     int64_t t = wid % g.ntiles;
     int64_t tile_m, tile_n;
-    if (g.lower_only) {
+    if (g.xc_max) {                              // balanced triangular mapping, as gemm_kernel
+        const int64_t per = 8 * g.xc_max, rem = (int64_t)blockIdx.x % per;
+        zs = (int64_t)blockIdx.x / per;
+        int64_t row = rem & 7, j = rem >> 3;
+        while (row < g.tm && j >= row + 1) { j -= row + 1; row += 8; }
+        if (row >= g.tm) return;
+        tile_m = row; tile_n = j;
+    } else if (g.lower_only) {
         int64_t row = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while (row * (row + 1) / 2 > t) --row;
         while ((row + 1) * (row + 2) / 2 <= t) ++row;
@@ -355,48 +367,59 @@ __global__ __launch_bounds__(512, 2) void gemm_f64_nt_dma_kernel(GemmArgs<double
     double* __restrict__ C = g.C + (int64_t)batch * g.sC;
     int64_t kbeg = (int64_t)split * g.kchunk;
     int64_t kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    if (g.k_from_m == 1) { const int64_t kf = m0 / BK * BK; if (kf > kbeg) kbeg = kf; }
     if (g.k_from_m == 2) { const int64_t kl = m0 + BM; if (kl < kend) kend = kl; }
-    const int64_t nk = (kend - kbeg) / DBK;
+    const int64_t nk = kend > kbeg ? (kend - kbeg) / DBK : 0;
 
     Acc<double> acc;
     acc.zero();
-    // DMA: one wave instruction fills 1 KB = 8 rows x 128 B; wave w, instruction j (0, 1) of an operand: rows 16 w + 8 j .. + 8.
-    // lane l -> row (l >> 3), position (l & 7); it fetches the unit that belongs at that position: u = pos ^ ((row >> 1) & 7)
+    // DMA sources of this lane, two instructions per operand and block.  (m, k) storage: instruction j covers rows 16 w + 8 j .. + 8, lane l
+    // -> row (l >> 3), position (l & 7), fetching unit pos ^ ((row >> 1) & 7).  (k, m) storage: instruction j is k row 2 w + j, lane l -> m = 2 l.
     const double* srcA[2];
     const double* srcB[2];
+    int dstA[2], dstB[2];
+    int64_t stepA, stepB;                 // source advance per k block
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int row = 16 * wave + 8 * j + (lane >> 3);
-        const int u = (lane & 7) ^ ((row >> 1) & 7);
-        srcA[j] = A + (m0 + row) * g.lda + kbeg + 2 * u;
-        srcB[j] = B + (n0 + row) * g.ldb + kbeg + 2 * u;
+        if (AKM) { const int kr = 2 * wave + j; srcA[j] = A + (kbeg + kr) * g.lda + m0 + 2 * lane; dstA[j] = kr * DKM_LD; }
+        else { const int row = 16 * wave + 8 * j + (lane >> 3); srcA[j] = A + (m0 + row) * g.lda + kbeg + 2 * ((lane & 7) ^ ((row >> 1) & 7)); dstA[j] = (16 * wave + 8 * j) * DBK; }
+        if (BKM) { const int kr = 2 * wave + j; srcB[j] = B + (kbeg + kr) * g.ldb + n0 + 2 * lane; dstB[j] = ASZ + kr * DKM_LD; }
+        else { const int row = 16 * wave + 8 * j + (lane >> 3); srcB[j] = B + (n0 + row) * g.ldb + kbeg + 2 * ((lane & 7) ^ ((row >> 1) & 7)); dstB[j] = ASZ + (16 * wave + 8 * j) * DBK; }
     }
+    stepA = AKM ? (int64_t)DBK * g.lda : DBK;
+    stepB = BKM ? (int64_t)DBK * g.ldb : DBK;
 #define D_ISSUE(kb, SLOT)                                                                                                           \
     do {                                                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                             \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (kb) * DBK),                 \
-                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][0][(16 * wave + 8 * j) * DBK]), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (kb) * DBK),                 \
-                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][1][(16 * wave + 8 * j) * DBK]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (kb) * stepA),               \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][dstA[j]]), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (kb) * stepB),               \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][dstB[j]]), 16, 0, 0);            \
         }                                                                                                                           \
     } while (0)
 #define D_WAIT(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
     const int li = lane & 15, lk = lane >> 4;
-    // operand element (row, k = 4 q + lk) of a slab: unit (4 q + lk) >> 1 at its swizzled position, half (lk & 1)
+    // operand element (row, k = 4 q + lk) of a slab
     int offA[4][4], offB[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { const int row = wm + 16 * x + li; offA[x][q] = row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1); }
+        for (int x = 0; x < 4; ++x) {
+            const int row = wm + 16 * x + li;
+            offA[x][q] = AKM ? (4 * q + lk) * DKM_LD + row : row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1);
+        }
 #pragma unroll
-        for (int y = 0; y < 2; ++y) { const int row = wn + 16 * y + li; offB[y][q] = row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1); }
+        for (int y = 0; y < 2; ++y) {
+            const int row = wn + 16 * y + li;
+            offB[y][q] = ASZ + (BKM ? (4 * q + lk) * DKM_LD + row : row * DBK + ((((4 * q + lk) >> 1) ^ ((row >> 1) & 7)) << 1) + (lk & 1));
+        }
     }
 #define D_COMPUTE(SLOT)                                                                                                             \
     do {                                                                                                                            \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                             \
             double a_[4], b_[2];                                                                                                    \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x) a_[x] = smem[SLOT][0][offA[x][q]];                                        \
-            _Pragma("unroll") for (int y = 0; y < 2; ++y) b_[y] = smem[SLOT][1][offB[y][q]];                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) a_[x] = smem[SLOT][offA[x][q]];                                           \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) b_[y] = smem[SLOT][offB[y][q]];                                           \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
                 _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
                     acc.c[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[x], b_[y], acc.c[x][y], 0, 0, 0);                         \
@@ -668,9 +691,11 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     dim3 grid((unsigned)g.nwg, 1, 1);
     if constexpr (sizeof(T) == 8) {
         static const int dma_env = getenv("MXF_GEMM_F64_DMA") ? atoi(getenv("MXF_GEMM_F64_DMA")) : 1;
-        if (dma_env && !ta && tb && g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % DBK == 0 && kchunk % DBK == 0 && g.k_from_m != 1 &&
-            !g.xc_max && NWAVE == 8) {
-            hipLaunchKernelGGL(gemm_f64_nt_dma_kernel, grid, dim3(512), 0, st, g);
+        if (dma_env && g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % DBK == 0 && kchunk % DBK == 0 && NWAVE == 8) {
+            if (!ta && tb) hipLaunchKernelGGL((gemm_f64_dma_kernel<false, false>), grid, dim3(512), 0, st, g);
+            else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_dma_kernel<true, true>), grid, dim3(512), 0, st, g);
+            else if (ta && tb) hipLaunchKernelGGL((gemm_f64_dma_kernel<true, false>), grid, dim3(512), 0, st, g);
+            else hipLaunchKernelGGL((gemm_f64_dma_kernel<false, true>), grid, dim3(512), 0, st, g);
             MXF_LAUNCH_CHECK(h);
             return 0;
         }
