@@ -231,18 +231,19 @@ __global__ __launch_bounds__(128) void potrf_panel_kernel(T* __restrict__ A, int
     }
 }
 
-// ---- persistent tile-dataflow Cholesky (float64, n a multiple of 64, n <= 1024): ONE launch, one workgroup per 64-row block row --------
-// The launch-per-panel form above costs 16 x (panel kernel ~45 us + left-looking GEMM + two dependent-launch gaps) at n = 1024: 0.86 ms,
-// every one of them on the critical path of the SVGP step when few samples are left per GPU.  Here workgroup i owns
-// block row i and walks its tiles j = 0 .. i left-looking:
-//     C = A[i][j] - sum_{k<j} L[i][k] L[j][k]^T      (ONE k loop of length 64 j over two contiguous row panels, f64 MFMA)
-//     j < i :  L[i][j] = C L[j][j]^-T                 (row solve against block row j's diagonal factor)
-//     j = i :  L[i][i] = chol(C)
+// ---- tile-dataflow Cholesky (float64, n a multiple of 64): one workgroup per 64-row block row -----------------------------------------
+// n <= 512 in ONE launch; larger n one launch per 512-column outer panel (below).  The launch-per-panel form above costs 16 x (panel
+// kernel ~45 us + left-looking GEMM + two dependent-launch gaps) at n = 1024: 0.86 ms, every one of them on the critical path of the SVGP
+// step when few samples are left per GPU.  Here workgroup i owns block row i and walks its tiles j = 0 .. i
+// left-looking:
+//     C = A[i][j] - sum_{k<j} L[i][k] L[j][k]^T      (ONE k loop of length 64 j over two contiguous row panels, f64 MFMA, software-pipelined)
+//     j < i :  L[i][j] = C L[j][j]^-T                 (with the inverses of L[j][j]'s four 16 x 16 diagonal blocks, which its owner publishes)
+//     j = i :  L[i][i] = chol(C)                      (16 x 16 sub-blocks as rank-1 MFMA steps in one accumulator)
 // and hands tiles on through a progress counter per block row (release store after the tile is in memory; readers acquire): tile (i, j)
 // needs progress[j] >= j before its k loop and progress[j] == j + 1 before its solve.  The diagonal tile's update is accumulated
-// incrementally (one 64^3 product after every solve), so the critical path per block column is factor (19 us) -> solve of the next row's
-// tile -> one product -> factor.  Every workgroup must be resident at once (<= 32 workgroups); spins are bounded (a lost hand-off reports
-// info = -1 instead of hanging the queue).
+// incrementally (one 64^3 product after every solve), so the critical path per block column is factor -> solve of the next row's tile ->
+// one product -> factor: 23 us (DESIGN.md section 4 has the stage table; tests/probes/potrf_trace.py measures it).  Every workgroup
+// must be resident at once (<= 256 workgroups); spins are bounded (a lost hand-off reports info = -1 instead of hanging the queue).
 #ifdef MXF_POTRF_TRACE
 // probe build only (tests/probes/potrf_trace.py): 100 MHz timestamps of the stages of block rows 0 .. 15, [row][column j][stage]
 __device__ long long potrf_trace_buf[16 * 17 * 16];
@@ -767,7 +768,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
     static const int tiles_env = getenv("MXF_POTRF_TILES") ? atoi(getenv("MXF_POTRF_TILES")) : 1;
-    // tiles_env: 0 = launch-per-panel form everywhere, 1 = the one-launch kernel for n <= 1024 and per outer panel for larger n, 2 = only n <= 1024
+    // tiles_env: 0 = launch-per-panel form everywhere, 1 = the tile kernel (one launch up to MXF_POTRF_ONE_MAX = 512, per outer panel beyond), 2 = only its one-launch form
     const bool tiles_ok = sizeof(T) == 8 && tiles_env && n % NB == 0 && n >= 2 * NB && S <= 64;
     if constexpr (sizeof(T) == 8) {
         static const int one_max = getenv("MXF_POTRF_ONE_MAX") ? atoi(getenv("MXF_POTRF_ONE_MAX")) : 512;
