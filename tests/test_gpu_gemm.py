@@ -25,6 +25,24 @@ def test_gemm_vs_cpu(dtype, tol, ta, tb, M, N, K, S):
     assert np.allclose(out2.cpu().numpy(), (ref + 0.3 * C0) / 0.7, rtol=tol, atol=tol * scale)
 
 
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K,S', [(1152, 1280, 208, 1),      # > 64 tiles of 128 x 128, short K: one launch, no split
+                                     (1152, 1152, 1040, 2),     # batched, long K: split-K with the atomic epilogue
+                                     (2048, 1024, 48, 1)])      # three 16-wide k blocks only (the unpipelined remainder path)
+def test_gemm_float64_lds_dma_kernel(ta, tb, M, N, K, S):
+    """gemm_f64_dma_kernel (128-aligned float64 shapes with more than 64 tiles; all four operand layouts, B broadcast over the batch,
+    alpha / beta, split-K) against numpy."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(S, K, M) if ta else rng.randn(S, M, K)
+    B = rng.randn(1, N, K) if tb else rng.randn(1, K, N)
+    C0 = rng.randn(S, M, N)
+    ref = 0.7 * (np.swapaxes(A, 1, 2) if ta else A) @ (np.swapaxes(B, 1, 2) if tb else B) - 0.3 * C0
+    out = torch.as_tensor(C0).cuda()
+    ops.gemm(torch.as_tensor(A).cuda(), torch.as_tensor(B).cuda(), ta, tb, 0.7, -0.3, out=out)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * np.sqrt(K))
+
+
 @pytest.mark.parametrize('M,N,K,lower', [(128, 128, 16, False), (256, 384, 1024, False), (130, 70, 50, False), (1, 5, 7, False),
                                           (1024, 1024, 4096, True), (300, 300, 333, True), (512, 8192, 512, False)])
 def test_gemm_f32x3_is_f32_accurate(M, N, K, lower):
