@@ -28,7 +28,7 @@ def test_gemm_vs_cpu(dtype, tol, ta, tb, M, N, K, S):
 @pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize('M,N,K,S', [(1152, 1280, 208, 1),      # > 64 tiles of 128 x 128, short K: one launch, no split
                                      (1152, 1152, 1040, 2),     # batched, long K: split-K with the atomic epilogue
-                                     (2048, 1024, 48, 1)])      # three 16-wide k blocks only (the unpipelined remainder path)
+                                     (2048, 1024, 48, 1)])      # three 16-wide k blocks only: one pipelined trip, both look-ahead requests clamped (13 blocks above: remainder 1)
 def test_gemm_float64_lds_dma_kernel(ta, tb, M, N, K, S):
     """gemm_f64_dma_kernel (128-aligned float64 shapes with more than 64 tiles; all four operand layouts, B broadcast over the batch,
     alpha / beta, split-K) against numpy."""
