@@ -102,6 +102,26 @@ def test_potrf_tiles_scratch_rings_wrap_and_streams_do_not_collide():
         assert np.allclose(lb[0].cpu().numpy(), refB, rtol=1e-11, atol=1e-11)
 
 
+def test_potrf_outer_panel_split_launch_batched():
+    """The two-launch form of an outer panel (chain rows, then the rows below without hand-offs) only engages with >= 64 block rows below
+    a panel (n >= 4608); MXF_POTRF_SPLIT_ROWS=2 (read once per process, hence the subprocess) forces it at n = 1536 with a batch of 2."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mxfusion_amd import ops\n"
+        "rng = np.random.RandomState(3)\n"
+        "A = rng.randn(2, 1536, 1536); A = A @ np.swapaxes(A, 1, 2) / 1536 + np.eye(1536)[None]\n"
+        "L, info = ops.potrf_(torch.as_tensor(A).cuda())\n"
+        "assert int(info.abs().sum()) == 0\n"
+        "assert np.allclose(L.cpu().numpy(), np.linalg.cholesky(A), rtol=1e-11, atol=1e-11)\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MXF_POTRF_SPLIT_ROWS='2'), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
 def test_potrf_not_positive_definite_reports_info():
     from mxfusion_amd import ops, _lib
     A = np.eye(70)[None].repeat(2, 0)
