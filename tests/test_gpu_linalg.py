@@ -67,6 +67,20 @@ def test_potrf_tiles_not_positive_definite_reports_info():
     assert int(info2[0]) == 0 and np.allclose(L2[0].cpu().numpy(), np.linalg.cholesky(A[0]), rtol=1e-11, atol=1e-11)
 
 
+def test_potrf_panel_form_not_positive_definite_reports_info():
+    """the same in the panel form (n = 1024: two outer panels, trailing update in between): a negative pivot in the SECOND panel of batch item 1."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(6)
+    A = _spd(rng, 2, 1024)
+    A[1, 700, 700] = -5.0
+    L, info = ops.potrf_(_dev(A, torch.float64))
+    info = info.cpu().numpy()
+    assert info[0] == 0 and info[1] == 701, info
+    assert np.allclose(L[0].cpu().numpy(), np.linalg.cholesky(A[0]), rtol=1e-11, atol=1e-11)
+    # the leading 700 x 700 block of the failing item is still its Cholesky factor
+    assert np.allclose(L[1, :700, :700].cpu().numpy(), np.linalg.cholesky(A[1, :700, :700]), rtol=1e-11, atol=1e-11)
+
+
 def test_potrf_tiles_scratch_rings_wrap_and_streams_do_not_collide():
     """The tile kernel hands tiles on through two per-handle rings (progress counters, inverse blocks of the diagonal factors): 400
     back-to-back factorisations wrap both; two streams factoring at the same time (as the SVGP step does with Kuu and Su) use disjoint
