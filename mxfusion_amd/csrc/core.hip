@@ -42,7 +42,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
 
 extern "C" const char* mxf_last_error(mxf_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)(h->ws_bytes + h->gram_ws_bytes) : -1; }
+extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)(h->ws_bytes + h->gram_ws_bytes + h->bwd_acc_bytes + h->pinv_elems * sizeof(double)) : -1; }
 
 extern "C" int64_t mxf_workspace_generation(mxf_handle h) { return h ? h->ws_generation : -1; }
 
