@@ -114,6 +114,54 @@ def build_minibatch(N, Q, M, B, S_local, dtype, Z, prior_var=1e-2):
     return m, infr, loop
 
 
+_RANK_TIMES = {}      # filled by _finish_timing: this rank's own time of the timed region, gathered over the ranks
+
+
+def _finish_timing(t0, distributed):
+    """Closing bracket of the timed region: synchronize, barrier, MAX over the ranks.  Also records every rank's own time up to its
+    synchronize (before the barrier) in _RANK_TIMES['per_rank_s'] -- the spread shows load imbalance, max - own the wait in the barrier."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        own = [torch.zeros(1, dtype=torch.float64, device='cuda') for _ in range(dist.get_world_size())]
+        dist.all_gather(own, torch.tensor([t_own], dtype=torch.float64, device='cuda'))
+        _RANK_TIMES['per_rank_s'] = [float(x) for x in own]
+    else:
+        _RANK_TIMES['per_rank_s'] = [t_own]
+    return (dt,)
+
+
+def dist_report(world, steps, grad_elems, dtype):
+    """What a reader needs to check an N-GPU line without the builder in the loop: the rank count the communicator itself reports, every
+    rank's own ms per step, and the cost of the step's one collective (all-reduce of a flat gradient of this model's size) measured on its
+    own with HIP events -- 20 back-to-back all-reduces on RCCL's stream order, mean per call."""
+    import torch.distributed as dist
+    rep = {"rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+           "per_rank_ms_per_step": [round(t / steps * 1e3, 4) for t in _RANK_TIMES.get('per_rank_s', [])]}
+    if dist.is_initialized():
+        buf = torch.zeros(int(grad_elems) + 1, dtype=dtype, device='cuda')
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        rep["allreduce_ms"] = e0.elapsed_time(e1) / 20
+        rep["allreduce_bytes"] = buf.numel() * buf.element_size()
+    return rep
+
+
 def time_minibatch_steps(infr, loop, Xd, Yd, B, steps, warmup, lr, distributed):
     """One step = one minibatch: slice B rows of a fixed shuffle (the same on every rank), forward + reverse mode on this rank's MC samples,
     gradient all-reduce, Trainer.step(batch_size=B)."""
@@ -138,15 +186,7 @@ def time_minibatch_steps(infr, loop, Xd, Yd, B, steps, warmup, lr, distributed):
     t0 = time.perf_counter()
     for i in range(steps):
         loss = one(warmup + i)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    return dt, float(loss.detach())
+    return _finish_timing(t0, distributed) + (float(loss.detach()),)
 
 
 def build_deepgp(N, Q, M, Dh, S_local, dtype, X, Y, distributed):
@@ -350,15 +390,7 @@ def time_steps_multi(infr, loop, data, steps, warmup, lr, distributed):
     for _ in range(steps):
         loss = loop.step(executor, data, infr.params)
         trainer.step(batch_size=1)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    return dt, float(loss.detach())
+    return _finish_timing(t0, distributed) + (float(loss.detach()),)
 
 
 def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
@@ -377,15 +409,7 @@ def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     for _ in range(steps):
         loss = loop.step(executor, [Yd], infr.params)
         trainer.step(batch_size=1)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    return dt, float(loss.detach())
+    return _finish_timing(t0, distributed) + (float(loss.detach()),)
 
 
 def gram_roofline(N, Q, dtype, reps=40):
@@ -566,8 +590,28 @@ def main():
         with os.fdopen(os.dup(_json_fd), 'w') as f:
             f.write(json.dumps(obj) + '\n')
 
+    # --gpus N without a launcher around us: start the N ranks ourselves (one process per GPU through torch.distributed.run, exactly the
+    # command line the driver uses) and let rank 0's JSON line through; never a silent one-rank run that reports n_gpus = 1.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible to this process' % (args.gpus, ndev))
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.dup2(_json_fd, 1)                       # the children inherit the real stdout (rank 0 writes the one JSON line to it)
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world != max(1, args.gpus) and not args.force_dist:
+        raise SystemExit('bench.py: launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    if torch.cuda.device_count() < min(world, 1 + int(os.environ.get('LOCAL_RANK', '0'))):
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1 or args.force_dist      # --force-dist: run the RCCL code path (init, broadcast, all-reduce, barriers) even with one rank
     torch.cuda.set_device(local_rank)
@@ -618,14 +662,15 @@ def main():
         td = torch.float32 if args.dtype == 'float32' else torch.float64
         data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]
         dt, last_loss = time_steps_multi(infr, loop, data, args.steps, args.warmup, args.lr, distributed)
+        rep = dist_report(world, args.steps, infr.params.flat.numel(), td)          # collective: every rank
         if rank == 0:
-            emit(({
+            emit(dict({
                 "metric": "ELBO-steps/sec, 2-layer SVGP deep GP (BASELINE.json configs[4])", "value": args.steps / dt, "unit": "ELBO-steps/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
                 "config": {"workload": "deep GP: SVGPRegression(Matern52+RBF, Q=%d) -> H (N x %d, mean-field q(H)) -> SVGPRegression(RBF-ARD), N=%d, "
                                        "M=%d per layer, %d MC samples" % (Q, Dh, N, M, args.samples), "samples_per_gpu": S_local},
-                "last_loss": last_loss}))
+                "last_loss": last_loss}, **rep))
         if distributed:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -638,8 +683,9 @@ def main():
         m, infr, loop = build_minibatch(N, Q, M, B, S_local, args.dtype, Z)
         dt, last_loss = time_minibatch_steps(infr, loop, torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda(), B, args.steps,
                                              args.warmup, args.lr, distributed)
+        rep = dist_report(world, args.steps, infr.params.flat.numel(), td)          # collective: every rank
         if rank == 0:
-            emit({"metric": "ELBO-steps/sec (minibatch steps), SVGP N=65k D=8 M=1024 minibatch=%d (BASELINE.json configs[3])" % B,
+            emit(dict({"metric": "ELBO-steps/sec (minibatch steps), SVGP N=65k D=8 M=1024 minibatch=%d (BASELINE.json configs[3])" % B,
                   "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                   "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
@@ -647,7 +693,7 @@ def main():
                                          "(rv_scaling %g), %d MC samples, step = minibatch ELBO + reverse mode + grad all-reduce + Adam"
                                          % (N, Q, M, B, N / B, args.samples),
                              "samples_per_gpu": S_local, "parallelism": "mc-samples sharded x%d, 1 RCCL all-reduce of the flat gradient/step" % world},
-                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())})
+                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())}, **rep))
         if distributed:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -656,6 +702,7 @@ def main():
     td = torch.float32 if args.dtype == 'float32' else torch.float64
     Yd = torch.as_tensor(Y, dtype=td).cuda()
     dt, last_loss = time_steps(infr, loop, Yd, args.steps, args.warmup, args.lr, distributed)
+    rep = dist_report(world, args.steps, infr.params.flat.numel(), td)              # collective: every rank
 
     out = {
         "metric": "ELBO-steps/sec + RBF Gram GB/s, SVGP N=65k D=8 M=1024, 1->8 MI355X",
@@ -670,6 +717,7 @@ def main():
         # LAPACK-style info of the last step's Cholesky factorisations (0 = every pivot positive)
         "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum()),
     }
+    out.update(rep)
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q
         torch.cuda.empty_cache()

@@ -21,9 +21,12 @@ def vregs(text):
     return out
 
 
-def check(path):
-    lines = open(path).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if KERNEL in l and l.rstrip().endswith(':') or (KERNEL in l and ':' in l and not l.startswith('\t')))
+def kernel_starts(lines):
+    """line indices of the entry labels of every instantiation of the kernel template"""
+    return [i for i, l in enumerate(lines) if KERNEL in l and not l.startswith(('\t', ' ', '.')) and l.split(';')[0].rstrip().endswith(':')]
+
+
+def check(lines, start):
     errors, pending, n_loads, n_waits = [], [], 0, 0
     for ln in lines[start + 1:]:
         s = ln.strip()
@@ -67,8 +70,15 @@ def check(path):
 
 
 if __name__ == '__main__':
-    errs, nl, nw = check(sys.argv[1])
-    print('%s: %d register loads, %d vmcnt waits, %d violations' % (KERNEL, nl, nw, len(errs)))
-    for e in errs[:20]:
-        print('  ', e)
-    sys.exit(1 if errs else 0)
+    lines = open(sys.argv[1]).read().splitlines()
+    starts = kernel_starts(lines)
+    bad = not starts
+    if not starts:
+        print('%s: no instantiation found in %s' % (KERNEL, sys.argv[1]))
+    for st in starts:
+        errs, nl, nw = check(lines, st)
+        print('%s: %d register loads, %d vmcnt waits, %d violations' % (lines[st].split(':')[0], nl, nw, len(errs)))
+        for e in errs[:20]:
+            print('  ', e)
+        bad = bad or bool(errs) or nl == 0
+    sys.exit(1 if bad else 0)

@@ -767,11 +767,11 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
-    static const int tiles_env = getenv("MXF_POTRF_TILES") ? atoi(getenv("MXF_POTRF_TILES")) : 1;
+    static const int tiles_env = MXF_KNOB("MXF_POTRF_TILES", 1);
     // tiles_env: 0 = launch-per-panel form everywhere, 1 = the tile kernel (one launch up to MXF_POTRF_ONE_MAX = 512, per outer panel beyond), 2 = only its one-launch form
     const bool tiles_ok = sizeof(T) == 8 && tiles_env && n % NB == 0 && n >= 2 * NB && S <= 64;
     if constexpr (sizeof(T) == 8) {
-        static const int one_max = getenv("MXF_POTRF_ONE_MAX") ? atoi(getenv("MXF_POTRF_ONE_MAX")) : 512;
+        static const int one_max = MXF_KNOB("MXF_POTRF_ONE_MAX", 512);
         if (tiles_ok && n <= one_max) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
             const unsigned nbk = (unsigned)(n / NB);
             int* progress = mxf_flags(h, (nbk + 1) * (unsigned)S);
@@ -785,7 +785,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         }
     }
     const bool panel_tiles = tiles_ok && tiles_env == 1 && n / NB <= 256;      // every block row's workgroup must be resident at once
-    static const int look_env = getenv("MXF_POTRF_LOOKAHEAD") ? atoi(getenv("MXF_POTRF_LOOKAHEAD")) : 2;
+    static const int look_env = MXF_KNOB("MXF_POTRF_LOOKAHEAD", 2);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
@@ -800,7 +800,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 // rows below against the finished diagonal block, nothing to wait for (~90 us of MFMA work each).  In one launch those rows
                 // sit resident and mostly idle for the whole chain, one CU each, and the look-ahead GEMM next to them (whose 133 KB of LDS
                 // cannot share a CU with a tile workgroup) runs on what is left.
-                static const int split_rows = getenv("MXF_POTRF_SPLIT_ROWS") ? atoi(getenv("MXF_POTRF_SPLIT_ROWS")) : 64;
+                static const int split_rows = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
                 const bool split = split_rows > 0 && nbr - npt >= (unsigned)split_rows;
                 const unsigned na = split ? npt : nbr;
                 int* progress = mxf_flags(h, (na + 1) * (unsigned)S);

@@ -25,11 +25,9 @@ struct RcclApi {
     bool ok = false;
 };
 
-RcclApi* rccl() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+// resolved once; a function-local static initialised by a lambda is published only when fully populated (thread-safe by the language rules)
+RcclApi load_rccl() {
+    RcclApi api;
     void* src = RTLD_DEFAULT;                       // an RCCL the process already holds (e.g. the caller's framework)
     if (!dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
         const char* env = getenv("MXF_RCCL_LIB");
@@ -39,7 +37,7 @@ RcclApi* rccl() {
             api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (api.lib) break;
         }
-        if (!api.lib) return &api;
+        if (!api.lib) return api;
         src = api.lib;
     }
 #define SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(src, name))
@@ -51,6 +49,11 @@ RcclApi* rccl() {
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast && api.GetErrorString;
+    return api;
+}
+
+RcclApi* rccl() {
+    static RcclApi api = load_rccl();
     return &api;
 }
 

@@ -5,7 +5,19 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <stdlib.h>
 #include "../../include/mxf_gp.h"
+
+// Tuning knobs.  The shipped library is built WITHOUT -DMXF_PROBES: every knob is the compile-time default (the measured best) and the
+// library reads no MXF_* environment variable except MXF_RCCL_LIB (a path).  The probe build (make probe -> libmxf_gp_probe.so, selected
+// with MXF_GP_LIB by tests/probes/*) reads them from the environment once per process, for A/B measurements.
+#ifdef MXF_PROBES
+#define MXF_KNOB(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#define MXF_KNOB_SET(name) (getenv(name) != nullptr)
+#else
+#define MXF_KNOB(name, dflt) ((long long)(dflt))
+#define MXF_KNOB_SET(name) (false)
+#endif
 
 struct mxf_ctx {
     int device = 0;
@@ -29,7 +41,23 @@ struct mxf_ctx {
     size_t pinv_elems = 0, pinv_cursor = 0;
     int* flags = nullptr;      // zero-initialised arrival counters for in-kernel workgroup hand-offs (potrf panel); each use leaves 0 behind
     unsigned flag_cursor = 0;
+    unsigned* gsync = nullptr; // zero-initialised rendezvous counters of the wide split GEMMs (pacing hints only; gemm_split.hip); each use leaves 0 behind
+    unsigned gsync_cursor = 0;
 };
+constexpr unsigned MXF_NGSYNC = 1u << 18;
+// a fresh run of `count` zeroed rendezvous counters (rotating: a run is reused only after 2^18 / count later launches have been queued --
+// by then the launch that used it has long left them at zero); nullptr = none available (the caller then launches without rendezvous)
+static inline unsigned* mxf_gsync(mxf_ctx* h, unsigned count) {
+    if (count == 0 || count > MXF_NGSYNC / 4) return nullptr;
+    if (!h->gsync) {
+        if (hipMalloc((void**)&h->gsync, MXF_NGSYNC * sizeof(unsigned)) != hipSuccess) { h->gsync = nullptr; return nullptr; }
+        if (hipMemset(h->gsync, 0, MXF_NGSYNC * sizeof(unsigned)) != hipSuccess) return nullptr;
+    }
+    if (h->gsync_cursor + count > MXF_NGSYNC) h->gsync_cursor = 0;
+    unsigned* p = h->gsync + h->gsync_cursor;
+    h->gsync_cursor += count;
+    return p;
+}
 constexpr unsigned MXF_NFLAGS = 1u << 18;
 // a fresh run of `count` zeroed counters (rotating; a slot is reused only after 2^18 / count later launches have been queued)
 static inline int* mxf_flags(mxf_ctx* h, unsigned count) {

@@ -560,10 +560,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB, sizeof(T));
     // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
-    static const int split_env = getenv("MXF_SVGP_SPLIT") ? atoi(getenv("MXF_SVGP_SPLIT")) : 1;
+    static const int split_env = MXF_KNOB("MXF_SVGP_SPLIT", 1);
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
     // operand format of the split GEMMs: two scaled f16 terms / three products (default) or three bf16 terms / six products
-    static const int split_mode = (getenv("MXF_SPLIT_MODE") && !strcmp(getenv("MXF_SPLIT_MODE"), "bf16x3")) ? MXF_SPLIT_BF16X3 : MXF_SPLIT_F16X2;
+    static const int split_mode = MXF_KNOB("MXF_SPLIT_BF16X3", 0) ? MXF_SPLIT_BF16X3 : MXF_SPLIT_F16X2;
     const float split_ga = split_mode == MXF_SPLIT_F16X2 ? (1.f / 16384.f) : 1.f;     // Gram planes hold k / variance * 2^14 in the f16x2 format
     const float* split_var = split_mode == MXF_SPLIT_F16X2 ? (const float*)var : nullptr;
     const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
@@ -603,10 +603,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
     int rc;
-    static const int64_t psi2_ka = getenv("MXF_SVGP_PSI2_KA") ? atoll(getenv("MXF_SVGP_PSI2_KA")) : -1;
-    static const bool psi2_ra_env = getenv("MXF_SVGP_PSI2_RA") != nullptr;
-    static const int psi2_ra = psi2_ra_env ? atoi(getenv("MXF_SVGP_PSI2_RA")) : 148;
-    static const int psi2_rb = getenv("MXF_SVGP_PSI2_RB") ? atoi(getenv("MXF_SVGP_PSI2_RB")) : 16;
+    static const int64_t psi2_ka = MXF_KNOB("MXF_SVGP_PSI2_KA", -1);
+    static const bool psi2_ra_env = MXF_KNOB_SET("MXF_SVGP_PSI2_RA");
+    static const int psi2_ra = (int)MXF_KNOB("MXF_SVGP_PSI2_RA", 148);
+    static const int psi2_rb = MXF_KNOB("MXF_SVGP_PSI2_RB", 16);
     // ---- core, float64, once; two independent chains run concurrently (main: Kuu -> L -> Ki, w; side: Kuf_all, Su -> Ls -> Su^-1) ----
     if (!mxf_side_init(h)) MXF_FAIL(h, -5, "mxf_svgp_logpdf: cannot create the internal side stream");
     hipStream_t sd_ = h->side;

@@ -22,6 +22,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->gram_ws) (void)hipFree(h->gram_ws);
     if (h->flags) (void)hipFree(h->flags);
+    if (h->gsync) (void)hipFree(h->gsync);
     if (h->pinv) (void)hipFree(h->pinv);
     if (h->cond_dev) (void)hipFree(h->cond_dev);
     if (h->bwd_acc) (void)hipFree(h->bwd_acc);
@@ -51,7 +52,9 @@ extern "C" int mxf_svgp_last_cond(mxf_handle h, double* cond1_out) {
     *cond1_out = 0.0;
     if (!h->cond_dev) return 0;                      // no SVGP training call on this handle yet
     double v[2];
-    MXF_HIP(h, hipMemcpy(v, h->cond_dev, sizeof(v), hipMemcpyDeviceToHost));      // synchronises with the stream work that produced it
+    // the norms are written by kernels on the caller's (possibly non-blocking) stream: a plain hipMemcpy orders against the null stream only
+    MXF_HIP(h, hipDeviceSynchronize());
+    MXF_HIP(h, hipMemcpy(v, h->cond_dev, sizeof(v), hipMemcpyDeviceToHost));
     *cond1_out = v[0] * v[1];
     return 0;
 }

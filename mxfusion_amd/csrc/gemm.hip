@@ -586,7 +586,7 @@ bool gemm_small_launch(mxf_ctx*, GemmArgs<T>&, int, int, int64_t, int64_t, int64
 template <>
 bool gemm_small_launch<double>(mxf_ctx* h, GemmArgs<double>& g, int ta, int tb, int64_t M, int64_t N, int64_t K, double beta, int batch, int lower_only,
                                hipStream_t st, int& rc) {
-    static const int small_env = getenv("MXF_GEMM_SMALL") ? atoi(getenv("MXF_GEMM_SMALL")) : 1;
+    static const int small_env = MXF_KNOB("MXF_GEMM_SMALL", 1);
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     if (!small_env || t128 > 64 || M > 65535) return false;       // the big kernel fills at least a quarter of the chip: keep it
     const int64_t tm = (M + SBM_ - 1) / SBM_, tn = (N + SBM_ - 1) / SBM_;
@@ -654,7 +654,7 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
         splitk = (int)sk;
     }
     {   // probe knob (A/B experiments only)
-        static const int sk_env = getenv("MXF_GEMM_SPLITK") ? atoi(getenv("MXF_GEMM_SPLITK")) : 0;
+        static const int sk_env = MXF_KNOB("MXF_GEMM_SPLITK", 0);
         if (sk_env > 0 && K >= 4096) splitk = sk_env;
     }
     int64_t kchunk = BK;
@@ -671,9 +671,9 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     g.ntiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     g.nwg = g.ntiles * batch * splitk;
     g.xc_max = 0;
-    static const int rev_env = getenv("MXF_GEMM_REV_M") ? atoi(getenv("MXF_GEMM_REV_M")) : 1;
+    static const int rev_env = MXF_KNOB("MXF_GEMM_REV_M", 1);
     g.rev_m = rev_env;
-    static const int tri_balance = getenv("MXF_GEMM_TRI_BALANCE") ? atoi(getenv("MXF_GEMM_TRI_BALANCE")) : 1;
+    static const int tri_balance = MXF_KNOB("MXF_GEMM_TRI_BALANCE", 1);
     if (tri_balance && lower_only && g.k_from_m == 1 && splitk == 1 && tm >= 16) {
         for (int64_t x = 0; x < 8; ++x) {
             int64_t cnt = 0;
@@ -690,7 +690,7 @@ int gemm_typed(mxf_ctx* h, int ta, int tb, int64_t M, int64_t N, int64_t K, doub
     }
     dim3 grid((unsigned)g.nwg, 1, 1);
     if constexpr (sizeof(T) == 8) {
-        static const int dma_env = getenv("MXF_GEMM_F64_DMA") ? atoi(getenv("MXF_GEMM_F64_DMA")) : 1;
+        static const int dma_env = MXF_KNOB("MXF_GEMM_F64_DMA", 1);
         if (dma_env && g.vecA && g.vecB && M % BM == 0 && N % BN == 0 && K % DBK == 0 && kchunk % DBK == 0 && NWAVE == 8) {
             if (!ta && tb) hipLaunchKernelGGL((gemm_f64_dma_kernel<false, false>), grid, dim3(512), 0, st, g);
             else if (ta && !tb) hipLaunchKernelGGL((gemm_f64_dma_kernel<true, true>), grid, dim3(512), 0, st, g);
@@ -726,7 +726,7 @@ extern "C" int mxf_gemm(mxf_handle h, int dtype, int transA, int transB, int64_t
     if (!h) return -1;
     if (M < 0 || N < 0 || K < 0 || batch < 0) MXF_FAIL(h, -2, "mxf_gemm: negative dimension");
     if ((M > 0 && N > 0 && batch > 0) && (!A || !B || !C) && K > 0) MXF_FAIL(h, -2, "mxf_gemm: null operand");
-    static const int lower_env = getenv("MXF_GEMM_LOWER") ? atoi(getenv("MXF_GEMM_LOWER")) : 0;   // probe knob
+    static const int lower_env = MXF_KNOB("MXF_GEMM_LOWER", 0);   // probe knob
     return mxf_gemm_internal(h, dtype, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc,
                              strideC, batch, (lower_env && M == N) ? 1 : 0, (hipStream_t)stream);
 }

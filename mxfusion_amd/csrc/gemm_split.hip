@@ -135,6 +135,9 @@ struct SplitArgs {
     const float* ad0; int pow0;          // alpha *= ad0[0]^pow0 (device scalar, e.g. the kernel variance of Gram planes)
     const unsigned* maxbits;             // alpha /= scale_from_maxbits(maxbits[0]) (the power-of-two scale of an f16x2 operand)
     const unsigned* maxbits2;            // the same for the other operand
+    // rendezvous of the workgroups that share operand lines (wide kernels; see wg_rendezvous): counters (nullptr = none), workgroups per
+    // group, loop trips between two rendezvous (0 = one per work item, at its start: group = sync_n consecutive work items), counters per k split
+    unsigned* sync; int sync_n, sync_period, sync_slots;
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
@@ -314,19 +317,49 @@ __global__ __launch_bounds__(SNT, (NP == 2 && !DMA) ? 4 : 3) void gemm_split_ker
             }
 }
 
-// ------------------------------------------------------------------------------------------------ the 128 x 256 kernel (f16x2 operands)
+// ------------------------------------------------------------------------------------------------ the (32 XT) x 256 kernels (f16x2 operands)
 // The 128 x 128 kernel above moves every operand through LDS: per 16-wide k block and workgroup 16 KB of LDS-DMA writes and 32 KB of
 // fragment reads for 48 MFMAs, and the LDS (not the matrix pipe: 58 % busy) is what it runs out of.  This kernel cuts the LDS traffic per
 // MFMA to a quarter:
-//   * block tile 128 (A rows) x 256 (B rows), four waves side by side along B: wave w owns ALL 128 rows x columns [64 w, 64 w + 64)
-//     = 4 x 2 MFMA tiles, 24 v_mfma_f32_32x32x16_f16 per k block (128 accumulator VGPRs);
-//   * A (shared by the four waves) goes through LDS as before: 8 KB of LDS-DMA per k block, a three-slot ring, 8 ds_read_b128 per wave;
+//   * block tile (32 XT) (A rows) x 256 (B rows), four waves side by side along B: wave w owns ALL A rows x columns [64 w, 64 w + 64)
+//     = XT x 2 MFMA tiles, 6 XT v_mfma_f32_32x32x16_f16 per k block.  XT = 4: 128 rows, 128 accumulator registers, two workgroups per CU;
+//     XT = 8: 256 rows, 256 accumulators (the whole AGPR half of the register file), one workgroup per CU -- per MFMA it moves 2/3 of
+//     the bytes the 128-row tile moves from L2 (A 16 KB + B 16 KB per 192 MFMAs instead of 8 + 16 per 96);
+//   * A (shared by the four waves) goes through LDS: LDS-DMA, a three-slot ring, 2 XT ds_read_b128 per wave and k block;
 //   * B is private to a wave, so it never touches LDS: each lane fetches its 16-byte fragment units straight from global memory
 //     (the plane layout makes a wave's 32 rows x 16 k one contiguous 1 KB run) two k blocks ahead into a three-deep register ring.
 // One barrier per k block.  Inline-asm loads + hand-counted s_waitcnt vmcnt: the compiler's own waits would drain the LDS-DMA queue at the
 // first use of an ordinary load (cdna_hip_programming.md section 5, "mixing load kinds").  The MFMA operands are swapped (D = B A^T), which
 // leaves every lane with four CONSECUTIVE output columns per accumulator quad: the epilogue is 16-byte stores.
-constexpr int WBM = 128, WBN = 256;
+//
+// L2 locality by rendezvous (r03).  The workgroups that share operand lines -- the row tiles of one column strip of T (same B strip, and
+// with the whole XCD in step also the same A k-window), the tiles of one k split of Psi2 -- are dealt to ONE XCD, but nothing kept them in
+// step: each walks its own k loop, they drift apart by more than the 4 MB L2 holds, and every operand line was fetched ~3 times from the
+// fabric (r02 PMC: 26.2 GB for 8.6 GB of planes).  wg_rendezvous() is a BOUNDED spin on one counter per group (at the start of a work item
+// for T, every `sync_period` loop trips for the long-K products): a pacing hint, never needed for correctness -- a workgroup that waited
+// SYNC_LIMIT for its partners goes on alone and stops waiting after its second time-out, so a launch next to kernels that hold some CUs,
+// or two such launches on different streams, cannot deadlock.  Every workgroup adds exactly 2 to its group's counter (arrive + depart,
+// or both at once when it no longer waits); the add that completes 2 n resets the word, so the counters are zero between launches.
+constexpr int WBN = 256;
+constexpr unsigned long long SYNC_LIMIT = 2000ull;       // wall_clock64 ticks (100 MHz): 20 us
+
+__device__ __forceinline__ void wg_rendezvous(unsigned* ctr, unsigned n, int& patience) {
+    if (threadIdx.x == 0) {
+        if (patience > 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+                if (wall_clock64() - t0 > SYNC_LIMIT) { --patience; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == 2u * n)
+                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (__hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2u == 2u * n) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __builtin_amdgcn_s_barrier();        // bare: requests in flight (LDS-DMA, the previous item's stores) stay in flight
+}
 
 __device__ __forceinline__ u32x4 gload16(unsigned voff, const void* sbase) {
     u32x4 r;
@@ -339,9 +372,26 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
     return r;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
-    __shared__ u32x4 smem[3][2][256];              // [ring slot][plane][16-byte unit]: 3 x 8 KB (A only)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// NH = 2: 512-thread workgroups, two row halves of four waves each (wave = 4 h + w owns rows [32 XT h, +32 XT) x columns [64 w, +64)):
+// the 256-row tile with TWO waves per SIMD -- a wave's loads, LDS reads and waits run under its partner's MFMAs, which a single
+// 512-register wave per SIMD cannot do (r03: the XT = 8, NH = 1 form halves the fabric fetch and clocks 1.83 instead of 1.56 GHz, but its
+// matrix pipe idles through every ds_read / VMEM issue: same wall time).  The two halves share the A slab in LDS; both fetch the B
+// fragments of their column quarter (identical addresses, a few hundred cycles apart: the second is an L1 / L2 hit, no fabric traffic).
+//
+// PP ("ping-pong", NH = 2 only): the two row halves run half a k step apart.  A k step is split into a LOAD phase (request block k + 2,
+// read the A fragments of block k from LDS, wait for block k + 1) and a COMPUTE phase (24 MFMAs), with a workgroup barrier after each; the
+// second half starts one phase late, so on every SIMD one wave computes while its partner loads.  Without it both waves of a SIMD reach the
+// shared barrier together, want the matrix pipe together and then wait for LDS / memory together.
+template <int XT, int NH, bool PP>
+__global__ __launch_bounds__(256 * NH, (XT == 8 && NH == 1) ? 1 : 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
+    static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
+    constexpr int WBMt = 32 * XT * NH;             // A rows per tile
+    constexpr int NU = 64 * XT * NH;               // 16-byte units of one plane's (WBMt x 16) slab
+    constexpr int ND = XT / 4;                     // LDS-DMA requests per thread, plane and k block
+    constexpr int NTH = 256 * NH;
+    __shared__ u32x4 smem[3][2][NU];               // [ring slot][plane][16-byte unit]: 3 x 8 KB (128 rows) / 3 x 16 KB (256 rows), A only
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
+    int patience = 2;
     // Persistent over the (tile, k split) work items: workgroup b takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so its items
     // stay on its XCD's run of tiles).  The epilogue's stores of one item drain while the next item's first loads are in flight; with one
     // item per workgroup every tile paid a dispatch + an un-overlapped pipeline fill + a store burst (~30 % of a K = 1024 tile).
@@ -354,38 +404,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
     const int64_t split = wid / g.ntiles;
     int64_t t = wid % g.ntiles;
     int64_t tile_m, tile_n;
-    if (g.lower_only) {             // tiles (tm, tn) with 256 tn <= 128 tm + 127, i.e. tn <= tm / 2: row tm holds tm / 2 + 1 tiles
+    if (g.lower_only) {             // tiles (tm, tn) with 256 tn <= WBMt tm + WBMt - 1: row tm holds (WBMt tm + WBMt - 1) / 256 + 1 tiles
         int64_t row = 0;
-        while (t >= row / 2 + 1) { t -= row / 2 + 1; ++row; }
+        while (t >= (WBMt * row + WBMt - 1) / WBN + 1) { t -= (WBMt * row + WBMt - 1) / WBN + 1; ++row; }
         tile_m = row; tile_n = t;
     } else {
         tile_m = t % g.tm; tile_n = t / g.tm;       // the row tiles of one column tile are neighbours: they share the B columns in L2
     }
-    const int64_t m0 = tile_m * WBM, n0 = tile_n * WBN;
+    const int64_t m0 = tile_m * WBMt, n0 = tile_n * WBN;
     const int64_t kbeg = split * g.kchunk;
     const int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
+    if (g.sync && g.sync_period == 0) wg_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
 
-    f32x16 c[4][2];
+    f32x16 c[XT][2];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < XT; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;
 
-    // A: LDS-DMA, thread t fills 16-byte unit t of each plane's (128 x 16) slab; the XOR swizzle of the two k halves is applied to the source
+    // A: LDS-DMA, thread t fills 16-byte units t (+ NTH u) of each plane's slab; the XOR swizzle of the two k halves is applied to the
+    // source (unit U <-> row U >> 1; NTH more units = NTH / 2 more rows leave the swizzle bit (row >> 3) & 1 as it is)
     const int drow = tid >> 1, dkh = (tid & 1) ^ ((drow >> 3) & 1);
     const unsigned short* da = g.A + (m0 + drow) * 16 + dkh * 8;
     // B: lane <-> (row = lane & 31, k half = lane >> 5) of the wave's two 32-row fragments; per-lane byte offset inside the k block's slab
-    const unsigned bvoff = (unsigned)(((64 * wave + (lane & 31)) * 16 + (lane >> 5) * 8) * 2);
+    const unsigned bvoff = (unsigned)(((64 * wq + (lane & 31)) * 16 + (lane >> 5) * 8) * 2);
     const unsigned short* bbase = g.B + n0 * 16;                     // wave-uniform
     const int li = lane & 31, lk = lane >> 5;
-    int ua[4];
+    int ua[XT];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) ua[x] = lds_unit(32 * x + li, lk);
+    for (int x = 0; x < XT; ++x) ua[x] = lds_unit(32 * XT * wh + 32 * x + li, lk);
 
     u32x4 b0[2][2], b1[2][2], b2[2][2];          // register ring of the B fragments [y][plane]: blocks kb, kb + 1, kb + 2
-    // per k block six requests, in this order: four B fragment loads (registers), two LDS-DMA requests (A slab)
+    // per k block 4 + 2 ND requests, in this order: four B fragment loads (registers), 2 ND LDS-DMA requests (A slab)
 #define W_ISSUE(kb, SLOT, BR)                                                                                                       \
     do {                                                                                                                            \
         const unsigned short* bk_ = bbase + (kb) * g.N * 16;                                                                        \
@@ -393,33 +445,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
         BR[1][0] = gload16_o1024(bvoff, bk_);                                                                                       \
         BR[0][1] = gload16(bvoff, bk_ + g.pB);                                                                                      \
         BR[1][1] = gload16_o1024(bvoff, bk_ + g.pB);                                                                                \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + (kb) * g.M * 16),                     \
-                                         (__attribute__((address_space(3))) void*)(&smem[SLOT][0][wave * 64]), 16, 0, 0);           \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + g.pA + (kb) * g.M * 16),              \
-                                         (__attribute__((address_space(3))) void*)(&smem[SLOT][1][wave * 64]), 16, 0, 0);           \
+        _Pragma("unroll") for (int u_ = 0; u_ < ND; ++u_) {                                                                         \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + u_ * (NTH / 2) * 16 + (kb) * g.M * 16), \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][0][wave * 64 + NTH * u_]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + u_ * (NTH / 2) * 16 + g.pA + (kb) * g.M * 16), \
+                                             (__attribute__((address_space(3))) void*)(&smem[SLOT][1][wave * 64 + NTH * u_]), 16, 0, 0); \
+        }                                                                                                                           \
     } while (0)
-    // all but the N requests issued last have landed (this wave's share; the barrier extends it to the workgroup).  The B registers
-    // that are now complete are tied to the wait ("+v"), so that no use of them can be scheduled above it.  The wait always sits in
-    // STRAIGHT-LINE code: inside a branch the compiler may place the register copies of a control-flow merge in front of it, i.e. copy
+    // all but the requests of the block issued last have landed (this wave's share; the barrier extends it to the workgroup).  The B
+    // registers that are now complete are tied to the wait ("+v"), so that no use of them can be scheduled above it.  The wait always sits
+    // in STRAIGHT-LINE code: inside a branch the compiler may place the register copies of a control-flow merge in front of it, i.e. copy
     // registers whose loads are still in flight (seen in an earlier form of this kernel; csrc/check_wide_isa.py guards against it).
-#define W_WAIT(N, BR)                                                                                                               \
+#define W_WAIT_ASM(NSTR, BR) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(BR[0][0]), "+v"(BR[0][1]), "+v"(BR[1][0]), "+v"(BR[1][1])::"memory")
+#define W_WAIT1(BR)                                                                                                                 \
     do {                                                                                                                            \
-        asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(BR[0][0]), "+v"(BR[0][1]), "+v"(BR[1][0]), "+v"(BR[1][1])::"memory");          \
+        if constexpr (XT == 4) W_WAIT_ASM("6", BR); else W_WAIT_ASM("8", BR);                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        asm volatile("" ::: "memory");                                                                                              \
+    } while (0)
+#define W_WAIT0(BR)                                                                                                                 \
+    do {                                                                                                                            \
+        W_WAIT_ASM("0", BR);                                                                                                        \
         __builtin_amdgcn_s_barrier();                                                                                               \
         asm volatile("" ::: "memory");                                                                                              \
     } while (0)
 #define HF(v) __builtin_bit_cast(f16x8, v)
 #define W_COMPUTE(SLOT, BR)                                                                                                         \
     do {                                                                                                                            \
-        u32x4 a_[4][2];                                                                                                             \
-        _Pragma("unroll") for (int x = 0; x < 4; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }          \
-        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+        u32x4 a_[XT][2];                                                                                                            \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }         \
+        W_MFMAS(a_, BR);                                                                                                            \
+    } while (0)
+#define W_MFMAS(a_, BR)                                                                                                             \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][1]), c[x][y], 0, 0, 0);      /* hi' lo */   \
-        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][1]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* lo' hi */   \
-        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                               \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* hi' hi */   \
     } while (0)
@@ -431,7 +496,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
         const int64_t k2_ = (kk) + 2 < kend ? (kk) + 2 : klast;                                                                     \
         W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
         W_COMPUTE(SLOT, BR);                                                                                                        \
-        W_WAIT(6, BRN);                                                                                                             \
+        W_WAIT1(BRN);                                                                                                               \
+    } while (0)
+    // ping-pong form of a step: LOAD phase | barrier | COMPUTE phase | barrier.  Nothing may be scheduled across the barriers (the MFMAs
+    // are not memory operations: only sched_barrier keeps them on their side).  The fragment reads are complete (lgkmcnt(0)) before the
+    // barrier that ends the load phase: the slot they read is rewritten by a partner's request two barriers later.
+#define W_PHASE_END()                                                                                                               \
+    do {                                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    } while (0)
+#define W_STEP_PP(kk, SLOT, BR, SLOT2, BR2, BRN)                                                                                    \
+    do {                                                                                                                            \
+        const int64_t k2_ = (kk) + 2 < kend ? (kk) + 2 : klast;                                                                     \
+        W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
+        u32x4 a_[XT][2];                                                                                                            \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }         \
+        W_WAIT_ASM("6", BRN);                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
+        W_PHASE_END();                                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        W_MFMAS(a_, BR);                                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+        W_PHASE_END();                                                                                                              \
     } while (0)
     if (kbeg < kend) {
         const int64_t klast = kend - 1;
@@ -439,19 +527,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
         // the block count modulo 3 first, unpipelined (request, drain, multiply): the pipelined loop then runs whole trips of three
         for (int i = (int)((kend - kbeg) % 3); i > 0; --i, ++kb) {
             W_ISSUE(kb, 0, b0);
-            W_WAIT(0, b0);
+            W_WAIT0(b0);
             W_COMPUTE(0, b0);
             __builtin_amdgcn_s_barrier();          // slot 0 is rewritten by the next request
         }
         if (kb < kend) {
             W_ISSUE(kb, 0, b0);
             W_ISSUE(kb + 1, 1, b1);
-            W_WAIT(6, b0);
+            W_WAIT1(b0);
+            if constexpr (PP) { if (wh == 1) W_PHASE_END(); }         // the second half runs one phase behind from here on ...
+            int trip = 0, sync_ix = 0;
             for (; kb < kend; kb += 3) {           // three k blocks per trip: ring indices are compile-time constants, one loop exit
+                if constexpr (PP) {
+                    W_STEP_PP(kb, 0, b0, 2, b2, b1);
+                    W_STEP_PP(kb + 1, 1, b1, 0, b0, b2);
+                    W_STEP_PP(kb + 2, 2, b2, 1, b1, b0);
+                } else {
                 W_STEP(kb, 0, b0, 2, b2, b1);
                 W_STEP(kb + 1, 1, b1, 0, b0, b2);
                 W_STEP(kb + 2, 2, b2, 1, b1, b0);
+                }
+                // long-K products: every sync_period trips the tiles of this k split wait for each other (bounded), so that the operand
+                // rows they share are fetched into the XCD's L2 once.  (The branch defines none of the ring registers: no merge copies.)
+                if (g.sync_period > 0 && ++trip == g.sync_period) {
+                    trip = 0;
+                    if (sync_ix < g.sync_slots) wg_rendezvous(g.sync + split * g.sync_slots + sync_ix, (unsigned)g.sync_n, patience);
+                    ++sync_ix;
+                }
             }
+            if constexpr (PP) { if (wh == 0) W_PHASE_END(); }         // ... to here: every wave has passed the same number of barriers
             // the surplus requests of the last two steps target registers / LDS the epilogue does not read, but they must have landed
             // before the registers are reused
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b1[0][0]), "+v"(b1[0][1]),
@@ -459,8 +563,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
         }
     }
 #undef W_STEP
+#undef W_STEP_PP
+#undef W_PHASE_END
+#undef W_MFMAS
 #undef HF
-#undef W_WAIT
+#undef W_WAIT1
+#undef W_WAIT0
+#undef W_WAIT_ASM
 #undef W_ISSUE
     float alpha = g.alpha;
     const float beta = g.beta;
@@ -468,16 +577,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
     if (g.maxbits) alpha /= scale_from_maxbits(g.maxbits[0]);
     if (g.maxbits2) alpha /= scale_from_maxbits(g.maxbits2[0]);
     const bool atomic = g.atomic != 0;
-    // D = B A^T: accumulator register r of tile (x, y) is C[m0 + 32 x + (lane & 31)][n0 + 64 wave + 32 y + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
+    // D = B A^T: accumulator register r of tile (x, y) is C[m0 + 32 XT wh + 32 x + (lane & 31)][n0 + 64 wq + 32 y + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
     typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int64_t row = m0 + 32 * x + li;
+    for (int x = 0; x < XT; ++x) {
+        const int64_t row = m0 + 32 * XT * wh + 32 * x + li;
 #pragma unroll
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int64_t col = n0 + 64 * wave + 32 * y + 8 * q + 4 * lk;
+                const int64_t col = n0 + 64 * wq + 32 * y + 8 * q + 4 * lk;
                 float* p = g.c_blk ? g.C + ((col >> 4) * g.M + row) * 16 + (col & 15) : g.C + row * g.ldc + col;
                 f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
                 if (g.lower_only && col + 3 > row) {             // tile on the diagonal: element-wise
@@ -546,32 +655,39 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
     g.pA = pA; g.pB = pB; g.ldc = ldc;
     g.alpha = (float)alpha; g.beta = (float)beta; g.lower_only = lower_only;
-    static const int nprod = getenv("MXF_SPLIT_NPROD") ? atoi(getenv("MXF_SPLIT_NPROD")) : 6;
+    static const int nprod = (int)MXF_KNOB("MXF_SPLIT_NPROD", 6);      // diagnostic: fewer products
     g.nprod = nprod;
-    static const int use_dma = getenv("MXF_SPLIT_DMA") ? atoi(getenv("MXF_SPLIT_DMA")) : 1;
+    static const int use_dma = (int)MXF_KNOB("MXF_SPLIT_DMA", 1);      // 0: staged loads instead of LDS-DMA (128 x 128 kernel)
     g.use_dma = use_dma;
-    static const int wide_env = getenv("MXF_SPLIT_WIDE") ? atoi(getenv("MXF_SPLIT_WIDE")) : 3;
+    static const int wide_env = (int)MXF_KNOB("MXF_SPLIT_WIDE", 3);
     // MXF_SPLIT_WIDE: 0 = never, 1 = whenever the shape allows, 2 = only the long-K lower-triangle products (Psi2), 3 (default) = those and
     // products written in 16-column blocks (T of the training step).  The kernel's epilogue puts ROWS on lanes: fine for a blocked C
     // (rows are 64 bytes apart) and for the small square Psi2, 16-byte pieces 4 N bytes apart for a wide row-major C -- the T shape then
     // takes 16.7 ms instead of 13.4 on the 128 x 128 kernel, blocked it takes 12.3.  (Before the kernel walked its work items persistently
     // the blocked T lost 1.9 ms on it as well.)
-    const bool wide = wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % WBM) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
+    const bool wide = wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % 128) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
                       (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N);
+    // rows per tile of the wide kernel: 256 when the shape allows, else 128 (four waves, two workgroups per CU).  MXF_SPLIT_XT: 4 = always
+    // 128; 8 = 256 rows by four 512-register waves (one per SIMD); 16 (default) = 256 rows by eight waves, two row halves (two per SIMD)
+    static const int xt_env = (int)MXF_KNOB("MXF_SPLIT_XT", 16);
+    const int XT = (wide && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
+    const int NH = (wide && xt_env == 16 && (M % 256) == 0) ? 2 : 1;
+    const int64_t WBMh = 32 * XT * NH;
     int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
     int64_t tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
     if (wide) {
-        tm = M / WBM; tn = N / WBN;
+        tm = M / WBMh; tn = N / WBN;
         tiles = 0;
-        if (lower_only) { for (int64_t r = 0; r < tm; ++r) tiles += r / 2 + 1; }
+        if (lower_only) { for (int64_t r = 0; r < tm; ++r) tiles += (WBMh * r + WBMh - 1) / WBN + 1; }
         else tiles = tm * tn;
     }
     int splitk = 1;
-    // split-K target: ~one wave of workgroups (3 fit a CU; 3 or 4 per CU measure the same per step, 6 and more are slower; the wide kernel: 2)
-    // (a caller that reserves more than half of the chip wants a FEW workgroups next to other work -- phase A of Psi2, sized for the
-    //  four-per-CU kernel: keep its workgroup count with the two-per-CU wide kernel)
-    const int64_t slots = (int64_t)(256 - reserve_cus) * (wide ? (reserve_cus >= 128 ? 4 : 2) : (mode == MXF_SPLIT_F16X2 ? 4 : 3));
+    // split-K target: ~one wave of workgroups (3 fit a CU; 3 or 4 per CU measure the same per step, 6 and more are slower; the wide kernel: 2,
+    // its 256-row form 1).  A caller that reserves more than half of the chip wants a FEW workgroups next to other work -- phase A of Psi2,
+    // sized for the four-per-CU kernel: ~216 workgroups, one per CU on 216 CUs, whichever kernel runs.
+    const int64_t slots = wide ? (reserve_cus >= 128 ? (int64_t)(256 - reserve_cus) * 4 : (int64_t)(256 - reserve_cus) * (WBMh == 256 ? 1 : 2))
+                               : (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
     if (tiles < slots && g.K16 >= 16) {
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
@@ -586,6 +702,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     if (splitk < 1) splitk = 1;
     g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
     g.tm = tm; g.tn = tn; g.ntiles = tiles; g.nwg = tiles * splitk;
+    g.sync = nullptr; g.sync_n = 1; g.sync_period = 0; g.sync_slots = 0;
     if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm_split: grid too large");
     if (g.atomic && beta != 1.0) {
         if (M > 65535) MXF_FAIL(h, -3, "mxf_gemm_split: split-K path needs M<=65535");
@@ -594,10 +711,39 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     }
     const bool dma = g.use_dma && (M % SBM) == 0 && (N % SBN) == 0;
     if (wide) {
-        // persistent: two workgroups per CU (the kernel's occupancy) walk the work items; fewer items than that: one each
-        static const int64_t wide_grid = getenv("MXF_SPLIT_WIDE_GRID") ? atoll(getenv("MXF_SPLIT_WIDE_GRID")) : 512;
+        // persistent: as many workgroups as fit the chip (the kernel's occupancy) walk the work items; fewer items than that: one each
+        static const int64_t wide_grid_env = MXF_KNOB("MXF_SPLIT_WIDE_GRID", 0);
+        const int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? 256 : 512);
         const int64_t grid = (wide_grid >= 8 && g.nwg > wide_grid) ? wide_grid / 8 * 8 : g.nwg;
-        hipLaunchKernelGGL(gemm_f16x2_wide_kernel, dim3((unsigned)grid), dim3(256), 0, st, g);
+        // rendezvous groups (wg_rendezvous): MXF_SPLIT_SYNC 0 = none; 1 = the row tiles of one column strip (full products) / the tiles of
+        // one k split (split-K products); 2 = full products: all workgroups of an XCD, once per work item
+        static const int sync_env = (int)MXF_KNOB("MXF_SPLIT_SYNC", 1);
+        static const int sync_period_env = (int)MXF_KNOB("MXF_SPLIT_SYNC_PERIOD", 16);
+        if (sync_env && !lower_only && splitk == 1 && g.nwg % 8 == 0 && g.nwg >= 16) {
+            const int64_t q = g.nwg / 8, per_xcd = grid / 8;        // work items / resident workgroups per XCD
+            int64_t n = sync_env == 2 ? per_xcd : tm;
+            // a group = n consecutive work items of one XCD's run, taken in the same persistent round by n different workgroups
+            const bool ok = n >= 2 && q % n == 0 && per_xcd % n == 0 && (g.nwg <= grid || g.nwg % grid == 0);
+            if (ok) {
+                g.sync = mxf_gsync(h, (unsigned)(g.nwg / n));
+                g.sync_n = (int)n; g.sync_period = 0; g.sync_slots = 0;
+            }
+        } else if (sync_env && splitk > 1 && g.nwg <= grid && tiles >= 2 && sync_period_env > 0) {
+            // every tile of a k split is resident at once: they meet every `period` trips of three k blocks
+            const int64_t trips = kchunk / 3;
+            int64_t period = sync_period_env;
+            int64_t slots_per = trips / period;
+            while (slots_per * splitk > (int64_t)(MXF_NGSYNC / 8)) { period *= 2; slots_per = trips / period; }
+            if (slots_per >= 1) {
+                g.sync = mxf_gsync(h, (unsigned)(slots_per * splitk));
+                g.sync_n = (int)tiles; g.sync_period = (int)period; g.sync_slots = (int)slots_per;
+            }
+        }
+        static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 1);        // ping-pong phases of the two row halves (NH = 2)
+        if (NH == 2 && pp_env) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (NH == 2) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, false>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (XT == 8) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<8, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
         MXF_LAUNCH_CHECK(h);
         return 0;
     }

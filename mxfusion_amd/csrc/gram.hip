@@ -394,12 +394,12 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     a.vecst = (a.ldk % VEC == 0) && (a.sK % VEC == 0) && (((uintptr_t)a.K) % 16 == 0);
     // tuning knobs (A/B probes): rows per block, waves per block, store flavour.  Defaults measured on MI355X at N=65536, Q=8
     // (tests/probes/gram_variants.hip, tests/probes/gram_time.py): single-wave workgroups of 16 rows.
-    static const int tr_env = getenv("MXF_GRAM_TR") ? atoi(getenv("MXF_GRAM_TR")) : 0;
-    static const int nw_env = getenv("MXF_GRAM_NW") ? atoi(getenv("MXF_GRAM_NW")) : 0;
-    static const int nt_env = getenv("MXF_GRAM_NT") ? atoi(getenv("MXF_GRAM_NT")) : -1;
+    static const int tr_env = MXF_KNOB("MXF_GRAM_TR", 0);
+    static const int nw_env = MXF_KNOB("MXF_GRAM_NW", 0);
+    static const int nt_env = MXF_KNOB("MXF_GRAM_NT", -1);
     // f32 RBF: 16 rows (6.05 TB/s; 32: 5.75, 64: 5.29, 8: 5.27); the VALU-heavier epilogues (Matern, all float64) prefer 64 (f64 RBF 5.25 vs 5.13)
     // (float64 RBF in the expansion form, gram_lean_kernel XF: 16 rows 5.71 ms = 6.02 TB/s, 32: 5.95, 64: 6.36 ms)
-    static const int xf_tr = getenv("MXF_GRAM_F64_EXPAND") ? atoi(getenv("MXF_GRAM_F64_EXPAND")) : 1;
+    static const int xf_tr = MXF_KNOB("MXF_GRAM_F64_EXPAND", 1);
     a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((KIND == MXF_K_RBF && (sizeof(T) == 4 || xf_tr)) ? 16 : 64);
     a.nt = (nt_env >= 0) ? nt_env : 1;
     const int NW = (nw_env == 1 || nw_env == 4) ? nw_env : 1;
@@ -411,8 +411,8 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
 #define GO(QT)                                                                                                        \
     do {                                                                                                              \
         const bool fast = a.vecst && mode == MXF_WRITE && a.nt && (a.N2 % VEC == 0);                                  \
-        static const int lean_env = getenv("MXF_GRAM_LEAN") ? atoi(getenv("MXF_GRAM_LEAN")) : 1;                     \
-        static const int xf_env = getenv("MXF_GRAM_F64_EXPAND") ? atoi(getenv("MXF_GRAM_F64_EXPAND")) : 1;           \
+        static const int lean_env = MXF_KNOB("MXF_GRAM_LEAN", 1);                     \
+        static const int xf_env = MXF_KNOB("MXF_GRAM_F64_EXPAND", 1);           \
         const bool lean_ok = NW == 1 && fast && lean_env && KIND != MXF_K_BIAS && KIND != MXF_K_WHITE && (a.N + a.tr - 1) / a.tr <= 65535; \
         const bool xf = lean_ok && sizeof(T) == 8 && KIND == MXF_K_RBF && xf_env;                                     \
         T* xnorm = nullptr; T* znorm = nullptr; int64_t sxn = 0, szn = 0;                                             \

@@ -679,7 +679,7 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     constexpr int QA = QT + PT;
     const size_t fixed = (size_t)(TRB * QT + TRB * PT + 16) * sizeof(T) + 16 * sizeof(double) + 64;
     // LDS per block (the row accumulators): 30 KB = five blocks per CU; 80 KB (two blocks, fewer row flushes) measured 1 % slower per step
-    static const int bud_env = getenv("MXF_BWD_LDS_KB") ? atoi(getenv("MXF_BWD_LDS_KB")) : 30;
+    static const int bud_env = MXF_KNOB("MXF_BWD_LDS_KB", 30);
     const size_t budget = (size_t)bud_env * 1024;
     int64_t rb = (int64_t)((budget - fixed) / (QA * sizeof(T)));
     rb = rb / TRB * TRB;
@@ -694,7 +694,7 @@ int launch_q(mxf_ctx* h, GramBwdArgs<T> a, int S, hipStream_t st) {
     const int64_t rblocks = (a.N + rb - 1) / rb;
     const int64_t tiles = (a.N2 + 255) / 256;
     // enough blocks to fill the chip (~16 per CU at five resident blocks each) while keeping the per-block row flush amortised
-    static const int64_t gt_env = getenv("MXF_BWD_GRID") ? atoll(getenv("MXF_BWD_GRID")) : 4096;
+    static const int64_t gt_env = MXF_KNOB("MXF_BWD_GRID", 4096);
     int64_t ct = (tiles * rblocks * S + gt_env - 1) / gt_env;
     if (ct < 1) ct = 1;
     if (ct > 64) ct = 64;
@@ -791,7 +791,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     a.dX = dX; a.dY = dY; a.zacc = zacc; a.dls3 = zacc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
     a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1; a.tblk = t_blocked;
     const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
-    static const int64_t gt_env = getenv("MXF_BWD_MFMA_GRID") ? atoll(getenv("MXF_BWD_MFMA_GRID")) : 8192;
+    static const int64_t gt_env = MXF_KNOB("MXF_BWD_MFMA_GRID", 8192);
     int64_t ct = (quads * bands + gt_env - 1) / gt_env;
     if (ct < 1) ct = 1;
     if (ct > 256) ct = 256;
@@ -856,7 +856,7 @@ int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int
 // SVGP-fused reverse pass over Text = [H0; w^T] Kuf_all (rows 0..M-1: T, rows M..M+P-1: U); column-side output dXall is
 // WRITTEN (not accumulated); dZ, dls, dvar, R, scal are accumulated into (caller zeroes); dY written or (shared) accumulated.
 bool mxf_svgp_bwd_is_mfma(int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text) {
-    static const int mf_env = getenv("MXF_BWD_MFMA") ? atoi(getenv("MXF_BWD_MFMA")) : 1;
+    static const int mf_env = MXF_KNOB("MXF_BWD_MFMA", 1);
     return mf_env && dtype == MXF_F32 && P == 1 && Q <= 8 && SB % 4 == 0 && SB >= 16 && B % 16 == 0 && ((uintptr_t)Text % 16) == 0;
 }
 

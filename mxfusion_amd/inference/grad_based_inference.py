@@ -50,8 +50,16 @@ class GradBasedInference(Inference):
         from ..modules.gp_modules.svgp_regression import SVGPRegression
         if not any(isinstance(f, SVGPRegression) for g in self._graphs for f in getattr(g, '_factors', [])):
             return
+        ctx = self.mxnet_context
+        if isinstance(ctx, str):
+            ctx = torch.device(ctx)
+        if isinstance(ctx, torch.device) and ctx.type != 'cuda':
+            return
         from .. import ops
-        cond = ops.svgp_last_cond(self.mxnet_context)
+        try:                                   # a diagnostic: it must never fail a finished run
+            cond = ops.svgp_last_cond(ctx)
+        except Exception:                      # noqa: BLE001
+            return
         self.last_kuu_condition = cond
         if cond > self.F32_COND_LIMIT:
             import warnings

@@ -349,10 +349,23 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
     return out
 
 
+def _device_index(device):
+    """CUDA device index of `device` (None / torch.device('cuda') without an index -> the current device; int / torch.device / str)."""
+    if device is None:
+        return torch.cuda.current_device()
+    if isinstance(device, str):
+        device = torch.device(device)
+    if isinstance(device, torch.device):
+        if device.type != 'cuda':
+            raise ValueError('mxfusion_amd: %r is not a GPU device' % (device,))
+        return device.index if device.index is not None else torch.cuda.current_device()
+    return int(device)
+
+
 def svgp_last_cond(device=None):
     """1-norm condition number of Kuu + jitter I seen by the last svgp_logpdf training call of this thread on `device` (mxf_svgp_last_cond;
     synchronises).  The float32 streaming form is valid up to ~3e3 (include/mxf_gp.h)."""
-    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    idx = _device_index(device)
     return _lib.svgp_last_cond(idx)
 
 
@@ -361,7 +374,7 @@ def svgp_last_cond(device=None):
 def comm_unique_id(device=None):
     """128-byte rendezvous id (rank 0 creates it and hands it to the other ranks)."""
     import ctypes
-    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    idx = _device_index(device)
     buf = ctypes.create_string_buffer(128)
     _lib.call('mxf_comm_unique_id', _lib.handle(idx), ctypes.cast(buf, ctypes.c_void_p))
     return buf.raw
@@ -369,14 +382,14 @@ def comm_unique_id(device=None):
 
 def comm_init(nranks, rank, unique_id, device=None):
     import ctypes
-    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    idx = _device_index(device)
     assert len(unique_id) == 128
     buf = ctypes.create_string_buffer(bytes(unique_id), 128)
     _lib.call('mxf_comm_init', _lib.handle(idx), int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p))
 
 
 def comm_destroy(device=None):
-    idx = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    idx = _device_index(device)
     _lib.call('mxf_comm_destroy', _lib.handle(idx))
 
 

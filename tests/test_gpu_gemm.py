@@ -132,3 +132,46 @@ def test_gemm_f16x2_zero_operand():
     A = torch.zeros(128, 64, device='cuda')
     B = torch.randn(128, 64, device='cuda')
     assert float(ops.gemm_f16x2(A, B).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('xt,sync,pp', [(4, 0, 0), (4, 1, 0), (4, 2, 0), (8, 0, 0), (8, 2, 0), (16, 0, 0), (16, 1, 0), (16, 2, 0), (16, 0, 1), (16, 1, 1), (16, 2, 1)])
+def test_wide_split_gemm_variants(xt, sync, pp):
+    """Every form of the wide f16x2 kernel (128 rows; 256 rows by four 512-register waves; 256 rows by eight waves in two row halves, with and
+    without the ping-pong phases) with every rendezvous mode (none, per column strip / k split, per XCD), on
+    shapes where the kernel walks several work items per workgroup (T-like: 8 persistent rounds) and where the tiles of a k split meet
+    inside the k loop (Psi2-like), against float64.  The variants are knobs of the PROBE build of the library (the shipped one has them
+    compiled in), hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(root, 'mxfusion_amd', 'libmxf_gp_probe.so')
+    if not os.path.exists(probe):
+        pytest.skip('probe build of the library absent (make -C mxfusion_amd/csrc probe)')
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from mxfusion_amd import ops\n"
+        "g = torch.Generator(device='cuda').manual_seed(5)\n"
+        "M, N, K = 1024, 131072, 1024\n"
+        "A = torch.randn(M, K, device='cuda', generator=g); B = torch.rand(N, K, device='cuda', generator=g) - 0.3\n"
+        "pa, pb = ops.f16x2_split(A), ops.f16x2_split(B)\n"
+        "out = torch.full((M * N,), float('nan'), device='cuda')\n"
+        "for _ in range(3): ops.gemm_f16x2_planes(pa, pb, M, N, K, out=out.view(M, N), blocked=True)\n"
+        "Cb = out.view(N // 16, M, 16).permute(1, 0, 2).reshape(M, N)\n"
+        "idx = torch.randint(0, N, (2048,), device='cuda', generator=g)\n"
+        "ref = A.double() @ B[idx].double().T; sc = A.double().abs() @ B[idx].double().abs().T\n"
+        "assert not torch.isnan(Cb).any()\n"
+        "e1 = float(((Cb[:, idx].double() - ref).abs() / sc).max()); assert e1 < 6e-7, e1\n"
+        "K2 = 400000\n"
+        "C = torch.rand(M, K2, device='cuda', generator=g) - 0.2; pc = ops.f16x2_split(C)\n"
+        "P = torch.zeros(M, M, device='cuda')\n"
+        "for _ in range(3): ops.gemm_f16x2_planes(pc, pc, M, M, K2, out=P, lower_only=True)\n"
+        "ref = torch.tril(C.double() @ C.double().T); sc = C.double().abs() @ C.double().abs().T\n"
+        "e2 = float(((P.double() - ref).abs() / sc).max())\n"
+        "assert e2 < 2e-6, e2      # f32 accumulation of K2 / splits = 16 000 terms per partial sum, ~25 partial sums added atomically\n"
+        "assert float(torch.triu(P, 1).abs().max()) == 0.0\n"
+        "print('errors', e1, e2); print('ok')\n") % root
+    env = dict(os.environ, MXF_GP_LIB=probe, MXF_SPLIT_XT=str(xt), MXF_SPLIT_SYNC=str(sync), MXF_SPLIT_PP=str(pp))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]

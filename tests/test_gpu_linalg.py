@@ -118,10 +118,14 @@ def test_potrf_tiles_scratch_rings_wrap_and_streams_do_not_collide():
 
 def test_potrf_outer_panel_split_launch_batched():
     """The two-launch form of an outer panel (chain rows, then the rows below without hand-offs) only engages with >= 64 block rows below
-    a panel (n >= 4608); MXF_POTRF_SPLIT_ROWS=2 (read once per process, hence the subprocess) forces it at n = 1536 with a batch of 2."""
+    a panel (n >= 4608); MXF_POTRF_SPLIT_ROWS=2 (a knob of the PROBE build of the library, read once per process, hence the subprocess)
+    forces it at n = 1536 with a batch of 2."""
     import os
     import subprocess
     import sys
+    probe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mxfusion_amd', 'libmxf_gp_probe.so')
+    if not os.path.exists(probe):
+        pytest.skip('probe build of the library absent (make -C mxfusion_amd/csrc probe)')
     code = (
         "import numpy as np, torch, sys\n"
         "sys.path.insert(0, %r)\n"
@@ -132,7 +136,7 @@ def test_potrf_outer_panel_split_launch_batched():
         "assert int(info.abs().sum()) == 0\n"
         "assert np.allclose(L.cpu().numpy(), np.linalg.cholesky(A), rtol=1e-11, atol=1e-11)\n"
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MXF_POTRF_SPLIT_ROWS='2'), capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MXF_POTRF_SPLIT_ROWS='2', MXF_GP_LIB=probe), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
 
 
