@@ -739,7 +739,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
                 g.sync_n = (int)tiles; g.sync_period = (int)period; g.sync_slots = (int)slots_per;
             }
         }
-        static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 1);        // ping-pong phases of the two row halves (NH = 2)
+        static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
         if (NH == 2 && pp_env) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, false>), dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (XT == 8) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<8, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, g);

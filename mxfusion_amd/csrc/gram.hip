@@ -219,7 +219,10 @@ template <typename T> struct GramLean {
 // XF (float64 RBF only): the squared distance in the reference's own expansion form |x|^2 + |z|^2 - 2 x.z (stationary.py:98-107) --
 // 1 + QT fused multiply-adds per element instead of 2 QT operations -- with the row norms from prescale_kernel, and the table-driven
 // exp2 above.  In float64 the kernel is bound by its VALU work, not by HBM (~40 issue slots per 8-byte element before, ~27 with XF).
-template <typename T, int QT, int KIND, int XF>
+// TRC > 0 (r03): the rows per workgroup as a compile-time constant, and the diagonal term HOISTED -- a wave-uniform test in front of the row
+// loop sends only the workgroups the diagonal crosses (and a ragged last row block) through the loop with the per-row check.  Same-box
+// (tests/probes/gram_variants.hip "cand"): +2.0 ... 2.5 % over the run-time form at 16 rows; 12 rows measured between equal and +4 %.
+template <typename T, int QT, int KIND, int XF, int TRC>
 __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_all, const T* __restrict__ Zs_all, T* __restrict__ K_all,
                                                        const T* __restrict__ var, const T* __restrict__ dadd_p,
                                                        const T* __restrict__ Xn_all, const T* __restrict__ Zn_all, GramLean<T> a) {
@@ -230,7 +233,8 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
     __shared__ double tab[XF ? 64 : 1];
     // (forcing the whole argument segment into SGPRs up front with an `asm volatile("" :: "s"(...))` makes the compiler fetch the x rows
     //  with per-lane vector loads instead of s_loads: 6.4 -> 5.7 TB/s, tests/probes/gram_variants.hip "force")
-    const int64_t row0 = (int64_t)blockIdx.y * a.tr;
+    const int tr = TRC > 0 ? TRC : a.tr;
+    const int64_t row0 = (int64_t)blockIdx.y * tr;
     const int64_t wcol0 = (int64_t)blockIdx.x * (64 * VEC);       // first column of the wave
     const int64_t col0 = wcol0 + (int64_t)lane * VEC;
     const T variance = (KIND == MXF_K_LINEAR) ? (T)1 : var[(int64_t)s * a.svar];
@@ -249,8 +253,9 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
     }
     const T* __restrict__ Xrows = Xs_all + (int64_t)s * a.sXs + row0 * QT;       // wave-uniform: scalar loads
     T* __restrict__ Krow = K_all + (int64_t)s * a.sK + row0 * a.ldk + col0;
-    const bool diag_possible = a.has_diag != 0;          // decided on the host: a diagonal term exists (its value may still be 0)
-    const int rmax = (a.N - row0) < a.tr ? (int)(a.N - row0) : a.tr;
+    // a diagonal term exists (decided on the host; its value may still be 0) -- TRC form: ... and crosses this workgroup's rows x columns
+    const bool diag_possible = a.has_diag != 0 && (TRC == 0 || (row0 < wcol0 + 64 * VEC && row0 + tr > wcol0));
+    const int rmax = (a.N - row0) < tr ? (int)(a.N - row0) : tr;
     T zz[VEC];
     const T* __restrict__ Xn = nullptr;
     if constexpr (XF == 1) {     // t = -64 (|x|^2 + |z|^2 - 2 x.z) = fma(|x|^2, -64, -64 |z|^2) + sum_q x_q (128 z_q)
@@ -265,8 +270,7 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
             for (int q = 0; q < QT; ++q) z[v][q] *= (T)128;
         }
     }
-#pragma unroll 2
-    for (int r = 0; r < rmax; ++r) {
+    auto do_row = [&](int r, auto with_diag) {
         T x[QT];
 #pragma unroll
         for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];
@@ -310,11 +314,13 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
             }
         }
         // "+ noise / jitter on the diagonal": a scalar test (is this row inside the wave's column range?) guards the per-lane compares
-        if (diag_possible && (uint64_t)(row0 + r - wcol0) < (uint64_t)(64 * VEC)) {
+        if constexpr (decltype(with_diag)::value) {
+            if (diag_possible && (uint64_t)(row0 + r - wcol0) < (uint64_t)(64 * VEC)) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) if (col0 + v == row0 + r) {
-                if (XF == 1 && (a.has_diag & 2)) kv[v] = variance;     // k(x, x) = variance exactly (stationary.py:123-124), as the difference form gives
-                kv[v] += dadd;
+                for (int v = 0; v < VEC; ++v) if (col0 + v == row0 + r) {
+                    if (XF == 1 && (a.has_diag & 2)) kv[v] = variance;     // k(x, x) = variance exactly (stationary.py:123-124), as the difference form gives
+                    kv[v] += dadd;
+                }
             }
         }
         V out;
@@ -322,6 +328,17 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
 #pragma unroll
         for (int v = 0; v < VEC; ++v) po[v] = kv[v];
         __builtin_nontemporal_store(out, reinterpret_cast<V*>(Krow + (int64_t)r * a.ldk));
+    };
+    if constexpr (TRC > 0) {
+        if (rmax == TRC && !diag_possible) {
+#pragma unroll 2
+            for (int r = 0; r < TRC; ++r) do_row(r, std::false_type{});
+        } else {
+            for (int r = 0; r < rmax; ++r) do_row(r, std::true_type{});
+        }
+    } else {
+#pragma unroll 2
+        for (int r = 0; r < rmax; ++r) do_row(r, std::true_type{});
     }
 }
 
@@ -400,7 +417,8 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
     // f32 RBF: 16 rows (6.05 TB/s; 32: 5.75, 64: 5.29, 8: 5.27); the VALU-heavier epilogues (Matern, all float64) prefer 64 (f64 RBF 5.25 vs 5.13)
     // (float64 RBF in the expansion form, gram_lean_kernel XF: 16 rows 5.71 ms = 6.02 TB/s, 32: 5.95, 64: 6.36 ms)
     static const int xf_tr = MXF_KNOB("MXF_GRAM_F64_EXPAND", 1);
-    a.tr = (tr_env == 8 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((KIND == MXF_K_RBF && (sizeof(T) == 4 || xf_tr)) ? 16 : 64);
+    // (r03: float32 RBF 12 rows as a compile-time constant with the diagonal term hoisted, gram_lean_kernel TRC: between equal and +4 % against 16)
+    a.tr = (tr_env == 8 || tr_env == 12 || tr_env == 16 || tr_env == 32 || tr_env == 64) ? tr_env : ((KIND == MXF_K_RBF && sizeof(T) == 4) ? 12 : (KIND == MXF_K_RBF && xf_tr) ? 16 : 64);
     a.nt = (nt_env >= 0) ? nt_env : 1;
     const int NW = (nw_env == 1 || nw_env == 4) ? nw_env : 1;
     const int64_t cw = (int64_t)NW * 64 * VEC;          // columns per workgroup
@@ -446,9 +464,14 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
             const T* dptr = hd ? a.dadd : (a.var ? a.var : a.Xs);          /* any readable word when there is no diagonal term */ \
             dim3 gl(a.ncb, (unsigned)((a.N + a.tr - 1) / a.tr), (unsigned)S);                                         \
             if constexpr (sizeof(T) == 8 && KIND == MXF_K_RBF) {                                                      \
-                if (xf) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 1>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)xnorm, (const T*)znorm, l); \
-                else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
-            } else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+                if (xf && a.tr == 16) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 1, 16>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)xnorm, (const T*)znorm, l); \
+                else if (xf) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 1, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)xnorm, (const T*)znorm, l); \
+                else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+            } else if constexpr (sizeof(T) == 4 && KIND == MXF_K_RBF) {                                               \
+                if (a.tr == 12) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0, 12>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+                else if (a.tr == 16) hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0, 16>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+                else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
+            } else hipLaunchKernelGGL((gram_lean_kernel<T, QT, KIND, 0, 0>), gl, dim3(64), 0, st, a.Xs, a.Zs, a.K, a.var, dptr, (const T*)nullptr, (const T*)nullptr, l); \
         } else if (NW == 1 && fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, true>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K); \
         else if (NW == 1) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 1, false>), g, dim3(64), 0, st, a, a.Xs, a.Zs, a.K);            \
         else if (fast) hipLaunchKernelGGL((gram_kernel<T, QT, KIND, 4, true>), g, dim3(256), 0, st, a, a.Xs, a.Zs, a.K);               \

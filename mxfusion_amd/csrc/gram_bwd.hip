@@ -791,7 +791,10 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     a.dX = dX; a.dY = dY; a.zacc = zacc; a.dls3 = zacc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
     a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1; a.tblk = t_blocked;
     const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
-    static const int64_t gt_env = MXF_KNOB("MXF_BWD_MFMA_GRID", 8192);
+    // work items: ~1024 (r03; was 8192).  Every workgroup ends with a flush of its row-side sums (LDS, then float64 atomics), a fixed cost
+    // per workgroup: with 8192 of them the pass took 0.82 ms at 4 samples where 3.0 / 8 = 0.38 was its share (per-rank step 5.02 -> 4.63 ms
+    // with 1024; 32 samples: 25.18 -> 24.79 ms; 512 measures the same, tests/probes/bwd_grid.sh)
+    static const int64_t gt_env = MXF_KNOB("MXF_BWD_MFMA_GRID", 1024);
     int64_t ct = (quads * bands + gt_env - 1) / gt_env;
     if (ct < 1) ct = 1;
     if (ct > 256) ct = 256;

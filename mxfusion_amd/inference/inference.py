@@ -99,17 +99,10 @@ class Inference(object):
 
     # ---- checkpoint (inference.py:179-310): the reference's zip layout, parameters keyed by UUID -------------------
     def _graph_listing(self):
-        """graphs.json: per graph, every variable in registration order (deterministic for a given model script) with its
-        uuid / name / type.  (The reference dumps a networkx node-link graph; the payload files are identical in layout, the
-        graph file here carries what reconciliation needs: order, names and types.)"""
-        out = []
-        for g in self._graphs:
-            comps = []
-            for u, v in g.variables.items():
-                comps.append({'uuid': u, 'name': v.name, 'type': type(v).__name__, 'version': ser.__GRAPH_JSON_VERSION__,
-                              'var_type': str(getattr(v, 'type', None)), 'has_factor': v.factor is not None and type(v.factor).__name__})
-            out.append({'name': g.name, 'type': type(g).__name__, 'variables': comps})
-        return out
+        """graphs.json exactly as the reference lays it out (inference.py:283 -> FactorGraph.as_json, factor_graph.py:619-628): one
+        networkx node-link dict per graph, every component encoded as serialization.py:42-53 does -- util/graph_json.py."""
+        from ..util import graph_json
+        return [graph_json.graph_as_json(g) for g in self._graphs]
 
     def get_serializable(self):
         return {'observed': self.observed_variable_UUIDs}
@@ -130,19 +123,19 @@ class Inference(object):
                        ser.FILENAMES['version_file']: {'serialization_version': ser.SERIALIZATION_VERSION}},
                       {ser.FILENAMES['mxnet_params']: params, ser.FILENAMES['mxnet_constants']: arr_consts})
 
-    def load(self, zip_filename=ser.DEFAULT_ZIP):
-        """inference.py:179-228: reconcile the saved graphs with the current ones ({saved uuid: current uuid} in
-        self._uuid_map) and load the parameters / constants through that map.  Call after initialize()."""
-        import zipfile
-        ver = ser.load_json_from_zip(zip_filename, ser.FILENAMES['version_file'])
-        if ver.get('serialization_version') != ser.SERIALIZATION_VERSION:
-            raise SerializationError('Serialization version of saved inference and running code are not the same.')
-        with zipfile.ZipFile(zip_filename, 'r') as zf:
-            saved_params = ser.load_parameters(ser.FILENAMES['mxnet_params'], zf)
-            saved_consts = ser.load_parameters(ser.FILENAMES['mxnet_constants'], zf)
-        var_consts = ser.load_json_from_zip(zip_filename, ser.FILENAMES['variable_constants'])
-        saved_graphs = ser.load_json_from_zip(zip_filename, ser.FILENAMES['graphs'])
-        current = self._graph_listing()
+    def _reconcile_saved_graphs(self, saved_graphs):
+        """{saved uuid: current uuid}.  graphs.json in the reference's node-link layout (written by the reference itself or by save()
+        above) goes through the reference's reconciliation (FactorGraph.reconcile_graphs, factor_graph.py:479-588, restated in
+        util/graph_json.py); the positional listing round 1-2 checkpoints of this package carry is still understood."""
+        from ..util import graph_json
+        if graph_json.is_reference_graphs_json(saved_graphs):
+            if len(saved_graphs) != len(self._graphs):
+                raise SerializationError('saved inference has %d graphs, the current one %d' % (len(saved_graphs), len(self._graphs)))
+            prev = graph_json.load_graphs(saved_graphs)
+            return graph_json.reconcile_graphs(self._graphs, prev[0], prev[1:])
+        current = [{'name': g.name, 'variables': [{'uuid': u, 'name': v.name, 'type': type(v).__name__,
+                                                    'has_factor': v.factor is not None and type(v.factor).__name__}
+                                                   for u, v in g.variables.items()]} for g in self._graphs]
         if len(saved_graphs) != len(current):
             raise SerializationError('saved inference has %d graphs, the current one %d' % (len(saved_graphs), len(current)))
         uuid_map = {}
@@ -155,9 +148,26 @@ class Inference(object):
                     raise SerializationError('graph %s: saved component %s (%s) does not match current %s (%s)'
                                              % (cg['name'], sv['name'], sv['type'], cv['name'], cv['type']))
                 uuid_map[sv['uuid']] = cv['uuid']
-        self._uuid_map = uuid_map
+        return uuid_map
+
+    def load(self, zip_filename=ser.DEFAULT_ZIP):
+        """inference.py:179-228: reconcile the saved graphs with the current ones ({saved uuid: current uuid} in
+        self._uuid_map) and load the parameters / constants through that map.  Call after initialize().  Everything is validated BEFORE
+        the first write: a checkpoint that cannot be restored completely leaves the inference untouched."""
+        import zipfile
+        ver = ser.load_json_from_zip(zip_filename, ser.FILENAMES['version_file'])
+        if ver.get('serialization_version') != ser.SERIALIZATION_VERSION:
+            raise SerializationError('Serialization version of saved inference and running code are not the same.')
+        with zipfile.ZipFile(zip_filename, 'r') as zf:
+            saved_params = ser.load_parameters(ser.FILENAMES['mxnet_params'], zf)
+            saved_consts = ser.load_parameters(ser.FILENAMES['mxnet_constants'], zf)
+        var_consts = ser.load_json_from_zip(zip_filename, ser.FILENAMES['variable_constants'])
+        saved_graphs = ser.load_json_from_zip(zip_filename, ser.FILENAMES['graphs'])
         if not self._initialized:
             raise SerializationError('load() needs an initialised inference (call initialize(...) first, as the reference tests do)')
+        uuid_map = self._reconcile_saved_graphs(saved_graphs)
+        # ---- validate: every saved parameter has a counterpart of the same size, every trainable parameter is covered
+        plan = []
         for su, arr in saved_params.items():
             cu = uuid_map.get(su)
             if cu is None:
@@ -167,6 +177,18 @@ class Inference(object):
                 o, n, shape = self.params._slices[cu]
                 if raw.numel() != n:
                     raise SerializationError('saved parameter %s has %d elements, the current one %d' % (su, raw.numel(), n))
+            plan.append((cu, raw))
+        # a checkpoint that silently leaves some trainable parameters at their random initial values is worse than an error
+        restored = {cu for cu, _ in plan}
+        missing = [u for u in self.params._slices if u not in restored]
+        if missing:
+            names = [getattr(self.params._vars.get(u), 'name', None) or u for u in missing]
+            raise SerializationError('the checkpoint holds no value for %d trainable parameter(s): %s' % (len(missing), ', '.join(map(str, names[:8]))))
+        # ---- write
+        self._uuid_map = uuid_map
+        for cu, raw in plan:
+            if cu in self.params._slices:
+                o, n, shape = self.params._slices[cu]
                 with torch.no_grad():
                     self.params._flat[o:o + n] = raw.reshape(-1)
             else:
@@ -175,13 +197,6 @@ class Inference(object):
                     for g in self._graphs:
                         if cu in g.variables:
                             self.params._vars[cu] = g.variables[cu]
-        # every trainable parameter of the current graphs must have been restored: a checkpoint that silently leaves some of them at their
-        # random initial values is worse than an error
-        restored = {uuid_map[su] for su in saved_params if su in uuid_map}
-        missing = [u for u in self.params._slices if u not in restored]
-        if missing:
-            names = [getattr(self.params._vars.get(u), 'name', None) or u for u in missing]
-            raise SerializationError('the checkpoint holds no value for %d trainable parameter(s): %s' % (len(missing), ', '.join(map(str, names[:8]))))
         consts = {}
         for su, arr in saved_consts.items():
             if su in uuid_map:

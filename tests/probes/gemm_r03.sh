@@ -9,7 +9,7 @@ export MXF_GP_LIB=$R/mxfusion_amd/libmxf_gp_probe.so
 cd /tmp && export TMPDIR=/tmp
 mode=$1; shift
 for cfg in $1; do
-  IFS=: read xt sy pp <<< "$cfg"; pp=${pp:-1}
+  IFS=: read xt sy pp <<< "$cfg"; pp=${pp:-0}
   export MXF_SPLIT_XT=$xt MXF_SPLIT_SYNC=$sy MXF_SPLIT_PP=$pp
   if [ "$mode" = time ]; then
     echo "== XT=$xt SYNC=$sy PP=$pp"; python $R/tests/probes/t_time.py 2>&1 | tail -2

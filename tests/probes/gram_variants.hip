@@ -123,6 +123,49 @@ __global__ __launch_bounds__(64) void gram_l(const float* __restrict__ Xs_all, c
     }
 }
 
+// r03 production candidate: compile-time rows per workgroup, 2-D grid, variance / diagonal term through pointers, and the diagonal term
+// HOISTED: a wave-uniform test before the row loop picks the loop with the per-row check only for the workgroups the diagonal crosses
+template <int TRr>
+__global__ __launch_bounds__(64) void gram_t(const float* __restrict__ Xs_all, const float* __restrict__ Zs_all, float* __restrict__ K_all,
+                                             const float* __restrict__ var, const float* __restrict__ dadd_p, LeanArgs a) {
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.y * TRr;
+    const int64_t wcol0 = (int64_t)blockIdx.x * 256;
+    const int64_t col0 = wcol0 + (int64_t)lane * 4;
+    const float variance = var[0];
+    const float dadd = a.dscale * dadd_p[0] + a.jitter;
+    if (col0 >= a.N2) return;
+    float z[4][QT];
+    {
+        const float* Zs = Zs_all + col0 * QT;
+#pragma unroll
+        for (int i = 0; i < 4 * QT; i += 4) *reinterpret_cast<f32x4*>(&z[0][0] + i) = *reinterpret_cast<const f32x4*>(Zs + i);
+    }
+    const float* __restrict__ Xrows = Xs_all + row0 * QT;
+    float* __restrict__ Krow = K_all + row0 * a.ldk + col0;
+    const int rmax = (a.N - row0) < TRr ? (int)(a.N - row0) : TRr;
+    const bool on_diag = a.has_diag != 0 && row0 < wcol0 + 256 && row0 + TRr > wcol0;       // wave-uniform
+    if (rmax == TRr && !on_diag) {
+#pragma unroll 2
+        for (int r = 0; r < TRr; ++r) {
+            float x[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];
+            const f32x4 out = rbf_row(x, z, variance);
+            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(Krow + (int64_t)r * a.ldk));
+        }
+    } else {
+        for (int r = 0; r < rmax; ++r) {
+            float x[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) x[q] = Xrows[r * QT + q];
+            f32x4 out = rbf_row(x, z, variance);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) if (on_diag && col0 + v == row0 + r) out[v] += dadd;
+            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(Krow + (int64_t)r * a.ldk));
+        }
+    }
+}
 // one-wave workgroups of 16 rows with the row order varied per workgroup: ROT 1 = start at a workgroup-dependent row and wrap,
 // 2 = odd workgroups run bottom-up, 3 = two rows computed, then two stores back to back
 template <int ROT>
@@ -260,6 +303,7 @@ int main() {
     vs.push_back({nm, [=] { const unsigned ncb = N / (256 * NW), nrb = N / TRr;                                                    \
                             fill_v<TRr, ORD, NW><<<ncb * nrb, NW * 64>>>(K, N, ncb, nrb, 1.f); }, {}, false})
     ADDV("gram sgpr TR16 colfast nw1 nt", 16, 1, 0, 1, 1);
+    // r03 sweep: rows per one-wave workgroup, waves per workgroup sharing the scalar x rows, XCD-striped order
     float* dvar; hipMalloc(&dvar, 16); { float one[4] = {1.f, 0.f, 0.f, 0.f}; hipMemcpy(dvar, one, 16, hipMemcpyHostToDevice); }
     LeanArgs la; la.N = N; la.N2 = N; la.ldk = N; la.sXs = 0; la.sZs = 0; la.sK = 0; la.svar = 0; la.sdadd = 0; la.tr = 16; la.has_diag = 0;
     la.dscale = 0.f; la.jitter = 0.f;
@@ -268,11 +312,23 @@ int main() {
                             if (G2) gram_l<G2, RT, VP, DG, FC><<<dim3(ncb, nrb), 64>>>(Xs, Xs, K, dvar, dvar + 1, la, ncb);       \
                             else gram_l<G2, RT, VP, DG, FC><<<ncb * nrb, 64>>>(Xs, Xs, K, dvar, dvar + 1, la, ncb); }, {}, true})
     ADDL("lean 2d rt  ptr   diag   noforce (production lean)", 1, 1, 1, 1, 0);
-    vs.push_back({"rot: start row varies per workgroup", [=] { gram_rot<1><<<(N / 256) * (N / 16), 64>>>(Xs, K, N, N / 256, 1.f); }, {}, true});
-    vs.push_back({"rot: odd workgroups bottom-up", [=] { gram_rot<2><<<(N / 256) * (N / 16), 64>>>(Xs, K, N, N / 256, 1.f); }, {}, true});
-    vs.push_back({"rot: two rows, two stores back to back", [=] { gram_rot<3><<<(N / 256) * (N / 16), 64>>>(Xs, K, N, N / 256, 1.f); }, {}, true});
+    // r03: which ingredient of the production form costs the 2-3 % against the plain kernel?
+    ADDV("gram sgpr TR12 colfast nw1 nt", 12, 1, 0, 1, 1);
+    ADDV("gram sgpr TR10 colfast nw1 nt", 10, 1, 0, 1, 1);
+    ADDV("gram sgpr TR11 colfast nw1 nt", 11, 1, 0, 1, 1);
+    ADDV("gram sgpr TR13 colfast nw1 nt", 13, 1, 0, 1, 1);
+    ADDV("gram sgpr TR14 colfast nw1 nt", 14, 1, 0, 1, 1);
+    LeanArgs ld = la; ld.has_diag = 1; ld.jitter = 0.f; ld.dscale = 0.f;
+#define ADDT(nm, TRr, ARGS)                                                                                                        \
+    vs.push_back({nm, [=] { gram_t<TRr><<<dim3(N / 256, (N + TRr - 1) / TRr), 64>>>(Xs, Xs, K, dvar, dvar + 1, ARGS); }, {}, true})
+    ADDT("cand TR10 2d ptr diag-hoisted", 10, ld);
+    ADDT("cand TR11 2d ptr diag-hoisted", 11, ld);
+    ADDT("cand TR12 2d ptr diag-hoisted", 12, ld);
+    ADDT("cand TR13 2d ptr diag-hoisted", 13, ld);
+    ADDT("cand TR14 2d ptr diag-hoisted", 14, ld);
+    ADDT("cand TR16 2d ptr diag-hoisted", 16, ld);
+    ADDT("cand TR12 2d ptr nodiag", 12, la);
     vs.push_back({"rot: plain (control)", [=] { gram_rot<0><<<(N / 256) * (N / 16), 64>>>(Xs, K, N, N / 256, 1.f); }, {}, true});
-    vs.push_back({"w8: 512 columns per wave, 16 rows", [=] { gram_w8<<<(N / 512) * (N / 16), 64>>>(Xs, K, N, N / 512, 1.f); }, {}, true});
     vs.push_back({"hipMemsetAsync", [=] { hipMemsetAsync(K, 0, N * N * 4, 0); }, {}, false});
 
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -5,9 +5,9 @@ slice the observed rows and scale all three factors by N/B.
 
   * small: the first minibatch step through the API (model, posterior, StochasticVariationalInference, MinibatchInferenceLoop.step,
     injected noise) against the oracle's autograd -- loss and every gradient;
-  * full size (B = 8192, M = 1024, Q = 8, 4 samples = one GPU's share of 32 over 8 GPUs, log_pdf_scaling = 8): the streaming path where the
-    oracle cannot run -- exact linearity in log_pdf_scaling (float64) and float32-vs-float64 agreement of the ELBO at the initial AND at a
-    trained-like length-scale."""
+  * full size (B = 8192, M = 1024, Q = 8, 4 samples = one GPU's share of 32 over 8 GPUs, log_pdf_scaling = 8): exact linearity in
+    log_pdf_scaling (float64) and float32-vs-float64 agreement of the ELBO at the initial AND at a trained-like length-scale.  (The same
+    shape against the ORACLE's values and autograd gradients, S = 2: tests/test_gpu_fullsize_oracle.py.)"""
 import numpy as np
 import pytest
 import torch

@@ -1,6 +1,6 @@
-"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot run there): the N=65 536 RBF Gram
-(configs' metric kernel), the exact-GP factorisation at N=8 192 (configs[1]) and the SVGP training call at N=65 536, M=1 024
-(configs[2])."""
+"""Size-independent properties at BASELINE.json's FULL sizes: the N=65 536 RBF Gram (configs' metric kernel), the exact-GP factorisation at
+N=8 192 (configs[1]) and the SVGP training call at N=65 536, M=1 024 (configs[2]) incl. all 32 samples (2.1 M columns per call, which the
+oracle's materialising form cannot hold).  The comparison with the ORACLE itself at these shapes (S <= 2) is tests/test_gpu_fullsize_oracle.py."""
 import numpy as np
 import pytest
 import torch

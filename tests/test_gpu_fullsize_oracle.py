@@ -3,7 +3,8 @@ for op, float64 torch-CPU) and its autograd gradients, evaluated on the HOST at 
 Q = 8), configs[3] (S = 2, B = 8 192, M = 1 024, log_pdf_scaling 8) and of both layers of configs[4] (N = 131 072, Q = 16, M = 512,
 Matern52 + RBF first layer; S = 1), compared with the HIP path through the C ABI:
     float64 call:  ELBO and every gradient to 1e-9 (relative / normwise)
-    float32 call:  ELBO to 1e-5 relative (north_star), gradients to the normwise tolerances stated at each assert
+    float32 call:  ELBO to 1e-5 relative (north_star; measured 5e-8 at ell = 1, 4.8e-6 at ell = 2.2), gradients to the normwise
+                   tolerances stated at each assert
 at the initial length-scale 1 AND at the trained-like length-scale 2.2 (where a 300-step optimisation of the bench model ends).
 The oracle materialises ~6 (M x N) float64 temporaries plus the autograd tape: ~5 GB and a few seconds at S = 1, N = 65 536."""
 import numpy as np
@@ -74,12 +75,14 @@ def test_svgp_at_baseline_sizes_against_the_oracle(S, B, scaling, tag, ell):
     rel = float(np.abs(r32['logL'] - ref).max() / np.abs(ref).max())
     assert rel <= 1e-5, (tag, ell, rel)                                            # north_star: 1e-5 relative on the ELBO
     # float32 streaming step (f16x2 split GEMMs, f32 reverse pass, float64 M x M core) against the ORACLE's gradients, normwise.
-    # The q(u) / noise / variance gradients come out of the float64 core: 2e-4.  dX, dZ, dls carry the explicit-inverse streaming error
-    # ~ cond(Kuu) 2^-24 through T = H0 Kuf: 2e-4 at ell = 1 (Kuu ~ I), 5e-3 at the trained-like ell = 2.2 (cond_1 ~ 1.4e3).
-    loose = 2e-4 if ell == 1.0 else 5e-3
-    for hk, ok in _KEYS:
-        tol = loose if hk in ('dX', 'dZ', 'dls') else 2e-4
-        assert _rel(r32[hk], g[ok]) <= tol, (tag, ell, hk, _rel(r32[hk], g[ok]))
+    # Measured on MI355X (r03): at ell = 1 (Kuu ~ I) every gradient agrees to <= 2.1e-6; at the trained-like ell = 2.2 (cond_1(Kuu) ~ 1.4e3)
+    # whatever passes through the explicit inverse picks up ~ cond 2^-24 -- dZ 3.6e-4, dW 5.5e-4, dls 1.8e-4, dSdiag 1.2e-4, dvar 8e-5,
+    # dX 2.3e-5; dmu, dnoise 5e-6.  Tolerances = those figures with a factor ~4 of head room.
+    errs = {hk: _rel(r32[hk], g[ok]) for hk, ok in _KEYS}
+    print('f32 vs oracle, %s, ell %.1f: ELBO %.2e, gradients %s' % (tag, ell, rel, {k: '%.1e' % v for k, v in errs.items()}))
+    tol22 = {'dX': 2e-4, 'dZ': 2e-3, 'dmu': 5e-5, 'dW': 2e-3, 'dSdiag': 1e-3, 'dnoise': 5e-5, 'dls': 1e-3, 'dvar': 5e-4}
+    for hk, e in errs.items():
+        assert e <= (2e-5 if ell == 1.0 else tol22[hk]), (tag, ell, hk, e)
 
 
 def test_deep_gp_layers_at_config5_size_against_the_oracle():
@@ -91,26 +94,32 @@ def test_deep_gp_layers_at_config5_size_against_the_oracle():
     N, Q, M, Dh = 131072, 16, 512, 2
     rng = np.random.default_rng(21)
     X = rng.uniform(-3., 3., (1, N, Q))
-    H = np.sin(X[0] @ rng.standard_normal((Q, Dh)) / 4.0) + 0.05 * rng.standard_normal((N, Dh))
-    Y = np.sin(H @ rng.standard_normal((Dh, 1)))
+    # hidden layer values spread over [-8, 8]^2 and the second layer's inducing inputs on a jittered 23 x 23 grid (spacing 0.7 against
+    # length-scales 0.5 / 0.6): cond(Kuu) stays moderate, so that float64 in the explicit-inverse streaming form (HIP) and in the reference's
+    # solve form (oracle) agree to 1e-9 -- 512 inducing points drawn from the data in 2-D would put cond ~ 1e11 between the two
+    H = 8.0 * np.sin(X[0] @ rng.standard_normal((Q, Dh)) / 2.0) + 0.05 * rng.standard_normal((N, Dh))
+    Y = np.sin(H @ rng.standard_normal((Dh, 1)) / 3.0)
     Z1 = X[0][rng.permutation(N)[:M]].copy()
-    Z2 = H[rng.permutation(N)[:M]].copy()
+    gx = (np.arange(23) - 11.0) * 0.7
+    Z2 = (np.stack(np.meshgrid(gx, gx), -1).reshape(-1, 2) + 0.1 * rng.standard_normal((529, 2)))[rng.permutation(529)[:M]].copy()
     noise = np.array([0.02])
     qW = 0.4 * rng.standard_normal((M, M)) / np.sqrt(M)
     qd = rng.uniform(0.05, 0.5, M)
     # ---- layer 2: RBF-ARD on the (sampled) hidden inputs, P = 1 ---------------------------------------------------------------
     qm2 = 0.3 * rng.standard_normal((M, 1))
-    ls2, var2 = np.array([0.8, 1.1]), np.array([1.3])
+    ls2, var2 = np.array([0.5, 0.6]), np.array([1.3])
     ref, g = _oracle(O.RBF(Dh, ARD=True), {'rbf_lengthscale': ls2, 'rbf_variance': var2}, H[None], Y, Z2, noise, qm2, qW, qd, 1.0)
     r64 = _hip_rbf(torch.float64, H[None], Y, Z2, noise, qm2, qW, qd, ls2, var2, 1.0)
     assert np.allclose(r64['logL'], ref, rtol=1e-9, atol=0)
     for hk, ok in _KEYS:
         assert _rel(r64[hk], g[ok]) <= 1e-9, ('layer 2', hk, _rel(r64[hk], g[ok]))
     r32 = _hip_rbf(torch.float32, H[None], Y, Z2, noise, qm2, qW, qd, ls2, var2, 1.0)
-    assert float(np.abs(r32['logL'] - ref).max() / np.abs(ref).max()) <= 1e-5
-    for hk, ok in _KEYS:              # Q = 2 inducing inputs drawn from the data: cond(Kuu) is large -> the streaming-error keys get 5e-3
-        tol = 5e-3 if hk in ('dX', 'dZ', 'dls') else 5e-4
-        assert _rel(r32[hk], g[ok]) <= tol, ('layer 2 f32', hk, _rel(r32[hk], g[ok]))
+    rel = float(np.abs(r32['logL'] - ref).max() / np.abs(ref).max())
+    errs = {hk: _rel(r32[hk], g[ok]) for hk, ok in _KEYS}
+    print('layer 2 f32 vs oracle: ELBO %.2e, gradients %s' % (rel, {k: '%.1e' % v for k, v in errs.items()}))
+    assert rel <= 1e-5
+    for hk, e in errs.items():        # measured r03: <= 8e-5 on every key (well-conditioned Kuu); 5e-4 leaves head room
+        assert e <= 5e-4, ('layer 2 f32', hk, e)
     # ---- layer 1: Matern52 + RBF on the observed inputs, output = the hidden layer (P = Dh): the combination-kernel path of the module --
     # (SVGPRegressionLogPdf._compute_materialised: each sub-kernel one mxf_gram pass with its own reverse mode, the bound from mxf_svgp_logpdf_mat)
     from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
@@ -120,7 +129,7 @@ def test_deep_gp_layers_at_config5_size_against_the_oracle():
     kp = {'add_matern52_lengthscale': np.full(Q, 1.5), 'add_matern52_variance': np.array([0.7]), 'add_rbf_lengthscale': np.full(Q, 2.0),
           'add_rbf_variance': np.array([0.9])}
     ref1, g1 = _oracle(okern, kp, X, H, Z1, noise, qm1, qW, qd, 1.0)
-    for dt, vtol, gtol in ((torch.float64, 1e-9, 1e-9), (torch.float32, 1e-5, 5e-3)):
+    for dt, vtol, gtol in ((torch.float64, 1e-9, 1e-9), (torch.float32, 1e-5, 2e-3)):
         d = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
         dn = 'float64' if dt == torch.float64 else 'float32'
         kern = Matern52(Q, ARD=True, dtype=dn) + RBF(Q, ARD=True, dtype=dn)
