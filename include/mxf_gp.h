@@ -58,6 +58,11 @@ int64_t mxf_workspace_generation(mxf_handle h);
  * agreement with float64 is 3e-6 at cond 1.4e3 and 2e-3 at 5e4 (tests/probes/f32_accuracy.py) -- above ~3e3 use float64.  0 if there was
  * no such call.  (No reference counterpart: svgp_regression.py:83-92 solves with the Cholesky factor, in whatever dtype the model has.) */
 int mxf_svgp_last_cond(mxf_handle h, double* cond1_out);
+/* The same quantity WITHOUT synchronising: the running maximum of the condition numbers that the training calls finished so far on this
+ * handle have published (the last launch of every training call folds its cond_1 into one pinned, device-visible host word); reset != 0
+ * clears it after the read.  A caller polls it every step for free and lags by at most the calls still in flight -- the float32 guard of
+ * mxfusion_amd's SVGP module (automatic switch of the streaming stage to float64 above ~3e3) is built on it.  No reference counterpart. */
+int mxf_svgp_cond_nowait(mxf_handle h, double* cond1_max_out, int reset);
 
 /* out[0] = sum_i g[i] if the n values agree to 1e-6 relative, NaN otherwise.  The fused composites return the gradients of
  * gscale * sum_s logL[s] with ONE weight: the reverse-mode bridge uses this to scale them by the upstream gradient of mean_S(logL)
@@ -277,6 +282,23 @@ int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t
                     void* logL, int* info, int want_grad,
                     void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag,
                     void* dls, void* dvar, void* stream);
+
+/* The same bound with SAMPLED parameters: every operand of svgp_regression.py:43-109 may carry the sample axis (the reference broadcasts
+ * all of them to S, components/variables/runtime_variable.py:96-118, exercised by its tests with sampled variables): sample s uses slice
+ * s of every operand with a non-zero sample stride (in elements; 0 = shared), incl. its own Kuu / q(u) core.
+ *   X (S|1,B,Q)  Y (S|1,B,P)  Z (S|1,M,Q)  noise_var (S|1,1)  qU_mean (S|1,M,P)  qU_cov_W (S|1,M,M)  qU_cov_diag (S|1,M)
+ *   lengthscale (S|1,Q|1)  variance (S|1,1)
+ * outputs: logL (S), info (S ints).  If want_grad: dX (S,B,Q) dY (S,B,P) dZ (S,M,Q) dnoise (S) dmu (S,M,P) dW (S,M,M) dSdiag (S,M)
+ * dls (S,Q|1) dvar (S), all WRITTEN: slice s = gradient of gscale * logL[s] w.r.t. the operands sample s used (a shared operand's
+ * gradient is the sum of its slices).                                                                                            */
+int mxf_svgp_logpdf_sampled(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                            const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y, const void* Z, int64_t strideS_Z,
+                            const void* noise_var, int64_t strideS_noise, const void* qU_mean, int64_t strideS_mu,
+                            const void* qU_cov_W, int64_t strideS_W, const void* qU_cov_diag, int64_t strideS_sd,
+                            const void* lengthscale, int ard, int64_t strideS_ls, const void* variance, int64_t strideS_var,
+                            double jitter, double scaling, double gscale, void* logL, int* info, int want_grad,
+                            void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag, void* dls, void* dvar,
+                            void* stream);
 
 /* The same bound with heteroscedastic and/or per-output noise (svgp_regression.py:61-67: noise_var of shape (N, D'), D' in {1, D};
  * testing/modules/svgpregression_test.py:142-167).  noise_var is (noise_rows, noise_cols) with noise_rows in {1, B} and noise_cols in {1, P},

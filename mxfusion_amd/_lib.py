@@ -41,6 +41,8 @@ SIGNATURES = {
                       _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_logpdf': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp,
                         _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'mxf_svgp_logpdf_sampled': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i64,
+                                _vp, _i64, _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_f32x3_split': [_i64, _i64, _vp, _i64, _vp, _vp],
     'mxf_gemm_f32x3_planes': [_i64, _i64, _i64, _d, _vp, _vp, _d, _vp, _i64, _i, _vp],
     'mxf_gemm_f32x3': [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i, _vp],
@@ -56,6 +58,7 @@ SIGNATURES = {
     'mxf_sgp_logpdf': [_i, _i, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i,
                        _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_last_cond': [_c.POINTER(_d)],
+    'mxf_svgp_cond_nowait': [_c.POINTER(_d), _i],
     'mxf_comm_unique_id': [_vp],
     'mxf_comm_init': [_i, _i, _vp],
     'mxf_allreduce_sum': [_i, _vp, _i64, _vp],
@@ -126,6 +129,14 @@ def workspace_generation(device_index):
     """Re-allocation count of the (thread, device) handle's scratch (mxf_workspace_generation): hipGraph holders compare it before a
     replay -- a captured launch carries the scratch addresses of capture time."""
     return int(load().mxf_workspace_generation(handle(device_index)))
+
+
+def svgp_cond_nowait(device_index, reset=False):
+    """Running maximum of cond_1(Kuu + jitter I) over the SVGP training calls finished so far on this (thread, device) handle
+    (mxf_svgp_cond_nowait: a read of pinned host memory, no synchronisation)."""
+    out = _d(0.0)
+    call('mxf_svgp_cond_nowait', handle(device_index), ctypes.byref(out), int(bool(reset)))
+    return float(out.value)
 
 
 def svgp_last_cond(device_index):

@@ -60,14 +60,14 @@ class ConditionalGaussianProcess(Distribution):
             random_variable = random_variable - mean
         resid = (random_variable - rv_mean).sum(-1, keepdim=True)
         logL, _, _, info2 = CholLogPdfFn.apply(cov, resid, float(D))
-        self._last_info = info + info2
+        self._last_info = ops.merge_info(info, info2)
         return logL * self.log_pdf_scaling
 
     def draw_samples_impl(self, X, X_cond, Y_cond, rv_shape, num_samples=1, F=None, **kernel_params):
         """cond_gp.py:185-223."""
         cov, rv_mean, mean, info = self._moments(F, X, X_cond, Y_cond, dict(kernel_params))
         L, info2 = chol(cov)
-        self._last_info = info + info2
+        self._last_info = ops.merge_info(info, info2)
         out_shape = (num_samples,) + tuple(rv_shape)
         die = self._rand_gen.sample_normal(shape=out_shape, dtype=X.dtype, ctx=X.device)
         rv = gemm(L, die.reshape(out_shape).contiguous()) + rv_mean

@@ -769,10 +769,14 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
     static const int tiles_env = MXF_KNOB("MXF_POTRF_TILES", 1);
     // tiles_env: 0 = launch-per-panel form everywhere, 1 = the tile kernel (one launch up to MXF_POTRF_ONE_MAX = 512, per outer panel beyond), 2 = only its one-launch form
+    // The tile kernel's workgroups hand tiles to each other through progress counters: every workgroup of a launch must be RESIDENT at once
+    // (one per CU: 256 threads at one wave per SIMD, ~76 KB of LDS), or a waiting workgroup could hold the CU its producer needs.  The grid
+    // (block rows x batch) is therefore bounded by the CU count of the device; larger problems take the launch-per-panel form below.
+    static const int ncu = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 64; return v; }();
     const bool tiles_ok = sizeof(T) == 8 && tiles_env && n % NB == 0 && n >= 2 * NB && S <= 64;
     if constexpr (sizeof(T) == 8) {
         static const int one_max = MXF_KNOB("MXF_POTRF_ONE_MAX", 512);
-        if (tiles_ok && n <= one_max) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
+        if (tiles_ok && n <= one_max && (int64_t)(n / NB) * S <= ncu) {    // (n = 2048 as ONE left-looking launch: 2.6 ms vs 1.9 -- the last block rows carry 32 i^2 columns of products each)
             const unsigned nbk = (unsigned)(n / NB);
             int* progress = mxf_flags(h, (nbk + 1) * (unsigned)S);
             if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
@@ -784,7 +788,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
             return 0;
         }
     }
-    const bool panel_tiles = tiles_ok && tiles_env == 1 && n / NB <= 256;      // every block row's workgroup must be resident at once
+    const bool panel_tiles = tiles_ok && tiles_env == 1 && (int64_t)(n / NB) * S <= ncu;      // every block row's workgroup must be resident at once
     static const int look_env = MXF_KNOB("MXF_POTRF_LOOKAHEAD", 2);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);

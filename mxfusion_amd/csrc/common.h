@@ -33,6 +33,7 @@ struct mxf_ctx {
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
     double* cond_dev = nullptr; // [ |Kuu + jitter I|_1, |(Kuu + jitter I)^-1|_1 ] of the last SVGP training call (mxf_svgp_last_cond)
+    double* cond_host = nullptr; // pinned, device-visible host word: running MAX of the condition numbers the training calls published (mxf_svgp_cond_nowait)
     void* bwd_acc = nullptr;   // scratch of the MFMA reverse pass (gram_bwd.hip): float64 row-side sums [M][16] + 16, scaled coordinates
     size_t bwd_acc_bytes = 0;
     void* comm = nullptr;      // RCCL communicator of mxf_comm_init (comm.hip); nullptr on single-GPU handles
@@ -72,7 +73,9 @@ static inline int* mxf_flags(mxf_ctx* h, unsigned count) {
     return p;
 }
 
-// ring allocator of the Cholesky tile kernel's inverse blocks (a region is reused only after the ring wrapped: >= 32 launches later)
+// ring allocator of the Cholesky tile kernel's inverse blocks: the ring holds at least two regions of the largest request, so a region is
+// reused no earlier than the launch after next ON THE SAME STREAM -- by then its readers (the previous launch) have finished in stream order.
+// (Two streams factoring through ONE handle would share the ring: the C ABI's rule is one handle per thread and calls not re-entrant.)
 static inline double* mxf_potrf_inv(mxf_ctx* h, size_t elems) {
     if (elems * 2 > h->pinv_elems) {
         if (h->pinv) { (void)hipDeviceSynchronize(); (void)hipFree(h->pinv); h->pinv = nullptr; h->pinv_elems = 0; }

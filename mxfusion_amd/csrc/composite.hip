@@ -529,6 +529,28 @@ __global__ __launch_bounds__(256) void norm1_sym_kernel(int64_t n, const double*
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, s));
 }
 
+// the training call's last launch: cond_1(Kuu + jitter I) = |K|_1 |K^-1|_1 of this call folded into the running maximum the host can read
+// without synchronising (pinned, device-visible memory; mxf_svgp_cond_nowait)
+__global__ void cond_publish_kernel(const double* __restrict__ cond_dev, double* __restrict__ host_max) {
+    const double c = cond_dev[0] * cond_dev[1];
+    if (c > *host_max) *host_max = c;
+    __threadfence_system();
+}
+
+// |A|_1 (see norm1_sym_kernel) with 16 rows per workgroup: n / 16 same-address atomics instead of n
+__global__ __launch_bounds__(256) void norm1_sym16_kernel(int64_t n, const double* __restrict__ A, int64_t lda, double* __restrict__ out) {
+    __shared__ double red[16];
+    double best = 0;
+    for (int64_t row = (int64_t)blockIdx.x * 16; row < (int64_t)blockIdx.x * 16 + 16 && row < n; ++row) {
+        double s = 0;
+        for (int64_t j = threadIdx.x; j < n; j += 256) s += fabs(A[row * lda + j]);
+        s = block_sum<double>(s, red);
+        best = s > best ? s : best;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, best));
+}
+
 template <typename T>
 int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P, const T* X, int64_t sX, const T* Y,
                       int64_t sY, const T* Z, const T* noise, int64_t nrows, int ncols, const T* mu, const T* W, const T* sdiag, const T* ls, int ard, const T* var,
@@ -697,15 +719,19 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
     // condition number of Kuu + jitter I (1-norm), for the float32 validity check of mxf_svgp_last_cond: |Kuu|_1 here, |Ki|_1 below
     if (!h->cond_dev && hipMalloc((void**)&h->cond_dev, 2 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
+    if (!h->cond_host) {
+        if (hipHostMalloc((void**)&h->cond_host, sizeof(double), hipHostMallocMapped) != hipSuccess) { h->cond_host = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the pinned condition word"); }
+        *h->cond_host = 0.0;
+    }
     MXF_HIP(h, hipMemsetAsync(h->cond_dev, 0, 2 * sizeof(double), st));
-    hipLaunchKernelGGL(norm1_sym_kernel, dim3((unsigned)M), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
+    hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false);                            // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
-    hipLaunchKernelGGL(norm1_sym_kernel, dim3((unsigned)M), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
+    hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
@@ -900,6 +926,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         }
     }
     if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, (const double*)h->cond_dev, h->cond_host);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
     MXF_LAUNCH_CHECK(h);
     return 0;
@@ -1139,6 +1166,38 @@ extern "C" int mxf_svgp_logpdf(mxf_handle h, int kind, int dtype, int S, int64_t
     return svgp_dispatch(h, "mxf_svgp_logpdf", kind, dtype, S, B, M, Q, P, X, strideS_X, Y, strideS_Y, Z, noise_var, 1, 1, qU_mean, qU_cov_W,
                          qU_cov_diag, lengthscale, ard, variance, jitter, scaling, gscale, logL, info, want_grad, dX, dY, dZ, dnoise, dmu, dW,
                          dSdiag, dls, dvar, stream);
+}
+
+// Sampled hyper-parameters / inducing inputs / q(u) (runtime_variable.py:96-118: every operand may carry its own sample axis; the
+// reference broadcasts them all to S and evaluates S independent bounds).  ONE call: sample s uses slice s of every operand whose sample
+// stride is non-zero (stride 0 = shared), its own (M x M) core included; the samples run back to back on the caller's stream with the
+// handle's scratch reused.  Every gradient output carries the sample axis (slice s = gradient of gscale * logL[s] with respect to the
+// operands sample s used): a caller whose operand was shared sums its slices.
+extern "C" int mxf_svgp_logpdf_sampled(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,
+                                       const void* X, int64_t strideS_X, const void* Y, int64_t strideS_Y, const void* Z, int64_t strideS_Z,
+                                       const void* noise_var, int64_t strideS_noise, const void* qU_mean, int64_t strideS_mu,
+                                       const void* qU_cov_W, int64_t strideS_W, const void* qU_cov_diag, int64_t strideS_sd,
+                                       const void* lengthscale, int ard, int64_t strideS_ls, const void* variance, int64_t strideS_var,
+                                       double jitter, double scaling, double gscale, void* logL, int* info, int want_grad,
+                                       void* dX, void* dY, void* dZ, void* dnoise, void* dmu, void* dW, void* dSdiag, void* dls, void* dvar,
+                                       void* stream) {
+    if (!h) return -1;
+    if (S <= 0) MXF_FAIL(h, -2, "mxf_svgp_logpdf_sampled: bad shape");
+    if (dtype != MXF_F32 && dtype != MXF_F64) MXF_FAIL(h, -2, "mxf_svgp_logpdf_sampled: bad dtype %d", dtype);
+    const int64_t e = (int64_t)mxf_esize(dtype), lsn = ard ? Q : 1;
+    auto at = [&](const void* p, int64_t off) -> const void* { return p ? (const void*)((const char*)p + off * e) : nullptr; };
+    auto atw = [&](void* p, int64_t off) -> void* { return p ? (void*)((char*)p + off * e) : nullptr; };
+    for (int s = 0; s < S; ++s) {
+        const int rc = svgp_dispatch(h, "mxf_svgp_logpdf_sampled", kind, dtype, 1, B, M, Q, P, at(X, s * strideS_X), 0, at(Y, s * strideS_Y), 0,
+                                     at(Z, s * strideS_Z), at(noise_var, s * strideS_noise), 1, 1, at(qU_mean, s * strideS_mu),
+                                     at(qU_cov_W, s * strideS_W), at(qU_cov_diag, s * strideS_sd), at(lengthscale, s * strideS_ls), ard,
+                                     at(variance, s * strideS_var), jitter, scaling, gscale, atw(logL, s), info ? info + s : nullptr, want_grad,
+                                     atw(dX, (int64_t)s * B * Q), atw(dY, (int64_t)s * B * P), atw(dZ, (int64_t)s * M * Q), atw(dnoise, s),
+                                     atw(dmu, (int64_t)s * M * P), atw(dW, (int64_t)s * M * M), atw(dSdiag, (int64_t)s * M), atw(dls, (int64_t)s * lsn),
+                                     atw(dvar, s), stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int mxf_svgp_logpdf_het(mxf_handle h, int kind, int dtype, int S, int64_t B, int64_t M, int Q, int P,

@@ -25,6 +25,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->gsync) (void)hipFree(h->gsync);
     if (h->pinv) (void)hipFree(h->pinv);
     if (h->cond_dev) (void)hipFree(h->cond_dev);
+    if (h->cond_host) (void)hipHostFree(h->cond_host);
     if (h->bwd_acc) (void)hipFree(h->bwd_acc);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -46,6 +47,13 @@ extern "C" const char* mxf_last_error(mxf_handle h) { return h ? h->err.c_str() 
 extern "C" int64_t mxf_workspace_bytes(mxf_handle h) { return h ? (int64_t)(h->ws_bytes + h->gram_ws_bytes + h->bwd_acc_bytes + h->pinv_elems * sizeof(double)) : -1; }
 
 extern "C" int64_t mxf_workspace_generation(mxf_handle h) { return h ? h->ws_generation : -1; }
+
+extern "C" int mxf_svgp_cond_nowait(mxf_handle h, double* cond1_max_out, int reset) {
+    if (!h || !cond1_max_out) return -1;
+    *cond1_max_out = h->cond_host ? *(volatile double*)h->cond_host : 0.0;      // no synchronisation: whatever the finished calls have published
+    if (reset && h->cond_host) *(volatile double*)h->cond_host = 0.0;
+    return 0;
+}
 
 extern "C" int mxf_svgp_last_cond(mxf_handle h, double* cond1_out) {
     if (!h || !cond1_out) return -1;

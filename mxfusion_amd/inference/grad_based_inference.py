@@ -43,8 +43,10 @@ class GradBasedInference(Inference):
 
     def _check_float32_validity(self):
         """The float32 streaming form of the SVGP bound applies Kuu^-1 explicitly: its rounding error grows like cond(Kuu + jitter I) 2^-24
-        (ELBO agreement with float64: 3e-6 at cond 1.4e3, 2e-3 at 5e4).  After a float32 run, warn when the model has left that regime --
-        the reference's dtype switch (config.DEFAULT_DTYPE / dtype='float64') is the remedy, as in its own GP tests."""
+        (ELBO agreement with float64: 3e-6 at cond 1.4e3, 2e-3 at 5e4).  The SVGP module guards itself while it runs
+        (modules/gp_modules/_fused.py: Float32Guard -- above the limit the streaming stage switches to float64 automatically); this records
+        what happened for the caller: `last_kuu_condition` (largest condition number the run's calls published) and
+        `float32_fallback_active`."""
         if config.torch_dtype(self.dtype) != torch.float32 or not torch.cuda.is_available():
             return
         from ..modules.gp_modules.svgp_regression import SVGPRegression
@@ -56,15 +58,19 @@ class GradBasedInference(Inference):
         if isinstance(ctx, torch.device) and ctx.type != 'cuda':
             return
         from .. import ops
+        from ..modules.gp_modules._fused import Float32Guard
         try:                                   # a diagnostic: it must never fail a finished run
-            cond = ops.svgp_last_cond(ctx)
+            torch.cuda.synchronize()
+            cond = max(ops.svgp_cond_nowait(ctx), ops.svgp_last_cond(ctx))
         except Exception:                      # noqa: BLE001
             return
         self.last_kuu_condition = cond
-        if cond > self.F32_COND_LIMIT:
+        self.float32_fallback_active = bool(Float32Guard.active)
+        if cond > self.F32_COND_LIMIT and not Float32Guard.enabled:
             import warnings
             warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e after this float32 run: beyond ~%.0e the float32 streaming SVGP bound '
-                          'loses accuracy (error ~ cond * 2^-24); run the inference with dtype=\'float64\'.' % (cond, self.F32_COND_LIMIT))
+                          'loses accuracy (error ~ cond * 2^-24) and the automatic float64 fallback is disabled; run the inference with '
+                          'dtype=\'float64\'.' % (cond, self.F32_COND_LIMIT))
 
 
 class GradTransferInference(GradBasedInference):

@@ -57,6 +57,60 @@ class GPLogPdfFn(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+class Float32Guard(object):
+    """Validity of the float32 streaming form of the SVGP bound.  The float32 training call applies
+    H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1 explicitly, so its rounding error grows like cond_1(Kuu + jitter I) 2^-24: 5e-8 ... 5e-6 on the ELBO up to
+    cond ~ 1.4e3, 2e-3 at 5e4 (tests/probes/f32_accuracy.py) -- beyond LIMIT the 1e-5 parity bar is out of reach in float32.  (A factorised
+    float32 form was costed instead of guessed: the cancellation sits in k_n^T (H0 k_n) itself, so only q_n = v_n^T (I - A_s A_s^T) v_n with
+    v_n = L^-1 k_n avoids it, which needs three full-width GEMMs plus two passes over them, ~2.5x the step, against the reference's own
+    remedy -- float64, svgp_regression.py:83-92 solves in the model's dtype -- at 5.8x.)
+
+    Every training call publishes its condition number into pinned host memory as its last launch (mxf_svgp_cond_nowait); the guard polls
+    that word before each float32 call -- no synchronisation, it lags by the calls still in flight -- and once the limit is crossed every
+    further float32 SVGP call of the process runs its streaming stage in FLOAT64 (inputs widened, outputs narrowed; same C-ABI call with
+    dtype = f64), with one warning.  The first training call of a process is checked synchronously, so a model that STARTS ill-conditioned is
+    never evaluated in float32 at all."""
+    LIMIT = 3e3
+    enabled = True
+    active = False          # sticky: the float64 fallback is on
+    _checked_first = False
+
+    @classmethod
+    def reset(cls):
+        cls.active, cls._checked_first = False, False
+
+    @classmethod
+    def _trip(cls, cond):
+        if not cls.active:
+            import warnings
+            warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e exceeds %.0e: the float32 streaming form of the SVGP bound loses '
+                          'accuracy there (error ~ cond * 2^-24); its streaming stage runs in float64 from now on.' % (cond, cls.LIMIT))
+        cls.active = True
+
+    @classmethod
+    def use_f64(cls, dev):
+        """Called before a float32 training call; True -> run it in float64."""
+        if not cls.enabled:
+            return False
+        if not cls.active:
+            c = ops.svgp_cond_nowait(dev)
+            if c > cls.LIMIT:
+                cls._trip(c)
+        return cls.active
+
+    @classmethod
+    def after_first_call(cls, dev):
+        """Synchronous check after the very first float32 training call; True -> its result must be recomputed in float64."""
+        if not cls.enabled or cls._checked_first:
+            return False
+        cls._checked_first = True
+        c = ops.svgp_last_cond(dev)
+        if c > cls.LIMIT:
+            cls._trip(c)
+            return True
+        return False
+
+
 class SVGPLogPdfFn(torch.autograd.Function):
     """mxf_svgp_logpdf.  Gradients are produced for mean_S(logL) (the only reduction the reference applies to a
     module's log-pdf, factor_graph.py:233) and scaled by sum(grad_output) in backward."""
@@ -65,11 +119,45 @@ class SVGPLogPdfFn(torch.autograd.Function):
     def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
         want = any(ctx.needs_input_grad[4:])
         S = max(X.shape[0], Y.shape[0])
-        r = ops.svgp_logpdf(kind, X, Y, Z[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1), ard,
-                            jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+
+        def run(cast):
+            a = [cast(t) for t in (X, Y, Z[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1))]
+            return ops.svgp_logpdf(kind, *a, ard, jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+        guard = want and X.is_cuda and X.dtype == torch.float32
+        if guard and Float32Guard.use_f64(X.device):
+            r = {k: (v.float() if v.is_floating_point() else v) for k, v in run(lambda t: t.double()).items()}
+        else:
+            r = run(lambda t: t)
+            if guard and Float32Guard.after_first_call(X.device):
+                r = {k: (v.float() if v.is_floating_point() else v) for k, v in run(lambda t: t.double()).items()}
         if want:
             ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'], r['dls'], r['dvar'])
             ctx.shapes = tuple(t.shape for t in (X, Y, Z, noise, mu, W, sdiag, ls, var))
+        ctx.mark_non_differentiable(r['info'])
+        return r['logL'], r['info']
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        c = _uniform_weight(g)
+        return (None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:], c)
+
+
+class SVGPSampledLogPdfFn(torch.autograd.Function):
+    """mxf_svgp_logpdf_sampled: ONE call for S samples of any of the operands (sampled hyper-parameters, inducing inputs, q(u); the
+    reference broadcasts them to S, runtime_variable.py:96-118).  The call returns per-sample gradients; an operand that was shared
+    (sample axis 1) receives their sum."""
+
+    @staticmethod
+    def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
+        want = any(ctx.needs_input_grad[4:])
+        ins = (X, Y, Z, noise, mu, W, sdiag, ls, var)
+        S = max(t.shape[0] for t in ins)
+        r = ops.svgp_logpdf_sampled(kind, X, Y, Z, noise.reshape(noise.shape[0], 1), mu, W, sdiag, ls, var.reshape(var.shape[0], 1), ard, jitter=jitter,
+                                    scaling=scaling, gscale=1.0 / S, want_grad=want)
+        if want:
+            keys = ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')
+            ctx.grads = tuple(r[k].reshape((S,) + tuple(t.shape[1:])) if t.shape[0] == S else r[k].sum(0).reshape(t.shape) for k, t in zip(keys, ins))
+            ctx.shapes = tuple(t.shape for t in ins)
         ctx.mark_non_differentiable(r['info'])
         return r['logL'], r['info']
 

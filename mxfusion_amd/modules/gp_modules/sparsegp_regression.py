@@ -82,7 +82,7 @@ class SparseGPRegressionLogPdf(VariationalInference):
         logL = logL + ((LAInvLinvKufY ** 2) / (2 * nv ** 2)).sum(-1).sum(-1)                                      # :96
         logL = logL - D * (Kff_diag / (2 * noise_var)).sum(-1)                                                    # :97
         logL = logL + D * ((LinvKuf ** 2) / (2. * nv)).sum(-1).sum(-1)                                            # :98
-        self._last_info = info + info2
+        self._last_info = ops.merge_info(info, info2)
         with torch.no_grad():      # :99-106 persist sample 0 only
             wv = ops.trsm_(L[:1].contiguous(), ops.trsm_(LA[:1].contiguous(), LAInvLinvKufY[:1].detach().contiguous().clone(), transpose=True),
                            transpose=True) / nv[:1]

@@ -16,7 +16,7 @@ from ...inference.inference_alg import SamplingAlgorithm
 from ...inference.variational import VariationalInference
 from ..module import Module, ModuleGraph
 from ...inference.forward_sampling import ForwardSamplingAlgorithm
-from ._fused import SVGPLogPdfFn, SVGPMatLogPdfFn
+from ._fused import SVGPLogPdfFn, SVGPMatLogPdfFn, SVGPSampledLogPdfFn
 from ._sampling_graph import build_sparse_gp_sampling_model
 from ...components.distributions.gp import _linalg as lin
 from .gp_regression import _grad_mode
@@ -63,7 +63,7 @@ class SVGPRegressionLogPdf(VariationalInference):
                                              kern, kern_params)
                 infos.append(self._last_info)
                 total = part if total is None else total + part
-            self._last_info = torch.stack(infos).sum(0)
+            self._last_info = ops.merge_info(*infos)
             return total
         return self._compute_columns(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
 
@@ -78,15 +78,19 @@ class SVGPRegressionLogPdf(VariationalInference):
         scaling = float(self.log_pdf_scaling)
         if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
             logL, info = SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
+        elif noise_var.numel() == noise_var.shape[0] and Y.shape[-1] <= self.PMAX:
+            # sampled hyper-parameters / inducing inputs / q(u) (runtime_variable.py:96-118 broadcast semantics): ONE fused call with a sample
+            # stride per operand (mxf_svgp_logpdf_sampled; the reference's test_log_pdf_w_samples_* pattern, svgpregression_test.py:142-167)
+            logL, info = SVGPSampledLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
+            info = ops.merge_info(*info.reshape(-1, 1))
         else:
-            # sampled hyper-parameters / inducing inputs (runtime_variable.py:102-118 broadcast semantics): one fused
-            # call per sample, each with its own parameter slice
+            # sampled parameters together with per-point / per-output noise: one heteroscedastic call per sample
             S = max(_S(t) for t in (X, Y) + shared)
             pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
             outs = [SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, pick(X, s), pick(Y, s), *[pick(t, s) for t in shared])
                     for s in range(S)]
             logL = torch.cat([o[0] for o in outs])
-            info = torch.stack([o[1] for o in outs]).sum(0)
+            info = ops.merge_info(*[o[1] for o in outs])
         self._last_info = info
         return logL
 
@@ -106,7 +110,7 @@ class SVGPRegressionLogPdf(VariationalInference):
         S = max(_S(t) for t in ops_in)
         pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
         outs = [SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *[pick(t, s) for t in ops_in]) for s in range(S)]
-        self._last_info = torch.stack([o[1] for o in outs]).sum(0)
+        self._last_info = ops.merge_info(*[o[1] for o in outs])
         return torch.cat([o[0] for o in outs])
 
 

@@ -183,13 +183,25 @@ def potrf_(A, info=None):
     return A, info
 
 
+def merge_info(*infos):
+    """Combine LAPACK-style info words of several factorisations WITHOUT masking: a negative word (an internal failure of the library, e.g.
+    a lost workgroup hand-off of the tile Cholesky) wins over everything, otherwise the largest positive one (first non-positive-definite
+    leading minor); 0 only if all are 0.  (A plain sum turns -1 + 1 into "fine".)"""
+    st = torch.stack([i.reshape(-1) if i.numel() > 1 else i.reshape(1) for i in infos])
+    lo, hi = st.min(0).values, st.max(0).values
+    return torch.where(lo < 0, lo, hi)
+
+
 def check_info(info, what='potrf'):
-    """Host sync + raise on a non-positive-definite matrix (MXNet raises lazily at the next blocking read)."""
+    """Host sync + raise on a non-positive-definite matrix (MXNet raises lazily at the next blocking read); a NEGATIVE word is an internal
+    failure of the factorisation kernels and always an error."""
     bad = info.nonzero()
     if bad.numel():
         s = int(bad[0, 0])
-        raise _lib.MXFError('%s: matrix of sample %d is not positive definite (leading minor %d)'
-                            % (what, s, int(info[s])))
+        v = int(info.reshape(-1)[s])
+        if v < 0:
+            raise _lib.MXFError('%s: internal failure of the factorisation of sample %d (info %d: a workgroup hand-off was lost)' % (what, s, v))
+        raise _lib.MXFError('%s: matrix of sample %d is not positive definite (leading minor %d)' % (what, s, v))
 
 
 def trsm_(L, B, transpose=False):
@@ -349,6 +361,37 @@ def svgp_logpdf(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, length
     return out
 
 
+def svgp_logpdf_sampled(kind, X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance, ard, jitter=0.0, scaling=1.0,
+                        gscale=1.0, want_grad=False):
+    """mxf_svgp_logpdf_sampled: the homoscedastic bound with any operand sampled.  Every operand carries a leading sample axis of size S or 1:
+    X (S|1,B,Q) Y (S|1,B,P) Z (S|1,M,Q) noise_var (S|1,1) qU_mean (S|1,M,P) qU_cov_W (S|1,M,M) qU_cov_diag (S|1,M) lengthscale (S|1,Q|1)
+    variance (S|1,1).  Returns logL (S,), info (S,) and -- if want_grad -- per-sample gradients (S, ...) of gscale * logL[s]."""
+    ops_in = [_c(t) for t in (X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance)]
+    X, Y, Z, noise_var, qU_mean, qU_cov_W, qU_cov_diag, lengthscale, variance = ops_in
+    S = max(t.shape[0] for t in ops_in)
+    if any(t.shape[0] not in (1, S) for t in ops_in):
+        raise ValueError('svgp_logpdf_sampled: sample axes must be 1 or %d' % S)
+    B, Q, P, M = X.shape[-2], X.shape[-1], Y.shape[-1], Z.shape[-2]
+    if noise_var.numel() != noise_var.shape[0]:
+        raise ValueError('svgp_logpdf_sampled: homoscedastic noise (S|1, 1) only')
+    dev, dt = X.device, X.dtype
+    st = lambda t: 0 if t.shape[0] == 1 else t[0].numel()
+    lsn = lengthscale[0].numel()
+    out = {'logL': torch.empty(S, dtype=dt, device=dev), 'info': torch.zeros(S, dtype=torch.int32, device=dev)}
+    g = {}
+    if want_grad:
+        E = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
+        g = {'dX': E(S, B, Q), 'dY': E(S, B, P), 'dZ': E(S, M, Q), 'dnoise': E(S, 1), 'dmu': E(S, M, P), 'dW': E(S, M, M), 'dSdiag': E(S, M),
+             'dls': E(S, lsn), 'dvar': E(S, 1)}
+    _lib.call('mxf_svgp_logpdf_sampled', _h(X), KIND[kind], _dt(X), S, B, M, Q, P, _p(X), st(X), _p(Y), st(Y), _p(Z), st(Z), _p(noise_var), st(noise_var),
+              _p(qU_mean), st(qU_mean), _p(qU_cov_W), st(qU_cov_W), _p(qU_cov_diag), st(qU_cov_diag), _p(lengthscale), int(bool(ard)), st(lengthscale),
+              _p(variance), st(variance), float(jitter), float(scaling), float(gscale), _p(out['logL']), _p(out['info']), int(want_grad),
+              _p(g.get('dX')), _p(g.get('dY')), _p(g.get('dZ')), _p(g.get('dnoise')), _p(g.get('dmu')), _p(g.get('dW')), _p(g.get('dSdiag')),
+              _p(g.get('dls')), _p(g.get('dvar')), _stream())
+    out.update(g)
+    return out
+
+
 def _device_index(device):
     """CUDA device index of `device` (None / torch.device('cuda') without an index -> the current device; int / torch.device / str)."""
     if device is None:
@@ -360,6 +403,12 @@ def _device_index(device):
             raise ValueError('mxfusion_amd: %r is not a GPU device' % (device,))
         return device.index if device.index is not None else torch.cuda.current_device()
     return int(device)
+
+
+def svgp_cond_nowait(device=None, reset=False):
+    """Running maximum of the condition numbers published by the finished svgp_logpdf training calls of this thread on `device`; does not
+    synchronise (mxf_svgp_cond_nowait)."""
+    return _lib.svgp_cond_nowait(_device_index(device), reset)
 
 
 def svgp_last_cond(device=None):

@@ -15,3 +15,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_float32_guard():
+    """The float32 guard of the SVGP module is process-wide and sticky (modules/gp_modules/_fused.py): every test starts with it cleared."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+            from mxfusion_amd import ops
+            Float32Guard.reset()
+            ops.svgp_cond_nowait(reset=True)
+    except Exception:       # noqa: BLE001 -- CPU-only runs, library absent: nothing to reset
+        pass
+    yield
