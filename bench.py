@@ -412,6 +412,20 @@ def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     return _finish_timing(t0, distributed) + (float(loss.detach()),)
 
 
+def _pmc_traffic(stem):
+    """(bytes per launch, source) from the newest profiles/r<NN>_<stem>.json that holds `hbm_traffic_bytes_per_launch`, else (None, None)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % stem)), reverse=True):
+        try:
+            with open(f) as fh:
+                pj = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if 'hbm_traffic_bytes_per_launch' in pj:
+            return int(pj['hbm_traffic_bytes_per_launch']), 'profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)' % os.path.basename(f)
+    return None, None
+
+
 def gram_roofline(N, Q, dtype, reps=40):
     """RBF Gram at N x N, Q: algorithmic bytes = N*N*sizeof written + 2*N*Q*sizeof read, timed with HIP
     events on the stream the kernel is launched on (torch's current stream).  40 timed launches behind 2 untimed ones: the first launch
@@ -436,16 +450,10 @@ def gram_roofline(N, Q, dtype, reps=40):
     del out
     torch.cuda.empty_cache()
     # HBM bytes per launch from the PMC passes of exactly this launch (separate rocprofv3 --pmc runs, WRITE_SIZE * 1024 + 2 * FETCH_SIZE *
-    # 1024 as MI355X_MICROARCH.md prescribes for gfx950): read from the committed summary profiles/r02_gram_pmc.json (produced by
-    # profiles/run_profiles_r02.sh + profiles/pmc_summary.py); only collected for the headline shape / dtype.  null if the file is absent.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, 'profiles', 'r02_gram_pmc.json')
-    if N == 65536 and Q == 8 and dtype == 'float32' and os.path.exists(pmc):
-        with open(pmc) as f:
-            pj = json.load(f)
-        if 'hbm_traffic_bytes_per_launch' in pj:
-            traffic, traffic_src = int(pj['hbm_traffic_bytes_per_launch']), 'profiles/r02_gram_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE)'
-    return {"bound": "hbm", "kernel": "gram_lean_kernel<%s,8,RBF> N=%d Q=%d" % (dtype, N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
+    # 1024 as MI355X_MICROARCH.md prescribes for gfx950): read from the NEWEST committed summary profiles/r<NN>_gram_pmc.json (produced by
+    # profiles/run_profiles_r<NN>.sh + profiles/pmc_summary.py); only collected for the headline shape / dtype.  null if there is none.
+    traffic, traffic_src = _pmc_traffic('gram_pmc') if (N == 65536 and Q == 8 and dtype == 'float32') else (None, None)
+    return {"bound": "hbm", "kernel": "gram_lean_kernel<%s,8,RBF,%s> N=%d Q=%d" % (dtype, "12 rows" if dtype == "float32" else "16 rows", N, Q), "achieved": nbytes / ms / 1e6, "peak": 8000.0,
             "unit": "GB/s", "frac": nbytes / ms / 1e6 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": ms,
             "algorithmic_bytes": nbytes, "write_only_pattern_ceiling_GBps": 6930.0,
             "ceiling_note": "fastest pure-store pattern measured on this part (tests/probes/gram_variants.hip, one row per workgroup): "
@@ -467,7 +475,7 @@ def mfma_roofline(M, SB, dtype, reps=3):
         out = torch.empty(M, SB, device='cuda')
         # as the training step runs it: T written in 16-column blocks (what the reverse pass reads), which puts it on the 128 x 256 kernel
         run = lambda: ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out, blocked=True)
-        name, peak, extra = "gemm_f16x2_wide_kernel (f32 = 2 scaled f16 terms, 3 MFMA products; C in 16-column blocks) %dx%dx%d" % (M, SB, M), 2500.0 / 3.0, \
+        name, peak, extra = "gemm_f16x2_wide_kernel_256 (f32 = 2 scaled f16 terms, 3 MFMA products; C in 16-column blocks) %dx%dx%d" % (M, SB, M), 2500.0 / 3.0, \
             {"peak_note": "dense f16 MFMA peak 2500 TFLOP/s / 3 products; the f32 MFMA peak is 157.3", "f32_mfma_peak": 157.3}
     else:
         A = torch.randn(1, M, M, device='cuda', dtype=torch.float64)
@@ -484,8 +492,9 @@ def mfma_roofline(M, SB, dtype, reps=3):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     torch.cuda.empty_cache()
+    traffic, traffic_src = _pmc_traffic('gemm_t_pmc') if (dtype == 'float32' and M == 1024 and SB == 2097152) else (None, None)
     r = {"bound": "mfma", "kernel": name, "achieved": fl / ms / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / peak,
-         "traffic": None, "ms_per_launch": ms, "algorithmic_flops": fl}
+         "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": ms, "algorithmic_flops": fl}
     r.update(extra)
     return r
 
@@ -510,9 +519,10 @@ def mfma_roofline_psi2(M, SB, reps=3):
     ms = e0.elapsed_time(e1) / reps
     torch.cuda.empty_cache()
     fl = 2.0 * (M * (M + 1) / 2.0) * SB
-    return {"bound": "mfma", "kernel": "gemm_f16x2_wide_kernel (lower blocks, split-K) %dx%dx%d" % (M, M, SB), "achieved": fl / ms / 1e9,
-            "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / (2500.0 / 3.0), "traffic": None, "ms_per_launch": ms,
-            "algorithmic_flops": fl}
+    traffic, traffic_src = _pmc_traffic('gemm_psi2_pmc') if (M == 1024 and SB == 2097152) else (None, None)
+    return {"bound": "mfma", "kernel": "gemm_f16x2_wide_kernel_256 (lower blocks, split-K) %dx%dx%d" % (M, M, SB), "achieved": fl / ms / 1e9,
+            "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / (2500.0 / 3.0), "traffic": traffic, "traffic_source": traffic_src,
+            "ms_per_launch": ms, "algorithmic_flops": fl}
 
 
 def cpu_baseline(N, Q, M, S, X, Y, Z):
@@ -646,7 +656,16 @@ def main():
                "config": {"workload": "GPRegression RBF-ARD N=%d Q=%d: Gram + potrf + trsm + closed-form reverse mode + Adam per step; "
                                       "dense N x N Cholesky does not shard (replicas only)" % (N, Q)},
                "last_loss": last_loss, "potrf_info": int(m.Y.factor.gp_log_pdf._last_info.abs().sum()),
-               "algorithmic_flops_per_step": N ** 3 / 3.0 + 2.0 * N ** 3 + 2.0 * N ** 3 / 3.0}
+               # the float64 MFMA work of a step as the library performs it: potrf N^3/3 + trtri N^3/3 + the lower triangle of
+               # K^-1 = L^-T L^-1 N^3/3 (the reverse mode needs K^-1; the solves against Y are N^2) = N^3 -- a roofline numerator for the
+               # 78.6 TFLOP/s float64 matrix peak (the dense-operator count 3 N^3 of r02 exceeded that peak: the kernels skip the
+               # triangular halves it counted)
+               "algorithmic_flops_per_step": float(N) ** 3}
+        if args.dtype == 'float64':
+            ach = float(N) ** 3 / (dt / args.steps) / 1e12
+            out["roofline_f64_mfma"] = {"bound": "mfma", "kernel": "potrf + trtri + lower L^-T L^-1 (float64 v_mfma_f64_16x16x4_f64)", "achieved": ach,
+                                        "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                                        "note": "whole step (incl. Gram, reverse pass, Adam) in the denominator"}
         if rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_gp(N, Q, X, Y)
         if rank == 0:

@@ -41,6 +41,9 @@ def check(lines, start):
             continue
         if op.startswith('global_load') or op.startswith('scratch_load') or op.startswith('buffer_load'):
             regs = vregs(s)
+            if not regs:                      # a spill reload into an AGPR / an address held in SGPRs only: no VGPR involved
+                pending.append(None)
+                continue
             dst, srcs = regs[0], regs[1:]
             for r in srcs:
                 if any(p and not (r[1] < p[0] or r[0] > p[1]) for p in pending):

@@ -762,8 +762,8 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 }
 
 template <typename T>
-int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper) {
-    if (info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
+int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info) {
+    if (info && zero_info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
     // that factorisation).  At n = 8192 the 128 panel steps (85 us each) otherwise serialise with 3.7 ms of trailing GEMMs.
@@ -903,10 +903,10 @@ int trsm_typed(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t n
 
 }  // namespace
 
-int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper) {
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info) {
     if (n <= 0 || S <= 0) return 0;
-    if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st, zero_upper);
-    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper);
+    if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st, zero_upper, zero_info);
+    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper, zero_info);
     MXF_FAIL(h, -2, "mxf_potrf: bad dtype %d", dtype);
 }
 

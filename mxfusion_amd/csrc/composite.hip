@@ -529,26 +529,44 @@ __global__ __launch_bounds__(256) void norm1_sym_kernel(int64_t n, const double*
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, s));
 }
 
+// the training call's first launch on the caller's stream: its status words (LAPACK info of the two factorisations, the split scale word)
+// cleared in ONE launch instead of a hipMemsetAsync each in front of the kernels of the critical chain (~10 us apiece there)
+__global__ void svgp_init_kernel(int* __restrict__ info, int* __restrict__ info2) {
+    if (threadIdx.x == 0 && info) info[0] = 0;
+    if (threadIdx.x < 4) info2[threadIdx.x] = 0;
+}
+
 // the training call's last launch: cond_1(Kuu + jitter I) = |K|_1 |K^-1|_1 of this call folded into the running maximum the host can read
 // without synchronising (pinned, device-visible memory; mxf_svgp_cond_nowait)
-__global__ void cond_publish_kernel(const double* __restrict__ cond_dev, double* __restrict__ host_max) {
+__global__ void cond_publish_kernel(double* __restrict__ cond_dev, double* __restrict__ host_max) {
     const double c = cond_dev[0] * cond_dev[1];
     if (c > *host_max) *host_max = c;
     __threadfence_system();
+    cond_dev[2] = cond_dev[0]; cond_dev[3] = cond_dev[1];       // kept for mxf_svgp_last_cond
+    cond_dev[0] = 0.0; cond_dev[1] = 0.0;                       // the next call's norm kernels accumulate with atomicMax: no memset in front of them
 }
 
-// |A|_1 (see norm1_sym_kernel) with 16 rows per workgroup: n / 16 same-address atomics instead of n
+// |A|_1 (see norm1_sym_kernel) with 16 rows per workgroup -- one row per wave at a time (coalesced loads + a DPP wave sum, no barrier per
+// row) and ONE atomic per workgroup: n / 16 same-address atomics instead of n (they serialise: 1024 of them were most of the 80 us this
+// took on the critical path in front of the Cholesky factorisation).
 __global__ __launch_bounds__(256) void norm1_sym16_kernel(int64_t n, const double* __restrict__ A, int64_t lda, double* __restrict__ out) {
-    __shared__ double red[16];
+    __shared__ double wmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double best = 0;
-    for (int64_t row = (int64_t)blockIdx.x * 16; row < (int64_t)blockIdx.x * 16 + 16 && row < n; ++row) {
+    for (int r = wave; r < 16; r += 4) {
+        const int64_t row = (int64_t)blockIdx.x * 16 + r;
+        if (row >= n) break;
         double s = 0;
-        for (int64_t j = threadIdx.x; j < n; j += 256) s += fabs(A[row * lda + j]);
-        s = block_sum<double>(s, red);
+        for (int64_t j = lane; j < n; j += 64) s += fabs(A[row * lda + j]);
+        s = wave_sum(s);
         best = s > best ? s : best;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, best));
+    if (lane == 0) wmax[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = wmax[w] > best ? wmax[w] : best;
+        atomicMax(reinterpret_cast<unsigned long long*>(out), __builtin_bit_cast(unsigned long long, best));
+    }
 }
 
 template <typename T>
@@ -622,6 +640,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // (W and diag(s) are converted on the second side stream, where Su is formed: two launches less in front of the Kuu chain)
     // (everything the Kuu chain does not need itself -- noise, mu, W, diag(s), the scalar accumulators -- is prepared on the second side
     //  stream, where Su is formed; the main stream waits for that stream's ev_su before it first touches them)
+    hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2);
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
     int rc;
@@ -718,14 +737,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
     // condition number of Kuu + jitter I (1-norm), for the float32 validity check of mxf_svgp_last_cond: |Kuu|_1 here, |Ki|_1 below
-    if (!h->cond_dev && hipMalloc((void**)&h->cond_dev, 2 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
+    if (!h->cond_dev) {
+        if (hipMalloc((void**)&h->cond_dev, 4 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
+        MXF_HIP(h, hipMemset(h->cond_dev, 0, 4 * sizeof(double)));
+    }
     if (!h->cond_host) {
         if (hipHostMalloc((void**)&h->cond_host, sizeof(double), hipHostMallocMapped) != hipSuccess) { h->cond_host = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the pinned condition word"); }
         *h->cond_host = 0.0;
     }
-    MXF_HIP(h, hipMemsetAsync(h->cond_dev, 0, 2 * sizeof(double), st));
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false);                            // L :83 (trtri / sumlogdiag read the lower triangle only)
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
@@ -741,8 +762,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
-    MXF_HIP(h, hipMemcpyAsync(tmp, Su, MM * sizeof(D), hipMemcpyDeviceToDevice, s2_));
-    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_, false);                         // Ls = chol(Su) :84
+    // (a plain kernel, not hipMemcpyAsync: the runtime's copy path sat idle for ~1 ms before it started next to busy queues -- r02 timeline:
+    //  the Su chain did not begin until 1.66 ms although nothing in the Kuu chain feeds it)
+    hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, s2_, (int64_t)1, MM, (const D*)Su, MM, tmp, MM);
+    rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_, false, false);                  // Ls = chol(Su) :84
     if (rc) return rc;
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, s2_);
     if (rc) return rc;
@@ -780,7 +803,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_is_mfma(dtype, SB, B, Q, P, Text)) ? 1 : 0;
     if (use_split) {
         unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
-        if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st); if (rc) return rc; }
+        if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st, false); if (rc) return rc; }      // (word cleared by svgp_init_kernel)
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st, split_mode, split_mode == MXF_SPLIT_F16X2 ? h0max : nullptr);
         if (rc) return rc;
     }
@@ -848,7 +871,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
                            (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
         MXF_LAUNCH_CHECK(h);
-        if (!want_grad) return 0;
+        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host); return 0; }
         // G' = 1/2 a1 Kuf diag(bs) Kuf^T (-> Psi2 slot), Gw = Kuf (a1 beta.e) (-> R slot), Kuf-side reverse mode from dKuf = Text
         rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Ksc, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
         if (rc) return rc;
@@ -880,7 +903,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
                            (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
         MXF_LAUNCH_CHECK(h);
-        if (!want_grad) return 0;
+        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host); return 0; }
     }
 
     if (het) {
@@ -902,7 +925,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL(aki_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)G, (const D*)T1, (const D*)Gw, (const D*)mud, (const D*)Su, bw, AKi);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, AKi, M, 0, 0.0, T2, M, 0, 1, 0, st);           // T2 = Ki A_Ki
     if (rc) return rc;
-    MXF_HIP(h, hipMemcpyAsync(dKuu, Ki, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, dKuu, MM);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
@@ -926,7 +949,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         }
     }
     if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
-    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, (const double*)h->cond_dev, h->cond_host);
+    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
     MXF_LAUNCH_CHECK(h);
     return 0;

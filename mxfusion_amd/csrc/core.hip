@@ -62,7 +62,7 @@ extern "C" int mxf_svgp_last_cond(mxf_handle h, double* cond1_out) {
     double v[2];
     // the norms are written by kernels on the caller's (possibly non-blocking) stream: a plain hipMemcpy orders against the null stream only
     MXF_HIP(h, hipDeviceSynchronize());
-    MXF_HIP(h, hipMemcpy(v, h->cond_dev, sizeof(v), hipMemcpyDeviceToHost));
+    MXF_HIP(h, hipMemcpy(v, h->cond_dev + 2, sizeof(v), hipMemcpyDeviceToHost));     // (words 2, 3: the finished call's norms; 0, 1 are the accumulators of the next)
     *cond1_out = v[0] * v[1];
     return 0;
 }

@@ -383,7 +383,7 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // second half starts one phase late, so on every SIMD one wave computes while its partner loads.  Without it both waves of a SIMD reach the
 // shared barrier together, want the matrix pipe together and then wait for LDS / memory together.
 template <int XT, int NH, bool PP>
-__global__ __launch_bounds__(256 * NH, (XT == 8 && NH == 1) ? 1 : 2) void gemm_f16x2_wide_kernel(SplitArgs g) {
+__device__ __forceinline__ void wide_body(const SplitArgs& g) {
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
     constexpr int WBMt = 32 * XT * NH;             // A rows per tile
     constexpr int NU = 64 * XT * NH;               // 16-byte units of one plane's (WBMt x 16) slab
@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256 * NH, (XT == 8 && NH == 1) ? 1 : 2) void gemm_f
     const int64_t kbeg = split * g.kchunk;
     const int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
     if (g.sync && g.sync_period == 0) wg_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
+    // (Measured and dropped, r03: skipping the MFMAs of the waves / 32 x 32 fragments that lie strictly above the diagonal of a lower-only
+    //  product -- 10 % / 17 % of Psi2's matrix work.  Any branch around the MFMA block costs the kernel its schedule: 231 -> 251 VGPRs with
+    //  the wave-uniform form, T 11.5 -> 12.5 ms although T never takes the branch; spills with the per-fragment form.)
 
     f32x16 c[XT][2];
 #pragma unroll
@@ -607,6 +610,14 @@ __global__ __launch_bounds__(256 * NH, (XT == 8 && NH == 1) ? 1 : 2) void gemm_f
     }   // work items
 }
 
+// The kernels:  _128: 128 x 256 tiles, two workgroups per CU;  _256 (the default for 256-aligned shapes): 256 x 256, eight waves in two row
+// halves;  _256w4: 256 x 256 by four 512-register waves;  _256pp: eight waves, ping-pong phases.  (The last two are measured alternatives
+// kept for the probe build)
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128(SplitArgs g) { wide_body<4, 1, false>(g); }
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_wide_kernel_256w4(SplitArgs g) { wide_body<8, 1, false>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g) { wide_body<4, 2, false>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
+
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
     if (col < N && !(lower_only && col > row)) {
@@ -619,8 +630,8 @@ __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, 
 
 size_t mxf_split_plane_elems(int64_t R, int64_t K) { return (size_t)((K + 15) / 16) * (size_t)R * 16; }
 
-int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st) {
-    MXF_HIP(h, hipMemsetAsync(out, 0, sizeof(unsigned), st));
+int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st, bool zero) {
+    if (zero) MXF_HIP(h, hipMemsetAsync(out, 0, sizeof(unsigned), st));
     const int64_t n = R * K;
     if (n <= 0) return 0;
     int64_t nb = (n + 256 * 16 - 1) / (256 * 16);
@@ -740,10 +751,10 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
             }
         }
         static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
-        if (NH == 2 && pp_env) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
-        else if (NH == 2) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 2, false>), dim3((unsigned)grid), dim3(512), 0, st, g);
-        else if (XT == 8) hipLaunchKernelGGL((gemm_f16x2_wide_kernel<8, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_f16x2_wide_kernel<4, 1, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
+        if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (XT == 8) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256w4, dim3((unsigned)grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128, dim3((unsigned)grid), dim3(256), 0, st, g);
         MXF_LAUNCH_CHECK(h);
         return 0;
     }

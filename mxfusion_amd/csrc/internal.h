@@ -10,7 +10,9 @@ int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t 
                       void* C, int64_t ldc, int64_t sC, int batch, int lower_only, hipStream_t st, int reserve_cus = 0, int k_from_m = 0);
 
 // zero_upper = false: leave the strict upper triangle outside the 64 x 64 diagonal blocks as it was (callers that only read the lower part)
-int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper = true);
+// zero_info = false: the caller has zeroed `info` already (the SVGP composite clears its status words in one launch off the critical path)
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper = true,
+                       bool zero_info = true);
 // rhs_lower: B is block-lower-triangular (trtri); only columns < (k+1)*64 of block row k are touched
 int mxf_trsm_internal(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t nrhs, const void* L, int64_t ldl,
                       int64_t sL, void* B, int64_t ldb, int64_t sB, int rhs_lower, hipStream_t st);
@@ -36,7 +38,7 @@ size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE
 // operand formats of the split GEMM (gemm_split.hip): three bf16 terms / two scaled f16 terms
 #define MXF_SPLIT_BF16X3 0
 #define MXF_SPLIT_F16X2 1
-int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st);   // out[0] = bit pattern of max |x|
+int mxf_maxabs_internal(mxf_ctx* h, int64_t R, int64_t K, const float* x, int64_t ld, unsigned* out, hipStream_t st, bool zero = true);   // out[0] = bit pattern of max |x| (zero = false: the caller cleared the word)
 int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, int64_t ld, unsigned short* planes, hipStream_t st,
                               int mode = MXF_SPLIT_BF16X3, const unsigned* maxbits = nullptr);
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,

@@ -187,7 +187,7 @@ def merge_info(*infos):
     """Combine LAPACK-style info words of several factorisations WITHOUT masking: a negative word (an internal failure of the library, e.g.
     a lost workgroup hand-off of the tile Cholesky) wins over everything, otherwise the largest positive one (first non-positive-definite
     leading minor); 0 only if all are 0.  (A plain sum turns -1 + 1 into "fine".)"""
-    st = torch.stack([i.reshape(-1) if i.numel() > 1 else i.reshape(1) for i in infos])
+    st = torch.stack(torch.broadcast_tensors(*[i.reshape(-1) for i in infos]))      # (one word per sample, or one for all of them)
     lo, hi = st.min(0).values, st.max(0).values
     return torch.where(lo < 0, lo, hi)
 
