@@ -588,6 +588,8 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
+    ap.add_argument('--no-f32-guard', action='store_true', help='disable the automatic float64 fallback of the float32 SVGP step above cond_1(Kuu) 3e3 '
+                                                                    '(DESIGN.md section 5): raw float32 timing of an ill-conditioned model')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to the C stdout at start-up (seen after the JSON when stdout
@@ -616,6 +618,17 @@ def main():
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         os.dup2(_json_fd, 1)                       # the children inherit the real stdout (rank 0 writes the one JSON line to it)
         raise SystemExit(subprocess.call(cmd, env=env))
+    if args.no_f32_guard:
+        from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+        Float32Guard.enabled = False
+
+    def guard_report():
+        """float32 validity of what was timed: the largest cond_1(Kuu + jitter I) the training calls published, and whether the SVGP module
+        switched its streaming stage to float64 (it does above 3e3)."""
+        from mxfusion_amd import ops
+        from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+        torch.cuda.synchronize()
+        return {"kuu_cond_max": ops.svgp_cond_nowait(), "float32_fallback_active": bool(Float32Guard.active), "float32_guard": bool(Float32Guard.enabled)}
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world != max(1, args.gpus) and not args.force_dist:
@@ -689,7 +702,7 @@ def main():
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
                 "config": {"workload": "deep GP: SVGPRegression(Matern52+RBF, Q=%d) -> H (N x %d, mean-field q(H)) -> SVGPRegression(RBF-ARD), N=%d, "
                                        "M=%d per layer, %d MC samples" % (Q, Dh, N, M, args.samples), "samples_per_gpu": S_local},
-                "last_loss": last_loss}, **rep))
+                "last_loss": last_loss}, **rep, **guard_report()))
         if distributed:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -712,7 +725,7 @@ def main():
                                          "(rv_scaling %g), %d MC samples, step = minibatch ELBO + reverse mode + grad all-reduce + Adam"
                                          % (N, Q, M, B, N / B, args.samples),
                              "samples_per_gpu": S_local, "parallelism": "mc-samples sharded x%d, 1 RCCL all-reduce of the flat gradient/step" % world},
-                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())}, **rep))
+                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())}, **rep, **guard_report()))
         if distributed:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -737,6 +750,7 @@ def main():
         "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum()),
     }
     out.update(rep)
+    out.update(guard_report())
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q
         torch.cuda.empty_cache()

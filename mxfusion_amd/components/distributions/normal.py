@@ -34,8 +34,10 @@ class _NormalLogPdfSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dx, dm, dv, ms, vs = ctx.grads
-        return (None if dx is None else dx * g, None if dm is None else (dm * g).reshape(ms),
-                None if dv is None else (dv * g).reshape(vs), None)
+        have = [t for t in (dx, dm, dv) if t is not None]
+        prod = iter(torch._foreach_mul(have, g) if have else [])          # one multi-tensor launch instead of one per gradient
+        dx, dm, dv = [next(prod) if t is not None else None for t in (dx, dm, dv)]
+        return (dx, None if dm is None else dm.reshape(ms), None if dv is None else dv.reshape(vs), None)
 
 
 class _NormalReparamFn(torch.autograd.Function):

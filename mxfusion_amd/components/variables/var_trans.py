@@ -17,6 +17,45 @@ class _SoftplusFn(torch.autograd.Function):
         return ops.softplus_bwd_(x, dy, torch.zeros_like(x))
 
 
+class _SoftplusManyFn(torch.autograd.Function):
+    """softplus of several tensors as ONE kernel each way (concatenate -> mxf_softplus_fwd -> views): a model has five to ten positive
+    parameters, and every one of them cost a launch forward and two backward in the step's launch-paced head and tail."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        sizes = [x.numel() for x in xs]
+        flat = torch.cat([x.reshape(-1) for x in xs]) if len(xs) > 1 else xs[0].reshape(-1)
+        ctx.save_for_backward(flat)
+        ctx.meta = (sizes, [x.shape for x in xs])
+        y = ops.softplus(flat)
+        return tuple(p.view(sh) for p, sh in zip(torch.split_with_sizes(y, sizes), ctx.meta[1]))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        (flat,) = ctx.saved_tensors
+        sizes, shapes = ctx.meta
+        parts = [(d.reshape(-1) if d is not None else flat.new_zeros(n)) for d, n in zip(dys, sizes)]
+        dy = torch.cat(parts) if len(parts) > 1 else parts[0]
+        dx = ops.softplus_bwd_(flat, dy, torch.zeros_like(flat))
+        return tuple(p.view(sh) for p, sh in zip(torch.split_with_sizes(dx, sizes), shapes))
+
+
+def transform_many(transformations, tensors):
+    """[t.transform(x) for t, x in zip(...)] with every plain softplus (offset 0, device tensor) of the list batched into one kernel call."""
+    out = list(tensors)
+    idx = [i for i, (t, x) in enumerate(zip(transformations, tensors))
+           if type(t) in (Softplus, PositiveTransformation) and not t._offset and isinstance(x, torch.Tensor) and x.is_cuda]
+    if len(idx) > 1 and len({(tensors[i].dtype, tensors[i].device) for i in idx}) == 1:
+        for i, y in zip(idx, _SoftplusManyFn.apply(*[tensors[i] for i in idx])):
+            out[i] = y
+        rest = [i for i in range(len(out)) if i not in set(idx)]
+    else:
+        rest = range(len(out))
+    for i in rest:
+        out[i] = transformations[i].transform(tensors[i])
+    return out
+
+
 class VariableTransformation(object):
     def transform(self, var, F=None, dtype=None):
         raise NotImplementedError

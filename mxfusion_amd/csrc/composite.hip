@@ -119,6 +119,9 @@ __global__ void bcast_copy_kernel(int S, int64_t n, const T* __restrict__ src, i
         dst[i] = scale * src[(i / n) * ssrc + (i % n)];
 }
 
+// dot_kernel ends with ONE atomic per workgroup on one word: 4096 of them serialise to ~0.16 ms (seen on the critical chain in front of the T
+// product, r03 timeline); 64 workgroups with a grid-stride loop take ~5 us
+inline unsigned dotgrid(int64_t n) { int64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 64) b = 64; return (unsigned)b; }
 inline unsigned gridn(int64_t n) { int64_t b = (n + 255) / 256; if (b < 1) b = 1; if (b > 4096) b = 4096; return (unsigned)b; }
 
 struct Carver {   // bump allocator over the handle's scratch
@@ -756,7 +759,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
     if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w ready: the Kfu planes + U pass may start
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
@@ -791,7 +794,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, H0, MM);     // H0 <- Ki (a plain kernel: the runtime's copy engine path costs ~10x as much next to busy queues)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
     // A_ext = [H0 ; w^T] in the streaming dtype
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
     hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
@@ -1069,10 +1072,10 @@ int sgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int64_t B, int64_t M, int 
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Psi2d, M, 0, ad, P, 0, 0.0, PA, P, 0, 1, 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)psi1d, (const D*)ad, 1.0, sc + 2);
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Psi2d, 1.0, sc + 3);
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MM)), dim3(256), 0, st, MM, (const D*)Ci, (const D*)Psi2d, 1.0, sc + 4);
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const D*)ad, (const D*)PA, 1.0, sc + 5);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)psi1d, (const D*)ad, 1.0, sc + 2);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Psi2d, 1.0, sc + 3);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ci, (const D*)Psi2d, 1.0, sc + 4);
+    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)ad, (const D*)PA, 1.0, sc + 5);
     hipLaunchKernelGGL((sgp_finalize_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, B, M, P, (const D*)sc, (const D*)noised, (const D*)vard, gscale,
                        logL, want_grad ? sc + 8 : (D*)nullptr, want_grad ? sc + 9 : (D*)nullptr, (const D*)ad, wv);
     // posterior side products (:99-106): L, LA = L^-1 chol(C)
