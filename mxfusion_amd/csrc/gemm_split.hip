@@ -382,7 +382,9 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // read the A fragments of block k from LDS, wait for block k + 1) and a COMPUTE phase (24 MFMAs), with a workgroup barrier after each; the
 // second half starts one phase late, so on every SIMD one wave computes while its partner loads.  Without it both waves of a SIMD reach the
 // shared barrier together, want the matrix pipe together and then wait for LDS / memory together.
-template <int XT, int NH, bool PP>
+// BLO = false: the B operand enters through its HIGH plane only (B rounded to f16, A still exact: two products instead of three, half the B
+// fetch) -- for products that feed GRADIENTS only (the T of the SVGP step; DESIGN.md section 4 states the error this leaves in them).
+template <int XT, int NH, bool PP, bool BLO = true>
 __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
     constexpr int WBMt = 32 * XT * NH;             // A rows per tile
@@ -446,8 +448,10 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         const unsigned short* bk_ = bbase + (kb) * g.N * 16;                                                                        \
         BR[0][0] = gload16(bvoff, bk_);                                                                                             \
         BR[1][0] = gload16_o1024(bvoff, bk_);                                                                                       \
-        BR[0][1] = gload16(bvoff, bk_ + g.pB);                                                                                      \
-        BR[1][1] = gload16_o1024(bvoff, bk_ + g.pB);                                                                                \
+        if constexpr (BLO) {                                                                                                        \
+            BR[0][1] = gload16(bvoff, bk_ + g.pB);                                                                                  \
+            BR[1][1] = gload16_o1024(bvoff, bk_ + g.pB);                                                                            \
+        }                                                                                                                           \
         _Pragma("unroll") for (int u_ = 0; u_ < ND; ++u_) {                                                                         \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + u_ * (NTH / 2) * 16 + (kb) * g.M * 16), \
                                              (__attribute__((address_space(3))) void*)(&smem[SLOT][0][wave * 64 + NTH * u_]), 16, 0, 0); \
@@ -459,10 +463,16 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     // registers that are now complete are tied to the wait ("+v"), so that no use of them can be scheduled above it.  The wait always sits
     // in STRAIGHT-LINE code: inside a branch the compiler may place the register copies of a control-flow merge in front of it, i.e. copy
     // registers whose loads are still in flight (seen in an earlier form of this kernel; csrc/check_wide_isa.py guards against it).
-#define W_WAIT_ASM(NSTR, BR) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(BR[0][0]), "+v"(BR[0][1]), "+v"(BR[1][0]), "+v"(BR[1][1])::"memory")
+#define W_WAIT_ASM(NSTR, BR)                                                                                                        \
+    do {                                                                                                                            \
+        if constexpr (BLO) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(BR[0][0]), "+v"(BR[0][1]), "+v"(BR[1][0]), "+v"(BR[1][1])::"memory"); \
+        else asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(BR[0][0]), "+v"(BR[1][0])::"memory");                                  \
+    } while (0)
+    // requests per k block: the B fragment loads (4, or 2 without the low plane) + 2 ND LDS-DMA requests
 #define W_WAIT1(BR)                                                                                                                 \
     do {                                                                                                                            \
-        if constexpr (XT == 4) W_WAIT_ASM("6", BR); else W_WAIT_ASM("8", BR);                                                       \
+        if constexpr (XT == 4 && BLO) W_WAIT_ASM("6", BR); else if constexpr (XT == 4) W_WAIT_ASM("4", BR);                         \
+        else if constexpr (BLO) W_WAIT_ASM("8", BR); else W_WAIT_ASM("6", BR);                                                      \
         __builtin_amdgcn_s_barrier();                                                                                               \
         asm volatile("" ::: "memory");                                                                                              \
     } while (0)
@@ -484,9 +494,11 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][1]), c[x][y], 0, 0, 0);      /* hi' lo */   \
+        if constexpr (BLO) {                                                                                                        \
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][1]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* lo' hi */   \
+        }                                                                                                                           \
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
                 c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* hi' hi */   \
@@ -516,7 +528,7 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
         u32x4 a_[XT][2];                                                                                                            \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }         \
-        W_WAIT_ASM("6", BRN);                                                                                                       \
+        if constexpr (BLO) W_WAIT_ASM("6", BRN); else W_WAIT_ASM("4", BRN);                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
         W_PHASE_END();                                                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                              \
@@ -561,8 +573,11 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
             if constexpr (PP) { if (wh == 0) W_PHASE_END(); }         // ... to here: every wave has passed the same number of barriers
             // the surplus requests of the last two steps target registers / LDS the epilogue does not read, but they must have landed
             // before the registers are reused
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b1[0][0]), "+v"(b1[0][1]),
-                         "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
+            if constexpr (BLO)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b1[0][0]), "+v"(b1[0][1]),
+                             "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[1][0]), "+v"(b1[0][0]), "+v"(b1[1][0])::"memory");
         }
     }
 #undef W_STEP
@@ -617,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128(SplitArgs g
 __global__ __launch_bounds__(256, 1) void gemm_f16x2_wide_kernel_256w4(SplitArgs g) { wide_body<8, 1, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g) { wide_body<4, 2, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
 
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
@@ -751,7 +767,9 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
             }
         }
         static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
-        if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
+        static const int bhi_env = (int)MXF_KNOB("MXF_SPLIT_BHI", 0);      // experiment: B through its high plane only, blocked-output products
+        if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (XT == 8) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256w4, dim3((unsigned)grid), dim3(256), 0, st, g);
         else hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128, dim3((unsigned)grid), dim3(256), 0, st, g);

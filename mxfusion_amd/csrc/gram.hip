@@ -601,6 +601,102 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
     }
 }
 
+// (r03) NP = 2 as ONE-WAVE workgroups, lane <-> minor index r (64 rows per wave), the sixteen major points of a k block wave-uniform
+// (scalar loads, no LDS staging, no barrier -- the layout of gram_lean_kernel).  A lane evaluates the 16 covariances of its row, i.e. BOTH
+// 16-byte halves of its 32-byte piece; v_permlane32_swap then trades half 1 of the rows of lanes 0..31 for half 0 of the rows of lanes
+// 32..63, so each of the two store instructions per plane covers 1 KB CONTIGUOUS (32 rows x 32 bytes).  (Without the swap each store
+// covers 16-byte pieces at a 32-byte stride: measured r02, 30 -> 40 ms per step.)  hi + lo come from the packed conversions
+// (v_cvt_pk_f16_f32: a plane's dword directly); the fused row U sums its sixteen terms per k block in index order.
+// Measured (tests/probes/planes_lean.sh, planes_store.hip): 1.82 / 1.69 ms for the two 8.6 GB passes of the bench step, the same as the staged
+// kernel -- neither the LDS staging nor the VALU count (16 -> 14 instructions per covariance here) is what bounds them; the store-only twin
+// of the same pattern takes 1.45 - 1.65 ms alone, memset 1.36 ms; PLAIN instead of non-temporal stores: 2.1 - 2.4 ms inside the step.
+template <int QT, int KIND, int PT>
+__global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
+                                                              const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
+                                                              int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
+                                                              int64_t ldU) {
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, r = r0 + lane;
+    float z[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q += 4) *reinterpret_cast<f32x4_t*>(&z[q]) = *reinterpret_cast<const f32x4_t*>(Xmin_s + r * QT + q);   // padded
+    float uacc[PT > 0 ? PT : 1];
+#pragma unroll
+    for (int p = 0; p < (PT > 0 ? PT : 1); ++p) uacc[p] = 0.f;
+    const int64_t K16 = (Kn + 15) / 16;
+    const int64_t kb_begin = (int64_t)blockIdx.y * kb_per_block;
+    const int64_t kb_end = (kb_begin + kb_per_block) < K16 ? (kb_begin + kb_per_block) : K16;
+    // store targets after the swap: instruction 1 <-> row r0 + lane % 32, instruction 2 <-> 32 rows further; the half is lane / 32
+    const int64_t ra = r0 + (lane & 31), rb = ra + 32;
+    const int hsel = lane >> 5;
+    auto kb_body = [&](int64_t kb, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const float* __restrict__ xk = Xmaj_s + kb * 16 * QT;                    // wave-uniform: scalar loads
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            f32x2 kv2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int nl = 2 * j + e;
+                f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < QT; q += 2) {
+                    const f32x2 xx = {xk[nl * QT + q], xk[nl * QT + q + 1]};
+                    const f32x2 zz = {z[q], z[q + 1]};
+                    const f32x2 d = xx - zz;
+                    acc2 = __builtin_elementwise_fma(d, d, acc2);
+                }
+                const float red = acc2.x + acc2.y;
+                const float kv = (FULL || kb * 16 + nl < Kn) ? cov_from<float, KIND>(red, 16384.f) : 0.f;
+                if (PT > 0) {
+                    const int64_t kk = FULL ? kb * 16 + nl : ((kb * 16 + nl < Kn) ? kb * 16 + nl : Kn - 1);     // (kv == 0 beyond Kn)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        const float wv = (PT == 1 || p < Pw) ? wk[kk * Pw + (PT == 1 ? 0 : p)] : 0.f;       // wave-uniform
+                        uacc[p] = fmaf(wv, kv, uacc[p]);
+                    }
+                }
+                kv2[e] = kv;
+            }
+            // hi + lo two values at a time: the packed conversions (v_cvt_pk_f16_f32) deliver the dword of the plane directly
+            const f16x2 fh = __builtin_convertvector(kv2, f16x2);
+            const f16x2 fl = __builtin_convertvector(kv2 - __builtin_convertvector(fh, f32x2), f16x2);
+            const unsigned hh = __builtin_bit_cast(unsigned, fh), ll = __builtin_bit_cast(unsigned, fl);
+            hi[j] = hh; lo[j] = ll;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi[i]), "+v"(hi[4 + i]));
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[i]), "+v"(lo[4 + i]));
+        }
+        unsigned short* base = P + (kb * R) * 16 + hsel * 8;
+        if (ra < R) {
+            const gp_u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+            __builtin_nontemporal_store(vh, reinterpret_cast<gp_u32x4*>(base + ra * 16));
+            __builtin_nontemporal_store(vl, reinterpret_cast<gp_u32x4*>(base + ra * 16 + pstride));
+        }
+        if (rb < R) {
+            const gp_u32x4 vh = {hi[4], hi[5], hi[6], hi[7]}, vl = {lo[4], lo[5], lo[6], lo[7]};
+            __builtin_nontemporal_store(vh, reinterpret_cast<gp_u32x4*>(base + rb * 16));
+            __builtin_nontemporal_store(vl, reinterpret_cast<gp_u32x4*>(base + rb * 16 + pstride));
+        }
+    };
+    const int64_t kb_full = Kn / 16 < kb_end ? Kn / 16 : kb_end;           // k blocks whose sixteen major points all exist
+    int64_t kb = kb_begin;
+    for (; kb < kb_full; ++kb) kb_body(kb, std::true_type{});
+    for (; kb < kb_end; ++kb) kb_body(kb, std::false_type{});
+    if (PT > 0) {
+        const float sc = var[0] * (1.f / 16384.f);
+        if (r < R) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) if (p < Pw) U[(int64_t)p * ldU + r] = uacc[p] * sc;
+        }
+    }
+}
+
 template <int KIND>
 int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
                      const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode,
@@ -622,13 +718,24 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     // (measured and dropped: one-wave workgroups with lane <-> row and the k-side points through scalar loads, as in the Gram kernel -- each
     //  store instruction then covers 16-byte pieces at a 32-byte stride and the step went from 30.1 to 40.0 ms; the (row, k half) <-> thread
     //  mapping below writes whole lines per instruction)
+    // r03: the one-wave form for the f16x2 planes (probe builds: MXF_PLANES_LEAN=0 selects the staged kernel)
+    const bool lean = mode == MXF_SPLIT_F16X2 && MXF_KNOB("MXF_PLANES_LEAN", 1) != 0;
+    int kbpb = fuse_u ? (int)K16 : (int)MXF_KNOB("MXF_PLANES_KB", 8);
+    while (!fuse_u && (K16 + kbpb - 1) / kbpb > 65535) kbpb *= 2;
+    dim3 lgrid((unsigned)((R + 63) / 64), (unsigned)((K16 + kbpb - 1) / kbpb));
 #define GO(QTV)                                                                                                                       \
     do {                                                                                                                              \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padr * QTV + 255) / 256), 1), dim3(256), 0, st, Xmin, (int64_t)0, ls, \
                            (int64_t)0, ard, R, Q, padr, buf);                                                                         \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
                            (int64_t)0, ard, Kn, Q, padk, bmaj);                                                                       \
-        if (mode == MXF_SPLIT_F16X2 && fuse_u && Pw == 1)                                                                             \
+        if (lean && fuse_u && Pw == 1)                                                                                         \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
+        else if (lean && fuse_u)                                                                                                      \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
+        else if (lean)                                                                                                                \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
+        else if (mode == MXF_SPLIT_F16X2 && fuse_u && Pw == 1)                                                                             \
             hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2, 1>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
         else if (mode == MXF_SPLIT_F16X2 && fuse_u)                                                                                   \
             hipLaunchKernelGGL((gram_planes_kernel<QTV, KIND, 2, 8>), grid, dim3(256), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, cpb, wk, Pw, U, ldU); \
