@@ -189,6 +189,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 // wave64 sum with DPP (no LDS traffic); the total is valid in LANE 63 only.
 // quad butterflies, row_half_mirror, row_mirror give every lane of a 16-lane row its row sum; row_bcast:15 / :31 fold rows.

@@ -138,6 +138,7 @@ struct SplitArgs {
     // rendezvous of the workgroups that share operand lines (wide kernels; see wg_rendezvous): counters (nullptr = none), workgroups per
     // group, loop trips between two rendezvous (0 = one per work item, at its start: group = sync_n consecutive work items), counters per k split
     unsigned* sync; int sync_n, sync_period, sync_slots;
+    unsigned* maxout;                    // wide kernels, plain (beta = 0, unsplit) products: atomicMax of the bit pattern of max |C| (nullptr: none)
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
@@ -394,6 +395,7 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     __shared__ u32x4 smem[3][2][NU];               // [ring slot][plane][16-byte unit]: 3 x 8 KB (128 rows) / 3 x 16 KB (256 rows), A only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
     int patience = 2;
+    float cmax = 0.f;                              // max |C| over this thread's outputs (g.maxout)
     // Persistent over the (tile, k split) work items: workgroup b takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so its items
     // stay on its XCD's run of tiles).  The epilogue's stores of one item drain while the next item's first loads are in flight; with one
     // item per workgroup every tile paid a dispatch + an un-overlapped pipeline fill + a store burst (~30 % of a K = 1024 tile).
@@ -616,6 +618,7 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
                     for (int e = 0; e < 4; ++e) atomic_add(p + e, v[e]);
                 } else if (beta == 0.f) {
                     *reinterpret_cast<f32x4*>(p) = v;      // (plain, not non-temporal: T of the SVGP step 12.7 -> 11.9 ms, same box)
+                    if (g.maxout) cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 } else {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(p);
                     *reinterpret_cast<f32x4*>(p) = v + beta * o;
@@ -623,6 +626,11 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
             }
     }
     }   // work items
+    if (g.maxout) {                                // one atomic per wave, and only if it can raise the word (non-negative floats order as their bits)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if (lane == 0 && __builtin_bit_cast(unsigned, cmax) > *(volatile unsigned*)g.maxout) atomicMax(g.maxout, __builtin_bit_cast(unsigned, cmax));
+    }
 }
 
 // The kernels:  _128: 128 x 256 tiles, two workgroups per CU;  _256 (the default for 256-aligned shapes): 256 x 256, eight waves in two row
@@ -673,10 +681,11 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 // [k0, k0+K) of a (R x Ktot) operand is the pointer planes + (k0 / 16) * R * 16 with the FULL operand's plane stride.
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
-                            int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked) {
+                            int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked,
+                            unsigned* maxout) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
-    g.c_blk = c_blocked;
+    g.c_blk = c_blocked; g.maxout = nullptr;
     if (c_blocked && (N % 16 != 0 || beta != 0.0 || lower_only || ldc != N)) MXF_FAIL(h, -2, "mxf_gemm_split: the blocked output layout needs N %% 16 == 0, ldc == N, beta == 0 and a full product");
     g.ad0 = ad0; g.pow0 = pow0; g.maxbits = maxbits; g.maxbits2 = maxbits2;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
@@ -738,6 +747,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     }
     const bool dma = g.use_dma && (M % SBM) == 0 && (N % SBN) == 0;
     if (wide) {
+        g.maxout = (splitk == 1 && beta == 0.0 && !lower_only) ? maxout : nullptr;       // (other paths leave the word as it is: the caller sees 0)
         // persistent: as many workgroups as fit the chip (the kernel's occupancy) walk the work items; fewer items than that: one each
         static const int64_t wide_grid_env = MXF_KNOB("MXF_SPLIT_WIDE_GRID", 0);
         const int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? 256 : 512);

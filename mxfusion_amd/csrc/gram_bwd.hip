@@ -367,6 +367,8 @@ struct BwdMfmaArgs {
     int64_t M, SB, B, sY;
     int Q, ard, CT, dY_shared, tblk;     // tblk: T in 16-column blocks, element (m, n) at ((n / 16) * M + m) * 16 + n % 16
     double a1;
+    // F16 accumulation (RBF): bit patterns of max |H0| (the T product's A operand), max |w_m|, max |y_n - U_n| -- the bound that scales the weights
+    const unsigned* h0max; const unsigned* mx; const unsigned* tmax;     // tmax: max |T| itself when the GEMM reported it (word != 0)
 };
 
 #ifndef MXF_MF_MT
@@ -406,13 +408,46 @@ constexpr int MF_RB = 16 * MF_MT;    // rows per band
                  "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\tv_mfma_f32_16x16x4_f32 %0, %7, %8, %0\n\ts_nop 11"               \
                  : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3))
 
-template <int KIND, bool FULL>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks)
+// F16 form of a stage (r03): the two ACCUMULATING products contract over the tile's 16 columns / 16 rows, which is exactly the K of one
+// v_mfma_f32_16x16x16_f16 -- with the weights and the coordinates split into hi + lo f16 (three products, f32-equivalent as in gemm_split.hip)
+// they take 3 + 3 half-length instructions instead of 4 + 4 full-length float32 ones; the dot products stay true float32.
+// Chains: d (dots of the next tile), c1 (row side, this tile), c2 (column side, previous tile), interleaved.
+#define MF_STAGE16(d, xa0_, zb0_, xa1_, zb1_, c1, wh, wl, xh, xl, c2, th, tl, zh, zl)                                     \
+    asm volatile("s_nop 4\n\t"                                                                                            \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %4, 0\n\t"                                                               \
+                 "v_mfma_f32_16x16x16_f16 %1, %7, %9, %1\n\t"                                                             \
+                 "v_mfma_f32_16x16x16_f16 %2, %11, %13, %2\n\t"                                                           \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %6, %0\n\t"                                                              \
+                 "v_mfma_f32_16x16x16_f16 %1, %7, %10, %1\n\t"                                                            \
+                 "v_mfma_f32_16x16x16_f16 %2, %11, %14, %2\n\t"                                                           \
+                 "v_mfma_f32_16x16x16_f16 %1, %8, %9, %1\n\t"                                                             \
+                 "v_mfma_f32_16x16x16_f16 %2, %12, %13, %2\n\ts_nop 11"                                                    \
+                 : "=&v"(d), "+v"(c1), "+v"(c2)                                                                            \
+                 : "v"(xa0_), "v"(zb0_), "v"(xa1_), "v"(zb1_), "v"(wh), "v"(wl), "v"(xh), "v"(xl), "v"(th), "v"(tl), "v"(zh), "v"(zl))
+#define MF_ACC16(c, ah, al, bh, bl)                                                                                       \
+    asm volatile("s_nop 4\n\tv_mfma_f32_16x16x16_f16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x16_f16 %0, %1, %4, %0\n\t"        \
+                 "v_mfma_f32_16x16x16_f16 %0, %2, %3, %0\n\ts_nop 11"                                                      \
+                 : "+v"(c) : "v"(ah), "v"(al), "v"(bh), "v"(bl))
+
+typedef _Float16 bw_f16x4 __attribute__((ext_vector_type(4)));
+// x (4 floats) = hi + lo, f16 each (hi = round(x), lo = round(x - hi)): the A / B operand of v_mfma_f32_16x16x16_f16 (k = 4 (lane / 16) + i)
+__device__ __forceinline__ void split4(const float (&x)[4], bw_f16x4& hi, bw_f16x4& lo) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v = {x[0], x[1], x[2], x[3]};
+    hi = __builtin_convertvector(v, bw_f16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bw_f16x4);
+}
+
+template <int KIND, bool FULL, bool F16>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks); F16: RBF only
 __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
+    static_assert(!F16 || KIND == MXF_K_RBF, "the f16 accumulation is scaled for the RBF weights");
     constexpr int QT = 8;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // LDS tables of the band (bank-conflict free for the access patterns below: PMC showed half of the LDS cycles in conflicts before)
-    __shared__ __attribute__((aligned(16))) float za[MF_RB][16];     // [z (scaled, 8) | 1 | 0 ...]: B operand of the column-side product (row-contiguous reads)
+    __shared__ __attribute__((aligned(16))) float za[F16 ? 1 : MF_RB][16];     // [z (scaled, 8) | 1 | 0 ...]: B operand of the column-side product (row-contiguous reads)
+    // F16: the same table as hi / lo f16, four consecutive rows of one entry j in 8 bytes: [row / 4][j][row % 4] -- the B operand of the 16 x 16 x 16 product
+    __shared__ __attribute__((aligned(16))) bw_f16x4 zah[F16 ? MF_RB / 4 : 1][16], zal[F16 ? MF_RB / 4 : 1][16];
     __shared__ __attribute__((aligned(16))) float zd[MF_RB][12];     // [z (8) | |z|^2 | w | - | -]: lanes read (row li, word lq): 12-word rows keep 16 rows x 4 words apart
     __shared__ float rowacc[MF_RB][10];
     __shared__ __attribute__((aligned(16))) float wt[4][2][16][20];  // per wave, double-buffered: the W tile, transposed on the way through (20-word rows)
@@ -428,9 +463,39 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     const float variance = a.var[0];
     const float c1 = (float)a.a1 / a.noise[0];
     const float kc = -c1 * variance;
-    for (int i = tid; i < MF_RB * 16; i += 256) {
-        const int r = i / 16, j = i % 16;
-        za[r][j] = (band0 + r < a.M) ? ((j < QT) ? a.Zs[(band0 + r) * QT + j] : (j == 8 ? 1.f : 0.f)) : 0.f;
+    if constexpr (F16) {
+        for (int i = tid; i < (MF_RB / 4) * 16; i += 256) {
+            const int g4 = i / 16, j = i % 16;
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t r = band0 + 4 * g4 + t;
+                v[t] = (r < a.M) ? ((j < QT) ? a.Zs[r * QT + j] : (j == 8 ? 1.f : 0.f)) : 0.f;
+            }
+            split4(v, zah[g4][j], zal[g4][j]);
+        }
+    } else {
+        for (int i = tid; i < MF_RB * 16; i += 256) {
+            const int r = i / 16, j = i % 16;
+            za[r][j] = (band0 + r < a.M) ? ((j < QT) ? a.Zs[(band0 + r) * QT + j] : (j == 8 ? 1.f : 0.f)) : 0.f;
+        }
+    }
+    // F16: weights are accumulated as (u k) 2^esc, |u k| 2^esc <= 2^14 from max |T| (reported by the split GEMM; else the bound
+    // variance M max|H0|) and |w e| <= max|w| max|e|
+    // (k <= 1 up to rounding); -(c1 variance) 2^-esc is applied when the sums are flushed.  f16 subnormals are kept by the matrix pipe
+    // (tests/probes/probe_mfma_overlap.hip), so a loose bound costs absolute, not relative, precision: 2^-25 / 2^14 of the bound.
+    float escf = 0.f, unsc = 1.f, fl = 1.f;     // fl: what the f16 sums still lack, -(c1 variance) 2^-esc
+    if constexpr (F16) {
+        const unsigned tb = a.tmax ? a.tmax[0] : 0u;
+        const float bnd = (tb ? __builtin_bit_cast(float, tb) : variance * (float)a.M * __builtin_bit_cast(float, a.h0max[0])) +
+                          __builtin_bit_cast(float, a.mx[0]) * __builtin_bit_cast(float, a.mx[1]);
+        const unsigned bb = __builtin_bit_cast(unsigned, bnd);
+        const int ex = (int)((bb >> 23) & 0xff);
+        int esc = (ex == 0 || ex == 0xff) ? 0 : 13 - (ex - 127);          // bnd < 2^(ex - 126): bnd 2^esc < 2^14
+        esc = esc > 60 ? 60 : (esc < -60 ? -60 : esc);
+        escf = (float)esc;
+        unsc = __builtin_bit_cast(float, (unsigned)(127 - esc) << 23);    // 2^-esc
+        fl = kc * unsc;
     }
     for (int r = tid; r < MF_RB; r += 256) {
         float n2 = 0.f;
@@ -461,25 +526,85 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     // row of T this lane reads in row tile mt: band0 + 16 mt + li (clamped: ragged rows are masked, not skipped -- no branches around loads)
     const int64_t rowl = band0 + li;
 
+    // Loads run AHEAD of their use across the column tiles (r03): the raw column-side values of tile it + 1 are requested at the top of
+    // tile it, and the T tiles PD row tiles ahead -- from tile it + 1's first rows while tile it works on its last ones.  (Before, every
+    // column tile began with a round of loads that were used at once and with T only two row tiles ahead: PMC had the waves waiting on
+    // memory for 42 % of their cycles.)
+    // (the Matern instances have no registers to spare -- they spill with the deeper pipeline: T two tiles ahead, the next column tile's
+    //  values requested behind the row tiles instead of in front of them)
+    constexpr bool AHEAD = RX;
+    constexpr int PD = AHEAD ? 4 : 2;                      // T tiles in flight per lane (MF_MT % PD == 0: a tile's slot is its index mod PD)
+    static_assert(MF_MT % PD == 0, "slot = row tile % PD needs MF_MT % PD == 0");
+    const int64_t tstep = a.tblk ? 256 : 16 * a.SB;       // blocked: a wave's 16 x 16 tile is ONE contiguous KB, the next row tile the next KB
+    struct Cols { float xa0, xa1; f32x4 xx, uu, yy; float xv[4]; int64_t smp; };
+    auto col_nt0 = [&](int it_) -> int64_t { return ((int64_t)blockIdx.x * a.CT + it_) * 64 + wave * 16; };   // the wave's 16 columns (the block's four waves side by side)
+    auto load_cols = [&](int64_t nt0_) -> Cols {
+        Cols c;
+        c.smp = nt0_ / a.B;                                                          // B % 16 == 0: a tile lies inside one sample
+        const int64_t n0_ = nt0_ + 4 * lq;
+        const int64_t n0c_ = (FULL || n0_ < a.SB) ? n0_ : a.SB - 4;
+        const int64_t nac_ = (FULL || nt0_ + li < a.SB) ? nt0_ + li : a.SB - 1;     // column of the dot product's A operand
+        c.xa0 = Xs[nac_ * QT + lq]; c.xa1 = Xs[nac_ * QT + 4 + lq];
+        c.xx = *reinterpret_cast<const f32x4*>(a.Xn + n0c_);
+        c.uu = *reinterpret_cast<const f32x4*>(a.U + n0c_);
+        c.yy = *reinterpret_cast<const f32x4*>(a.Y + c.smp * a.sY + (n0c_ - c.smp * a.B));     // (16-byte aligned: B % 16 == 0, sY = 0 or B)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c.xv[t] = Xs[(n0c_ + t) * QT + (li & 7)];
+        return c;
+    };
+    // T rows of this lane: band0 + li + 16 mt; ragged bands clamp to the last row and mask the value instead of branching
+    auto tbase = [&](int64_t nt0_, const float*& tl_) -> const float* {
+        const int64_t n0_ = nt0_ + 4 * lq;
+        const int64_t n0c_ = (FULL || n0_ < a.SB) ? n0_ : a.SB - 4;
+        tl_ = a.tblk ? Tm + ((nt0_ >> 4) * a.M + a.M - 1) * 16 + 4 * lq : Tm + n0c_ + (a.M - 1) * a.SB;
+        return a.tblk ? Tm + ((nt0_ >> 4) * a.M + rowl) * 16 + 4 * lq : Tm + n0c_ + rowl * a.SB;
+    };
+    auto tget = [&](const float* base_, const float* tl_, int j) -> f32x4 {
+        const float* q = base_ + (int64_t)j * tstep;
+        if (!FULL) q = q <= tl_ ? q : tl_;
+        return *reinterpret_cast<const f32x4*>(q);
+    };
+    int64_t nt0 = col_nt0(0);
+    if (nt0 < a.SB) {
+    Cols cur;
+    const float* tl_c = nullptr;
+    const float* tb_c = nullptr;
+    f32x4 tq[PD];
+    if constexpr (AHEAD) {
+        cur = load_cols(nt0);
+        tb_c = tbase(nt0, tl_c);
+#pragma unroll
+        for (int j = 0; j < PD; ++j) tq[j] = tget(tb_c, tl_c, j);
+    }
     for (int it = 0; it < a.CT; ++it) {
-        const int64_t nt0 = ((int64_t)blockIdx.x * a.CT + it) * 64 + wave * 16;      // the wave's 16 columns (the block's four waves side by side)
-        if (nt0 >= a.SB) break;
-        const int64_t smp = nt0 / a.B;                                               // B % 16 == 0: a tile lies inside one sample
+        int64_t nt0n = nt0;
+        bool has_next = false;
+        Cols nxt;
+        const float* tl_n = tl_c;
+        const float* tb_n = tb_c;
+        if constexpr (!AHEAD) {         // everything this column tile needs is requested here, at its top
+            cur = load_cols(nt0);
+            tb_c = tbase(nt0, tl_c);
+#pragma unroll
+            for (int j = 0; j < PD; ++j) tq[j] = tget(tb_c, tl_c, j);
+        } else {
+            nt0n = col_nt0(it + 1);
+            has_next = it + 1 < a.CT && nt0n < a.SB;
+            if (!has_next) nt0n = nt0;                        // (no next tile: harmless re-loads of this one)
+            nxt = load_cols(nt0n);
+            tb_n = tbase(nt0n, tl_n);
+        }
+        const int64_t smp = cur.smp;
         if (smp != cur_s) { flush_scal(); cur_s = smp; }
         const int64_t n0 = nt0 + 4 * lq;                                             // this lane's 4 consecutive columns
         const bool cval = FULL || n0 < a.SB;                                         // SB % 4 == 0: all four or none
-        const int64_t n0c = cval ? n0 : a.SB - 4;
-        const int64_t nac = (FULL || nt0 + li < a.SB) ? nt0 + li : a.SB - 1;         // column of the dot product's A operand
-        const float xa0 = Xs[nac * QT + lq], xa1 = Xs[nac * QT + 4 + lq];
-        const f32x4 xx = *reinterpret_cast<const f32x4*>(a.Xn + n0c);
-        const f32x4 uu = *reinterpret_cast<const f32x4*>(a.U + n0c);
+        const float xa0 = cur.xa0, xa1 = cur.xa1;
+        const f32x4 xx = cur.xx;
         float e[4], bx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float xv = Xs[(n0c + t) * QT + (li & 7)];
-            bx[t] = cval ? ((li < QT) ? xv : (li == 8 ? 1.f : 0.f)) : 0.f;
-            const float yv = a.Y[smp * a.sY + (n0c + t - smp * a.B)];
-            e[t] = cval ? yv - uu[t] : 0.f;
+            bx[t] = cval ? ((li < QT) ? cur.xv[t] : (li == 8 ? 1.f : 0.f)) : 0.f;
+            e[t] = cval ? cur.yy[t] - cur.uu[t] : 0.f;
         }
         if (blockIdx.y == 0 && li == 0 && cval) {          // one lane per column, first band only: dY and |e|^2
 #pragma unroll
@@ -492,19 +617,11 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
                 }
             }
         }
+        bw_f16x4 bxh, bxl;
+        f32x4 xxs = xx;
+        if constexpr (F16) { split4(bx, bxh, bxl); xxs = xx - escf; }       // r2 - esc: k comes out as k 2^esc
         float qn = 0.f;
         f32x4 C2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        // T rows of this lane: band0 + li + 16 mt, walked with a running pointer (the row offsets are column-tile invariant: computed up
-        // front they would sit in 2 registers per row tile); ragged bands clamp to the last row and mask the value instead of branching
-        const float* tp = a.tblk ? Tm + ((nt0 >> 4) * a.M + rowl) * 16 + 4 * lq : Tm + n0c + rowl * a.SB;
-        const float* const tlast = a.tblk ? Tm + ((nt0 >> 4) * a.M + a.M - 1) * 16 + 4 * lq : Tm + n0c + (a.M - 1) * a.SB;
-        const int64_t tstep = a.tblk ? 256 : 16 * a.SB;      // blocked: a wave's 16 x 16 tile is ONE contiguous KB, the next row tile the next KB
-        auto tload = [&]() -> f32x4 {
-            const float* q = (FULL || tp <= tlast) ? tp : tlast;
-            tp += tstep;
-            return *reinterpret_cast<const f32x4*>(q);
-        };
-        f32x4 tq0 = tload(), tq1 = tload();
         // software pipeline over the row tiles: the dot products of tile mt + 1 are issued BEFORE the arithmetic of tile mt (whose dots were
         // issued one iteration earlier), and the accumulating products of tile mt / the transposed product of tile mt - 1 AFTER it -- so the
         // matrix pipe works on ten MFMAs while the VALU does the next tile, instead of the two taking turns
@@ -518,8 +635,9 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
         for (int mt = 0; mt < MF_MT; ++mt) {
             const int rl = mt * 16 + li;
             asm volatile("" ::: "memory");
-            const f32x4 tq2 = (mt + 2 < MF_MT) ? tload() : tq1;                     // two row tiles ahead
-            f32x4 tv = tq0;
+            f32x4 tv = tq[mt % PD];
+            if (mt + PD < MF_MT) tq[mt % PD] = tget(tb_c, tl_c, mt + PD);                               // PD row tiles ahead
+            else if constexpr (AHEAD) tq[mt % PD] = tget(tb_n, tl_n, mt + PD - MF_MT);                  // ... into the next column tile
             if (!FULL) { const bool ok = cval && rowl + 16 * mt < a.M; tv = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f}; }
             f32x4 dotn = dotc;
             const f32x2 zwv = zwc;
@@ -531,19 +649,32 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             }
             // the transposed copy of the PREVIOUS row tile (written one iteration ago)
             float wtr[4], zb2[4];
+            bw_f16x4 th, tl, zh, zl;
             if (mt > 0) {
+                if constexpr (F16) {        // the product's k index is the row 4 lq + t
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    wtr[t] = wtw[((mt - 1) & 1) * WTB + (lq + 4 * t) * 20 + li];
-                    zb2[t] = za[(mt - 1) * 16 + lq + 4 * t][li];
+                    for (int t = 0; t < 4; ++t) wtr[t] = wtw[((mt - 1) & 1) * WTB + (4 * lq + t) * 20 + li];
+                    zh = zah[(mt - 1) * 4 + lq][li]; zl = zal[(mt - 1) * 4 + lq][li];       // (split below, behind the tile's arithmetic: the reads' latency stays hidden)
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        wtr[t] = wtw[((mt - 1) & 1) * WTB + (lq + 4 * t) * 20 + li];
+                        zb2[t] = za[(mt - 1) * 16 + lq + 4 * t][li];
+                    }
                 }
             }
             const float wm = zwv[1];
             f32x4 W;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float r2 = fmaf(-2.f, dotc[t], zwv[0] + xx[t]);
-                if constexpr (RX) {
+                float r2 = fmaf(-2.f, dotc[t], zwv[0] + xxs[t]);
+                if constexpr (F16) {
+                    const float k = __builtin_amdgcn_exp2f(-r2);          // k 2^esc
+                    const float u = fmaf(wm, e[t], tv[t]);
+                    W[t] = u * k;
+                    qn = fmaf(k, tv[t], qn);
+                    racc[mt] = fmaf(k, e[t], racc[mt]);
+                } else if constexpr (RX) {
                     // RBF: coordinates carry sqrt(log2(e) / 2) (as the forward Gram kernels'), so k = 2^-r2 is the bare v_exp_f32; the weight is
                     // W = 2 g w variance = -(c1 variance) (T + w e) k; variance and the sum over pairs of g k are applied once, at the flush
                     const float k = __builtin_amdgcn_exp2f(-r2);          // (r2 may round a few ulps below 0 for coincident points: k = 1 + O(1e-6))
@@ -564,7 +695,19 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
                 }
             }
             // this stage's MFMAs: dots of tile mt + 1, [B | S] += W . [X | 1] of tile mt, [D | C] += W^T . [Z | 1] of tile mt - 1
-            if (mt > 0 && mt + 1 < MF_MT) {
+            if constexpr (F16) {
+                const float wf[4] = {W[0], W[1], W[2], W[3]};
+                bw_f16x4 wh, wl;
+                split4(wf, wh, wl);
+                if (mt > 0) split4(wtr, th, tl);
+                if (mt > 0 && mt + 1 < MF_MT) {
+                    MF_STAGE16(dotn, xa0, zbc0, xa1, zbc1, C1[mt], wh, wl, bxh, bxl, C2, th, tl, zh, zl);
+                } else {
+                    if (mt + 1 < MF_MT) MF_DOT2(dotn, xa0, zbc0, xa1, zbc1);
+                    MF_ACC16(C1[mt], wh, wl, bxh, bxl);
+                    if (mt > 0) MF_ACC16(C2, th, tl, zh, zl);
+                }
+            } else if (mt > 0 && mt + 1 < MF_MT) {
                 MF_STAGE(dotn, xa0, zbc0, xa1, zbc1, C1[mt], W[0], bx[0], W[1], bx[1], W[2], bx[2], W[3], bx[3],
                          C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
             } else {
@@ -576,22 +719,30 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f32x4*>(wtw + (mt & 1) * WTB + li * 20 + 4 * lq) = W;
             __builtin_amdgcn_wave_barrier();
-            tq0 = tq1; tq1 = tq2;
             dotc = dotn;
             __builtin_amdgcn_sched_barrier(0);      // keep the unrolled row tiles apart
         }
         {   // the last row tile's transposed product
             float wtr[4], zb2[4];
+            if constexpr (F16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wtr[t] = wtw[((MF_MT - 1) & 1) * WTB + (4 * lq + t) * 20 + li];
+                bw_f16x4 th, tl;
+                split4(wtr, th, tl);
+                const bw_f16x4 zh = zah[(MF_MT - 1) * 4 + lq][li], zl = zal[(MF_MT - 1) * 4 + lq][li];
+                MF_ACC16(C2, th, tl, zh, zl);
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 wtr[t] = wtw[((MF_MT - 1) & 1) * WTB + (lq + 4 * t) * 20 + li];
                 zb2[t] = za[(MF_MT - 1) * 16 + lq + 4 * t][li];
             }
             MF_ACC4(C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
+            }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMA result -> VALU read: the hazard recogniser does not see it
         }
-        qsum += (double)(RX ? qn * variance : qn);
+        qsum += (double)(RX ? qn * (variance * unsc) : qn);
         // column side: C2[r] = [D | C] of column nt0 + 4 lq + r (= this lane's column n0 + r), entry j = li
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -599,9 +750,17 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             const float pr = bx[r] * Cn;                       // x_nq C_n (q = li; bx is x of column n0 + r at coordinate li)
             if (li < Q) {
                 dl3 = fmaf(bx[r], pr, dl3);
-                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * (ilj * (1.f / CS)));
+                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * (ilj * (1.f / CS) * fl));
             }
         }
+        if constexpr (AHEAD) {
+            if (!has_next) break;
+            cur = nxt; nt0 = nt0n; tb_c = tb_n; tl_c = tl_n;
+        } else {
+            nt0 = col_nt0(it + 1);
+            if (it + 1 >= a.CT || nt0 >= a.SB) break;
+        }
+    }
     }
     flush_scal();
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -610,12 +769,12 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     for (int mt = 0; mt < MF_MT; ++mt) {
         if (li < 9) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds_add(&rowacc[mt * 16 + 4 * lq + r][li], C1[mt][r]);
+            for (int r = 0; r < 4; ++r) lds_add(&rowacc[mt * 16 + 4 * lq + r][li], C1[mt][r] * fl);
         }
         float rr = racc[mt];                                   // R partials of row 16 mt + li: fold the four column groups
         rr += __shfl_xor(rr, 16, 64);
         rr += __shfl_xor(rr, 32, 64);
-        if (lane < 16) lds_add(&rowacc[mt * 16 + li][9], RX ? rr * variance : rr);
+        if (lane < 16) lds_add(&rowacc[mt * 16 + li][9], RX ? rr * (variance * unsc) : rr);
     }
     __syncthreads();
     for (int i = tid; i < MF_RB * 10; i += 256) {
@@ -624,7 +783,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     }
     if (a.dvar && !RX) { const float v = block_sum<float>(gvar, red); if (tid == 0) atomic_add(a.dvar, v); }     // RBF: -(sum of S) / variance, by the finishing kernel
     {   // sum_n x_nq^2 C_n: lane (q = li) holds its share
-        float v = (li < Q) ? dl3 : 0.f;
+        float v = (li < Q) ? dl3 * fl : 0.f;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < 16 && li < Q) atomic_add(a.dls3 + li, (double)v);       // in the kernel's coordinates: the finishing kernel divides by CS^2
@@ -751,11 +910,30 @@ int bwd_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q, const v
     return launch_kind<T, 0>(h, kind, a, S, st);
 }
 
-// dst[i][0..7] = cs * src[i][0..Q-1] / l_q, zero padded (rows i < n); norms[i] = |dst[i]|^2 (optional)
-__global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restrict__ src, int64_t n, int Q, const float* __restrict__ ls, int ard,
-                                                           float* __restrict__ dst, float* __restrict__ norms, float cs) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
+// dst[i][0..7] = cs * src[i][0..Q-1] / l_q, zero padded; norms[i] = |dst[i]|^2 (optional).  Rows i = blockIdx.y * B + (row inside the
+// sample), blockIdx.y = sample (the coordinates of the M inducing points: one "sample" of B = M rows).
+// mx (optional; zeroed by the caller): bit pattern of max_i |aux[i]| (yv == nullptr: the row w) or of max_i |yv[s * sY + i % B] - aux[i]| (the
+// residual y_n - U_n) -- the bound behind the f16 accumulation of the matrix-pipe pass.  One atomic per workgroup, and only if it can raise
+// the word (non-negative floats order as their bit patterns).
+__global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restrict__ src, int64_t B, int Q, const float* __restrict__ ls, int ard,
+                                                           float* __restrict__ dst, float* __restrict__ norms, float cs,
+                                                           const float* __restrict__ aux, const float* __restrict__ yv, int64_t sY,
+                                                           unsigned* __restrict__ mx) {
+    __shared__ float smax[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.y * B + i;
+    if (mx) {
+        float m = 0.f;
+        if (i < B) m = fabsf(yv ? yv[(int64_t)blockIdx.y * sY + i] - aux[r] : aux[r]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+            if (__builtin_bit_cast(unsigned, m) > *(volatile unsigned*)mx) atomicMax(mx, __builtin_bit_cast(unsigned, m));
+        }
+    }
+    if (i >= B) return;
     float v[8], n2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? src[r * Q + q] / ls[ard ? q : 0] * cs : 0.f; n2 = fmaf(v[q], v[q], n2); }
@@ -767,7 +945,8 @@ __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restri
 
 int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
                 const float* var, const float* Text, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dZ,
-                float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st, int t_blocked) {
+                float* dX, float* dls, float* dvar, float* dY, int dY_shared, float* R, double* scal, hipStream_t st, int t_blocked,
+                const unsigned* h0max, const unsigned* tmax) {
     const size_t nacc = ((size_t)M * 16 + 16) * sizeof(double);                                    // bytes, zeroed every call
     const size_t need = nacc + (((size_t)M + (size_t)SB) * 8 + (size_t)SB) * sizeof(float);        // + the scaled coordinates and |x_n|^2
     if (need > h->bwd_acc_bytes) {
@@ -784,12 +963,22 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     float* Xs = Zs + (size_t)M * 8;
     float* Xn = Xs + (size_t)SB * 8;
     const float cs = kind == MXF_K_RBF ? 0.84932180028801904272f : 1.f;      // RBF: exp(-r2 / 2) = 2^-(cs^2 r2), the bare v_exp_f32 in the pass
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr, cs);
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, st, X, SB, Q, ls, ard, Xs, Xn, cs);
+    // f16 accumulation (RBF; the T product's operand bound must be known: the split GEMM's max |H0| word)
+    static const int f16_env = (int)MXF_KNOB("MXF_BWD_F16", 1);
+    const bool f16 = f16_env && kind == MXF_K_RBF && h0max != nullptr;
+    unsigned* mx = reinterpret_cast<unsigned*>(zacc + (size_t)M * 16 + 8);          // two words behind dls3[8], zeroed with the accumulators
+    const float* Urow = Text + M * SB;
+    const int64_t nsamp = SB / B;         // (the matrix-pipe pass requires B % 16 == 0 and whole samples: SB = S B)
+    if (nsamp > 65535 || nsamp * B != SB) MXF_FAIL(h, -3, "svgp reverse pass: bad sample layout (SB %lld, B %lld)", (long long)SB, (long long)B);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr, cs,
+                       w, (const float*)nullptr, (int64_t)0, f16 ? mx : (unsigned*)nullptr);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)nsamp), dim3(256), 0, st, X, B, Q, ls, ard, Xs, Xn, cs,
+                       Urow, Y, sY, f16 ? mx + 1 : (unsigned*)nullptr);
     BwdMfmaArgs a;
     a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
     a.dX = dX; a.dY = dY; a.zacc = zacc; a.dls3 = zacc + (size_t)M * 16; a.dvar = dvar; a.scal = scal;
     a.M = M; a.SB = SB; a.B = B; a.sY = sY; a.Q = Q; a.ard = ard; a.dY_shared = dY_shared; a.a1 = a1; a.tblk = t_blocked;
+    a.h0max = h0max; a.mx = mx; a.tmax = tmax;
     const int64_t quads = (SB + 63) / 64, bands = (M + MF_RB - 1) / MF_RB;
     // work items: ~1024 (r03; was 8192).  Every workgroup ends with a flush of its row-side sums (LDS, then float64 atomics), a fixed cost
     // per workgroup: with 8192 of them the pass took 0.82 ms at 4 samples where 3.0 / 8 = 0.38 was its share (per-rank step 5.02 -> 4.63 ms
@@ -804,11 +993,15 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     const bool full = (M % MF_RB == 0) && (SB % 64 == 0);
 #define MF_GO(KIND)                                                                                             \
     do {                                                                                                        \
-        if (full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, true>), g, dim3(256), 0, st, a);              \
-        else hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, false>), g, dim3(256), 0, st, a);                  \
+        if (full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, true, false>), g, dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, false, false>), g, dim3(256), 0, st, a);           \
     } while (0)
     switch (kind) {
-        case MXF_K_RBF: MF_GO(MXF_K_RBF); break;
+        case MXF_K_RBF:
+            if (f16 && full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<MXF_K_RBF, true, true>), g, dim3(256), 0, st, a);
+            else if (f16) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<MXF_K_RBF, false, true>), g, dim3(256), 0, st, a);
+            else MF_GO(MXF_K_RBF);
+            break;
         case MXF_K_MATERN12: MF_GO(MXF_K_MATERN12); break;
         case MXF_K_MATERN32: MF_GO(MXF_K_MATERN32); break;
         case MXF_K_MATERN52: MF_GO(MXF_K_MATERN52); break;
@@ -824,7 +1017,8 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
 template <typename T>
 int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z, const void* Xall, const void* ls,
                 int ard, const void* var, const void* Text, const void* Y, int64_t sY, const void* w, const void* noise, double a1,
-                void* dZ, void* dXall, void* dls, void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked) {
+                void* dZ, void* dXall, void* dls, void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked,
+                const unsigned* h0max, const unsigned* tmax) {
     GramBwdArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.square = 0;
@@ -838,7 +1032,7 @@ int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, i
         if (mxf_svgp_bwd_is_mfma(MXF_F32, SB, B, Q, P, Text))
             return launch_mfma(h, kind, M, SB, B, Q, (const float*)Z, (const float*)Xall, (const float*)ls, ard, (const float*)var, (const float*)Text,
                                (const float*)Y, sY, (const float*)w, (const float*)noise, a1, (float*)dZ, (float*)dXall, (float*)dls, (float*)dvar,
-                               (float*)dY, dY_shared, (float*)R, scal, st, t_blocked);
+                               (float*)dY, dY_shared, (float*)R, scal, st, t_blocked, h0max, tmax);
     }
     if (t_blocked) MXF_FAIL(h, -2, "svgp fused reverse pass: only the matrix-pipe pass reads T in blocks");
     if (P == 1) return launch_kind<T, 1>(h, kind, a, 1, st);
@@ -866,10 +1060,11 @@ bool mxf_svgp_bwd_is_mfma(int dtype, int64_t SB, int64_t B, int Q, int P, const 
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
-                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked) {
+                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked,
+                                const unsigned* h0max, const unsigned* tmax) {
     if (P > PMAX_ALL) MXF_FAIL(h, -3, "svgp fused reverse pass: P > %d", PMAX_ALL);
-    if (dtype == MXF_F32) return fused_typed<float>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked);
-    if (dtype == MXF_F64) return fused_typed<double>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked);
+    if (dtype == MXF_F32) return fused_typed<float>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked, h0max, tmax);
+    if (dtype == MXF_F64) return fused_typed<double>(h, kind, M, SB, B, Q, P, Z, Xall, ls, ard, var, Text, Y, sY, w, noise, a1, dZ, dXall, dls, dvar, dY, dY_shared, R, scal, st, t_blocked, h0max, tmax);
     MXF_FAIL(h, -2, "svgp fused reverse pass: bad dtype %d", dtype);
 }
 

@@ -31,7 +31,11 @@ bool mxf_svgp_bwd_is_mfma(int dtype, int64_t SB, int64_t B, int Q, int P, const 
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,
-                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked = 0);
+                                void* dvar, void* dY, int dY_shared, void* R, double* scal, hipStream_t st, int t_blocked = 0,
+                                const unsigned* h0max = nullptr, const unsigned* tmax = nullptr);
+// (h0max: bit pattern of max |H0| when T = H0 Kuf came from the f16x2 split GEMM -- the operand bound that lets the matrix-pipe pass
+//  accumulate its RBF weights as hi + lo f16; nullptr: float32 accumulation.  tmax: bit pattern of max |T| if the GEMM reported it
+//  (word != 0): the tight bound)
 
 // f32-accurate GEMM on the bf16 matrix pipe (three-term bf16 splitting, gemm_split.hip)
 size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE plane of an (R x K) operand
@@ -44,7 +48,9 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus = 0, int mode = MXF_SPLIT_BF16X3, const float* ad0 = nullptr, int pow0 = 0,
-                            const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr, int c_blocked = 0);
+                            const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr, int c_blocked = 0,
+                            unsigned* maxout = nullptr);
+// (maxout: the wide kernel's plain products raise this word (atomicMax) to the bit pattern of max |C|; every other path leaves it untouched)
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
                              int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st,
