@@ -429,6 +429,26 @@ constexpr int MF_RB = 16 * MF_MT;    // rows per band
                  "v_mfma_f32_16x16x16_f16 %0, %2, %3, %0\n\ts_nop 11"                                                      \
                  : "+v"(c) : "v"(ah), "v"(al), "v"(bh), "v"(bl))
 
+#ifdef MXF_BWD_TRACE
+// probe build only (tests/probes/bwd_trace.py): shader-clock stamps of the stages of one wave's row tiles, [column tile it < 8][row tile][stage]
+__device__ unsigned bwd_trace_buf[8 * 8 * 8];
+extern "C" int mxf_debug_bwd_trace(unsigned* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bwd_trace_buf), sizeof(bwd_trace_buf)); }
+#define BT_STAMP2(mtv, k, dep)                                                                                            \
+    do {                                                                                                                  \
+        unsigned long long t_;                                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                            \
+        if (traced && it < 8 && lane == 0) bwd_trace_buf[(it * 8 + (mtv)) * 8 + (k)] = (unsigned)t_;                      \
+    } while (0)
+#define BT_STAMP(k, dep)                                                                                                  \
+    do {                                                                                                                  \
+        unsigned long long t_;                                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                            \
+        if (traced && it < 8 && lane == 0) bwd_trace_buf[(it * 8 + mt) * 8 + (k)] = (unsigned)t_;                         \
+    } while (0)
+#else
+#define BT_STAMP(k, dep) do { } while (0)
+#define BT_STAMP2(mtv, k, dep) do { } while (0)
+#endif
 typedef _Float16 bw_f16x4 __attribute__((ext_vector_type(4)));
 // x (4 floats) = hi + lo, f16 each (hi = round(x), lo = round(x - hi)): the A / B operand of v_mfma_f32_16x16x16_f16 (k = 4 (lane / 16) + i)
 __device__ __forceinline__ void split4(const float (&x)[4], bw_f16x4& hi, bw_f16x4& lo) {
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     for (int mt = 0; mt < MF_MT; ++mt) { C1[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; racc[mt] = 0.f; }
     float gvar = 0.f, dl3 = 0.f;
     double qsum = 0.0, esum = 0.0;
-    int64_t cur_s = -1;
+    int cur_s = -1;
     auto flush_scal = [&]() {       // wave-uniform call: per-sample sums of q_n (and |e_n|^2 from the first band)
         const double qs = wave_sum(qsum), es = wave_sum(esum);
         if (lane == 0 && cur_s >= 0) { atomic_add(a.scal + 2 * cur_s, qs); if (blockIdx.y == 0) atomic_add(a.scal + 2 * cur_s + 1, es); }
@@ -523,6 +543,8 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     };
     float* wtw = &wt[wave][0][0][0];
     constexpr int WTB = 16 * 20;      // words per transpose buffer
+    _Float16* const wth = reinterpret_cast<_Float16*>(wtw);      // F16: the same space as two planes of 16 x 20 halves per buffer
+    constexpr int WTB16 = 2 * WTB;    // halves per transpose buffer
     // row of T this lane reads in row tile mt: band0 + 16 mt + li (clamped: ragged rows are masked, not skipped -- no branches around loads)
     const int64_t rowl = band0 + li;
 
@@ -536,68 +558,76 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     constexpr int PD = AHEAD ? 4 : 2;                      // T tiles in flight per lane (MF_MT % PD == 0: a tile's slot is its index mod PD)
     static_assert(MF_MT % PD == 0, "slot = row tile % PD needs MF_MT % PD == 0");
     const int64_t tstep = a.tblk ? 256 : 16 * a.SB;       // blocked: a wave's 16 x 16 tile is ONE contiguous KB, the next row tile the next KB
-    struct Cols { float xa0, xa1; f32x4 xx, uu, yy; float xv[4]; int64_t smp; };
-    auto col_nt0 = [&](int it_) -> int64_t { return ((int64_t)blockIdx.x * a.CT + it_) * 64 + wave * 16; };   // the wave's 16 columns (the block's four waves side by side)
-    auto load_cols = [&](int64_t nt0_) -> Cols {
+    const int sb = (int)a.SB, bsz = (int)a.B;
+    struct Cols { float xa0, xa1; f32x4 xx, uu, yy; float xv[4]; int smp; };
+    auto col_nt0 = [&](int it_) -> int { return ((int)blockIdx.x * a.CT + it_) * 64 + wave * 16; };   // (SB < 2^31: the launcher checks)   // the wave's 16 columns (the block's four waves side by side)
+    // (the sample of a column tile, nt0 / B, is walked along: a wave's tiles are 64 columns apart, and a 64-bit division per tile is ~100 instructions)
+    auto load_cols = [&](int nt0_, int smp_) -> Cols {
         Cols c;
-        c.smp = nt0_ / a.B;                                                          // B % 16 == 0: a tile lies inside one sample
-        const int64_t n0_ = nt0_ + 4 * lq;
-        const int64_t n0c_ = (FULL || n0_ < a.SB) ? n0_ : a.SB - 4;
-        const int64_t nac_ = (FULL || nt0_ + li < a.SB) ? nt0_ + li : a.SB - 1;     // column of the dot product's A operand
+        c.smp = smp_;                                                                // B % 16 == 0: a tile lies inside one sample
+        const int n0_ = nt0_ + 4 * lq;
+        const int64_t n0c_ = (FULL || n0_ < sb) ? n0_ : sb - 4;
+        const int64_t nac_ = (FULL || nt0_ + li < sb) ? nt0_ + li : sb - 1;     // column of the dot product's A operand
         c.xa0 = Xs[nac_ * QT + lq]; c.xa1 = Xs[nac_ * QT + 4 + lq];
         c.xx = *reinterpret_cast<const f32x4*>(a.Xn + n0c_);
         c.uu = *reinterpret_cast<const f32x4*>(a.U + n0c_);
-        c.yy = *reinterpret_cast<const f32x4*>(a.Y + c.smp * a.sY + (n0c_ - c.smp * a.B));     // (16-byte aligned: B % 16 == 0, sY = 0 or B)
+        c.yy = *reinterpret_cast<const f32x4*>(a.Y + (int64_t)c.smp * a.sY + (n0c_ - (int64_t)c.smp * a.B));     // (16-byte aligned: B % 16 == 0, sY = 0 or B)
 #pragma unroll
         for (int t = 0; t < 4; ++t) c.xv[t] = Xs[(n0c_ + t) * QT + (li & 7)];
         return c;
     };
     // T rows of this lane: band0 + li + 16 mt; ragged bands clamp to the last row and mask the value instead of branching
-    auto tbase = [&](int64_t nt0_, const float*& tl_) -> const float* {
-        const int64_t n0_ = nt0_ + 4 * lq;
-        const int64_t n0c_ = (FULL || n0_ < a.SB) ? n0_ : a.SB - 4;
-        tl_ = a.tblk ? Tm + ((nt0_ >> 4) * a.M + a.M - 1) * 16 + 4 * lq : Tm + n0c_ + (a.M - 1) * a.SB;
-        return a.tblk ? Tm + ((nt0_ >> 4) * a.M + rowl) * 16 + 4 * lq : Tm + n0c_ + rowl * a.SB;
+    auto tbase = [&](int nt0_, const float*& tl_) -> const float* {
+        const int n0_ = nt0_ + 4 * lq;
+        const int64_t n0c_ = (FULL || n0_ < sb) ? n0_ : sb - 4;
+        tl_ = a.tblk ? Tm + ((int64_t)(nt0_ >> 4) * a.M + a.M - 1) * 16 + 4 * lq : Tm + n0c_ + (a.M - 1) * a.SB;
+        return a.tblk ? Tm + ((int64_t)(nt0_ >> 4) * a.M + rowl) * 16 + 4 * lq : Tm + n0c_ + rowl * a.SB;
     };
     auto tget = [&](const float* base_, const float* tl_, int j) -> f32x4 {
         const float* q = base_ + (int64_t)j * tstep;
         if (!FULL) q = q <= tl_ ? q : tl_;
         return *reinterpret_cast<const f32x4*>(q);
     };
-    int64_t nt0 = col_nt0(0);
-    if (nt0 < a.SB) {
+    int nt0 = col_nt0(0);
+#ifdef MXF_BWD_TRACE
+    const bool traced = blockIdx.x == gridDim.x / 2 && blockIdx.y == 3 && wave == 1;
+#endif
+    if (nt0 < sb) {
     Cols cur;
     const float* tl_c = nullptr;
     const float* tb_c = nullptr;
     f32x4 tq[PD];
+    int smp_w = nt0 / bsz, smp_end = (smp_w + 1) * bsz;       // sample of the tile at nt0 and the first column behind it (< 2^31 + B: unsigned compare)
+    auto advance_smp = [&](int nt0_) { while ((unsigned)nt0_ >= (unsigned)smp_end) { ++smp_w; smp_end += bsz; } return smp_w; };
     if constexpr (AHEAD) {
-        cur = load_cols(nt0);
+        cur = load_cols(nt0, smp_w);
         tb_c = tbase(nt0, tl_c);
 #pragma unroll
         for (int j = 0; j < PD; ++j) tq[j] = tget(tb_c, tl_c, j);
     }
     for (int it = 0; it < a.CT; ++it) {
-        int64_t nt0n = nt0;
+        int nt0n = nt0;
         bool has_next = false;
         Cols nxt;
         const float* tl_n = tl_c;
         const float* tb_n = tb_c;
         if constexpr (!AHEAD) {         // everything this column tile needs is requested here, at its top
-            cur = load_cols(nt0);
+            cur = load_cols(nt0, advance_smp(nt0));
             tb_c = tbase(nt0, tl_c);
 #pragma unroll
             for (int j = 0; j < PD; ++j) tq[j] = tget(tb_c, tl_c, j);
         } else {
             nt0n = col_nt0(it + 1);
-            has_next = it + 1 < a.CT && nt0n < a.SB;
+            has_next = it + 1 < a.CT && nt0n < sb;
             if (!has_next) nt0n = nt0;                        // (no next tile: harmless re-loads of this one)
-            nxt = load_cols(nt0n);
+            nxt = load_cols(nt0n, has_next ? advance_smp(nt0n) : cur.smp);
             tb_n = tbase(nt0n, tl_n);
         }
-        const int64_t smp = cur.smp;
+        BT_STAMP2(0, 6, tb_n);
+        const int smp = cur.smp;
         if (smp != cur_s) { flush_scal(); cur_s = smp; }
-        const int64_t n0 = nt0 + 4 * lq;                                             // this lane's 4 consecutive columns
-        const bool cval = FULL || n0 < a.SB;                                         // SB % 4 == 0: all four or none
+        const int n0 = nt0 + 4 * lq;                                                 // this lane's 4 consecutive columns
+        const bool cval = FULL || n0 < sb;                                         // SB % 4 == 0: all four or none
         const float xa0 = cur.xa0, xa1 = cur.xa1;
         const f32x4 xx = cur.xx;
         float e[4], bx[4];
@@ -613,13 +643,14 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
                 if (a.dY) {
                     const float g = -c1 * e[t];
                     const int64_t n = n0 + t;
-                    if (a.dY_shared) atomic_add(a.dY + (n - smp * a.B), g); else a.dY[n] = g;
+                    if (a.dY_shared) atomic_add(a.dY + (n - (int64_t)smp * a.B), g); else a.dY[n] = g;
                 }
             }
         }
         bw_f16x4 bxh, bxl;
         f32x4 xxs = xx;
         if constexpr (F16) { split4(bx, bxh, bxl); xxs = xx - escf; }       // r2 - esc: k comes out as k 2^esc
+        BT_STAMP2(0, 7, xxs[0]);
         float qn = 0.f;
         f32x4 C2 = f32x4{0.f, 0.f, 0.f, 0.f};
         // software pipeline over the row tiles: the dot products of tile mt + 1 are issued BEFORE the arithmetic of tile mt (whose dots were
@@ -635,7 +666,9 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
         for (int mt = 0; mt < MF_MT; ++mt) {
             const int rl = mt * 16 + li;
             asm volatile("" ::: "memory");
+            BT_STAMP(0, rl);
             f32x4 tv = tq[mt % PD];
+            BT_STAMP(1, tv[0]);
             if (mt + PD < MF_MT) tq[mt % PD] = tget(tb_c, tl_c, mt + PD);                               // PD row tiles ahead
             else if constexpr (AHEAD) tq[mt % PD] = tget(tb_n, tl_n, mt + PD - MF_MT);                  // ... into the next column tile
             if (!FULL) { const bool ok = cval && rowl + 16 * mt < a.M; tv = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -651,10 +684,10 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             float wtr[4], zb2[4];
             bw_f16x4 th, tl, zh, zl;
             if (mt > 0) {
-                if constexpr (F16) {        // the product's k index is the row 4 lq + t
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) wtr[t] = wtw[((mt - 1) & 1) * WTB + (4 * lq + t) * 20 + li];
-                    zh = zah[(mt - 1) * 4 + lq][li]; zl = zal[(mt - 1) * 4 + lq][li];       // (split below, behind the tile's arithmetic: the reads' latency stays hidden)
+                if constexpr (F16) {        // the product's k index is the row 4 lq + t: four consecutive rows of column li, 8 bytes per plane
+                    th = *reinterpret_cast<const bw_f16x4*>(wth + ((mt - 1) & 1) * WTB16 + li * 20 + 4 * lq);
+                    tl = *reinterpret_cast<const bw_f16x4*>(wth + ((mt - 1) & 1) * WTB16 + 320 + li * 20 + 4 * lq);
+                    zh = zah[(mt - 1) * 4 + lq][li]; zl = zal[(mt - 1) * 4 + lq][li];
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -695,11 +728,13 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
                 }
             }
             // this stage's MFMAs: dots of tile mt + 1, [B | S] += W . [X | 1] of tile mt, [D | C] += W^T . [Z | 1] of tile mt - 1
+            bw_f16x4 wh16, wl16;
+            BT_STAMP(2, W[3]);
             if constexpr (F16) {
                 const float wf[4] = {W[0], W[1], W[2], W[3]};
-                bw_f16x4 wh, wl;
-                split4(wf, wh, wl);
-                if (mt > 0) split4(wtr, th, tl);
+                split4(wf, wh16, wl16);
+                BT_STAMP(3, wl16);
+                const bw_f16x4 wh = wh16, wl = wl16;
                 if (mt > 0 && mt + 1 < MF_MT) {
                     MF_STAGE16(dotn, xa0, zbc0, xa1, zbc1, C1[mt], wh, wl, bxh, bxl, C2, th, tl, zh, zl);
                 } else {
@@ -715,20 +750,29 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
                 MF_ACC4(C1[mt], W[0], bx[0], W[1], bx[1], W[2], bx[2], W[3], bx[3]);
                 if (mt > 0) MF_ACC4(C2, wtr[0], zb2[0], wtr[1], zb2[1], wtr[2], zb2[2], wtr[3], zb2[3]);
             }
+            BT_STAMP(4, C1[mt][0]);
             // transpose the tile through LDS: written as (m = li, n = 4 lq .. + 3), read (next iteration) as (n = li, m = lq + 4 t)
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<f32x4*>(wtw + (mt & 1) * WTB + li * 20 + 4 * lq) = W;
+            if constexpr (F16) {
+                // the hi / lo planes go through LDS already split, element (m = li, n = 4 lq + t) to [n][m]: eight 2-byte stores (20-half rows:
+                // the four column groups of one store land 32 bytes apart, conflict-free), read back as 8 bytes per plane -- the weights are
+                // converted once for both products
+                _Float16* const wb = wth + (mt & 1) * WTB16;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { wb[(4 * lq + t) * 20 + li] = wh16[t]; wb[320 + (4 * lq + t) * 20 + li] = wl16[t]; }
+            } else {
+                *reinterpret_cast<f32x4*>(wtw + (mt & 1) * WTB + li * 20 + 4 * lq) = W;
+            }
             __builtin_amdgcn_wave_barrier();
             dotc = dotn;
+            BT_STAMP(5, dotc[0]);
             __builtin_amdgcn_sched_barrier(0);      // keep the unrolled row tiles apart
         }
         {   // the last row tile's transposed product
             float wtr[4], zb2[4];
             if constexpr (F16) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) wtr[t] = wtw[((MF_MT - 1) & 1) * WTB + (4 * lq + t) * 20 + li];
-                bw_f16x4 th, tl;
-                split4(wtr, th, tl);
+                const bw_f16x4 th = *reinterpret_cast<const bw_f16x4*>(wth + ((MF_MT - 1) & 1) * WTB16 + li * 20 + 4 * lq);
+                const bw_f16x4 tl = *reinterpret_cast<const bw_f16x4*>(wth + ((MF_MT - 1) & 1) * WTB16 + 320 + li * 20 + 4 * lq);
                 const bw_f16x4 zh = zah[(MF_MT - 1) * 4 + lq][li], zl = zal[(MF_MT - 1) * 4 + lq][li];
                 MF_ACC16(C2, th, tl, zh, zl);
             } else {
@@ -742,6 +786,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // inline-asm MFMA result -> VALU read: the hazard recogniser does not see it
         }
+        BT_STAMP2(7, 6, C2[0]);
         qsum += (double)(RX ? qn * (variance * unsc) : qn);
         // column side: C2[r] = [D | C] of column nt0 + 4 lq + r (= this lane's column n0 + r), entry j = li
 #pragma unroll
@@ -750,15 +795,16 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             const float pr = bx[r] * Cn;                       // x_nq C_n (q = li; bx is x of column n0 + r at coordinate li)
             if (li < Q) {
                 dl3 = fmaf(bx[r], pr, dl3);
-                if (a.dX && cval) atomic_add(a.dX + (n0 + r) * Q + li, (pr - C2[r]) * (ilj * (1.f / CS) * fl));
+                if (a.dX && cval) atomic_add(a.dX + (int64_t)(n0 + r) * Q + li, (pr - C2[r]) * (ilj * (1.f / CS) * fl));
             }
         }
+        BT_STAMP2(7, 7, dl3);
         if constexpr (AHEAD) {
             if (!has_next) break;
             cur = nxt; nt0 = nt0n; tb_c = tb_n; tl_c = tl_n;
         } else {
             nt0 = col_nt0(it + 1);
-            if (it + 1 >= a.CT || nt0 >= a.SB) break;
+            if (it + 1 >= a.CT || nt0 >= sb) break;
         }
     }
     }
@@ -968,6 +1014,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     const bool f16 = f16_env && kind == MXF_K_RBF && h0max != nullptr;
     unsigned* mx = reinterpret_cast<unsigned*>(zacc + (size_t)M * 16 + 8);          // two words behind dls3[8], zeroed with the accumulators
     const float* Urow = Text + M * SB;
+    if (SB > 2147483647LL - 4096) MXF_FAIL(h, -3, "svgp reverse pass: more than 2^31 columns (%lld)", (long long)SB);       // (32-bit column indices in the pass)
     const int64_t nsamp = SB / B;         // (the matrix-pipe pass requires B % 16 == 0 and whole samples: SB = S B)
     if (nsamp > 65535 || nsamp * B != SB) MXF_FAIL(h, -3, "svgp reverse pass: bad sample layout (SB %lld, B %lld)", (long long)SB, (long long)B);
     hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr, cs,
