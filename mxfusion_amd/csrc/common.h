@@ -19,7 +19,35 @@
 #define MXF_KNOB_SET(name) (false)
 #endif
 
+// Probe build only (MXF_SVGP_STAGES=1): device-time stamps of the SVGP training call's stages, printed (stderr) at the end of the call after a
+// device synchronise -- the call's own critical path without a profiler in the way (the profiler's ~30 us per launch makes a 4-sample step
+// host-bound and its timeline misleading).  tests/probes/svgp_stages.py
+#ifdef MXF_PROBES
+struct mxf_stage_log {
+    static const int N = 48;
+    hipEvent_t ev[N]; const char* name[N]; int n = 0; bool made = false;
+    void mark(const char* nm, hipStream_t s) {
+        if (!made) { for (int i = 0; i < N; ++i) (void)hipEventCreate(&ev[i]); made = true; }
+        if (n < N) { name[n] = nm; (void)hipEventRecord(ev[n], s); ++n; }
+    }
+    void dump() {
+        (void)hipDeviceSynchronize();
+        for (int i = 1; i < n; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[0], ev[i]); fprintf(stderr, "  stage %-28s %8.3f ms\n", name[i], ms); }
+        fprintf(stderr, "  --\n");
+        n = 0;
+    }
+};
+#define MXF_STAGE(h, nm, s) do { static const bool on_ = MXF_KNOB("MXF_SVGP_STAGES", 0) != 0; if (on_) (h)->stages.mark(nm, s); } while (0)
+#define MXF_STAGE_DUMP(h) do { static const bool on_ = MXF_KNOB("MXF_SVGP_STAGES", 0) != 0; if (on_) (h)->stages.dump(); } while (0)
+#else
+#define MXF_STAGE(h, nm, s) do { } while (0)
+#define MXF_STAGE_DUMP(h) do { } while (0)
+#endif
+
 struct mxf_ctx {
+#ifdef MXF_PROBES
+    mxf_stage_log stages;
+#endif
     int device = 0;
     std::string err;
     void* ws = nullptr;     // scratch, grown on demand (hipMalloc; never inside graph capture)

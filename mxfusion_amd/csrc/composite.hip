@@ -643,6 +643,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // (W and diag(s) are converted on the second side stream, where Su is formed: two launches less in front of the Kuu chain)
     // (everything the Kuu chain does not need itself -- noise, mu, W, diag(s), the scalar accumulators -- is prepared on the second side
     //  stream, where Su is formed; the main stream waits for that stream's ev_su before it first touches them)
+    MXF_STAGE(h, "start", st);
     hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2);
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
@@ -677,6 +678,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Wd, M, 0, Wd, M, 0, 1.0, Su, M, 0, 1, 0, s2_);       // Su = W W^T + diag(s) :76
     if (rc) return rc;
     MXF_HIP(h, hipEventRecord(h->ev_su, s2_));           // H0 needs Su only; its Cholesky (log-det, Su^-1 for the reverse mode) is OFF the critical path
+    MXF_STAGE(h, "Su formed (s2)", s2_);
     // Enqueue order = priority order (the host needs ~5 us per launch and a step has ~280 of them): first the few launches that carry
     // the bulk of the device work (Grams, Psi2), then the latency-critical Kuu chain, then the Su chain.
     // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
@@ -689,6 +691,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
                                       (int64_t)pl_big, gscr0, sd_, split_mode);
         if (rc) return rc;
+        MXF_STAGE(h, "Kuf planes (sd)", sd_);
         // (the Kfu planes -- operand (n, k = m) of the T GEMM -- are written later, on the second side stream, once w = Kuu^-1 mu exists:
         //  the same pass then also forms the row U = w^T Kuf)
     } else {
@@ -736,6 +739,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             }
         }
         hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_STAGE(h, "Psi2 (sd)", sd_);
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
     }
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
@@ -751,8 +755,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
+    MXF_STAGE(h, "potrf Kuu", st);
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
+    MXF_STAGE(h, "trtri Kuu", st);
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
@@ -761,6 +767,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
+    MXF_STAGE(h, "Ki, w", st);
     if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w ready: the Kfu planes + U pass may start
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
@@ -770,6 +777,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, s2_, (int64_t)1, MM, (const D*)Su, MM, tmp, MM);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_, false, false);                  // Ls = chol(Su) :84
     if (rc) return rc;
+    MXF_STAGE(h, "potrf Su (s2)", s2_);
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, tmp, M, MM, sc + 1, s2_);
     if (rc) return rc;
     if (want_grad) {
@@ -778,14 +786,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Lsinv, M, 0, Lsinv, M, 0, 0.0, Sui, M, 0, 1, 0, s2_);
         if (rc) return rc;
     }
+    MXF_STAGE(h, "Su^-1 (s2)", s2_);
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
     if (use_split) {
         // Kfu planes (operand (n, k = m) of the T GEMM) + the row U = w^T Kuf in ONE pass, behind the Su chain on the second side stream:
-        // HBM-write bound, it runs next to the MFMA-bound Psi2 product
+        // HBM-write bound.  (r03, tests/probes/svgp_stages.py: the pass starts when w = Kuu^-1 mu exists, and the Kuu chain -- potrf, trtri,
+        // Ki -- shares the chip with the Kuf planes pass and Psi2 and finishes just after Psi2: 0.9 / 1.4 / 1.6 ms at 4 samples against 0.6
+        // alone.  A stream of its own for this pass changes nothing: H0, hence the T GEMM, waits for the same chain.)
         MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
                                       (int64_t)pl_big, gscr1, s2_, split_mode, (const float*)wT, P, (float*)(Text + M * SB), SB);
         if (rc) return rc;
+        MXF_STAGE(h, "Kfu planes + U (s2)", s2_);
         MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes and U ready: the T GEMM / the reverse pass wait for it
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su formed (second side stream)
@@ -810,6 +822,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st, split_mode, split_mode == MXF_SPLIT_F16X2 ? h0max : nullptr);
         if (rc) return rc;
     }
+    MXF_STAGE(h, "H0 planes", st);
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
@@ -819,6 +832,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
+    MXF_STAGE(h, "T", st);
     if (use_split) {
         // (U = w^T Kuf was written by the Kfu planes pass)
     } else {
@@ -851,6 +865,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
         rc = su_reverse(sd_, true);
         if (rc) return rc;
+        MXF_STAGE(h, "Su reverse (sd)", sd_);
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
@@ -905,6 +920,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
                                          (const unsigned*)(info2 + 3));
         if (rc) return rc;
     }
+    MXF_STAGE(h, "reverse pass", st);
     if (!het) {
         hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
                            (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
@@ -955,8 +971,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         }
     }
     if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    MXF_STAGE(h, "core reverse", st);
     hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
+    MXF_STAGE(h, "end", st);
+    MXF_STAGE_DUMP(h);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
