@@ -7,6 +7,8 @@ python bench.py --minibatch 8192 --samples 4 --steps 30 --warmup 5 --no-cpu-base
 python bench.py --workload gp --dtype float64 --steps 5 --warmup 2 --no-cpu-baseline > $O/r03_bench_exact_gp_f64.json 2>/dev/null
 python bench.py --workload deepgp --samples 4 --steps 10 --warmup 3 --no-cpu-baseline > $O/r03_bench_deepgp_4samples.json 2>/dev/null
 python bench.py --workload deepgp --samples 32 --steps 5 --warmup 2 --no-cpu-baseline > $O/r03_bench_deepgp_32samples.json 2>/dev/null
+python bench.py --workload deepgp --samples 4 --no-f32-guard --steps 10 --warmup 3 --no-cpu-baseline > $O/r03_bench_deepgp_4samples_raw_f32.json 2>/dev/null
+python bench.py --workload deepgp --samples 32 --no-f32-guard --steps 5 --warmup 2 --no-cpu-baseline > $O/r03_bench_deepgp_32samples_raw_f32.json 2>/dev/null
 python bench.py --workload pilco --dtype float64 --graph 1 --steps 5 --warmup 3 --no-cpu-baseline > $O/r03_bench_pilco_f64_graph.json 2>/dev/null
 for f in $O/*.json; do python - $f <<'PY'
 import json,sys
