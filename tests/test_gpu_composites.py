@@ -228,7 +228,10 @@ def test_svgp_logpdf_mat_vs_oracle(dtype, tol, nshape):
 
 
 @pytest.mark.parametrize('kind', ['rbf', 'matern32'])
-@pytest.mark.parametrize('B,M,Q,P,S', [(512, 128, 8, 1, 2), (2048, 256, 3, 2, 1), (1040, 144, 16, 1, 3)])
+# (512, 128, .., 1, 2) / (1024, 256, 8, 1, 1): the matrix-pipe reverse pass with its f16 accumulation scaled from the max |T| word of the 128- / 256-row
+# wide GEMM; (1040, 144, 5, 1, 1): the same pass on ragged tiles (M % 128 != 0, S B % 64 != 0) behind the narrow split GEMM, which reports no
+# max |T|: the sigma^2 M max|H0| bound; P = 2 / Q = 16: the generic reverse pass
+@pytest.mark.parametrize('B,M,Q,P,S', [(512, 128, 8, 1, 2), (2048, 256, 3, 2, 1), (1040, 144, 16, 1, 3), (1040, 144, 5, 1, 1), (1024, 256, 8, 1, 1)])
 def test_svgp_logpdf_f32_split_path_vs_oracle(kind, B, M, Q, P, S):
     """The float32 training step as the bench runs it: Grams written as three-term bf16 planes, both big GEMMs on the bf16 matrix
     pipe (gemm_split.hip), w^T Kuf from the planes.  Taken when S*B and M are multiples of 16 and M >= 128 (every other f32 test in this
