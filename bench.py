@@ -426,17 +426,20 @@ def _pmc_traffic(stem):
     return None, None
 
 
-def gram_roofline(N, Q, dtype, reps=40):
+def gram_roofline(N, Q, dtype, reps=200):
     """RBF Gram at N x N, Q: algorithmic bytes = N*N*sizeof written + 2*N*Q*sizeof read, timed with HIP
-    events on the stream the kernel is launched on (torch's current stream).  40 timed launches behind 2 untimed ones: the first launch
-    of a process runs ~20 % longer (cold TLB / clocks), and a rocprofv3 --stats average of the same command should not be moved by it."""
+    events on the stream the kernel is launched on (torch's current stream).  200 timed launches behind 20 untimed ones.  The launch time
+    RAMPS after the idle gap in front of this measurement (the 17 GB output is allocated first): rocprofv3 per-launch durations of the r03
+    trace are 3.05, 3.71 | 3.23, 3.07, 2.89, 2.88, 2.79, ... and 2.61 - 2.68 ms from the 15th launch on (clocks coming back up).  A long window
+    reports the sustained rate, and a rocprofv3 --stats average of the same command (all 220 launches) agrees with it to ~1 %; with 2 + 40
+    launches the ramp was a third of the window (0.79 instead of 0.80 - 0.81 of 8 TB/s)."""
     from mxfusion_amd import ops
     td = torch.float32 if dtype == 'float32' else torch.float64
     X = torch.rand(1, N, Q, device='cuda', dtype=td) * 6 - 3
     ls = torch.ones(1, Q, device='cuda', dtype=td)
     var = torch.ones(1, 1, device='cuda', dtype=td)
     out = torch.empty(1, N, N, device='cuda', dtype=td)
-    for _ in range(2):
+    for _ in range(20):
         ops.gram('rbf', X, None, ls, var, True, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -460,10 +463,12 @@ def gram_roofline(N, Q, dtype, reps=40):
                             "6.93 TB/s; hipMemsetAsync 6.15 TB/s"}
 
 
-def mfma_roofline(M, SB, dtype, reps=3):
+def mfma_roofline(M, SB, dtype, reps=12):
     """The dominant MFMA kernel of the step: T = H0 Kuf_all  (M x M x SB).  float32: gemm_split_kernel -- f32 operands as two scaled f16
     terms, three f16 MFMA products, f32 accumulate (f32-equivalent accuracy); its peak is the dense f16 MFMA peak / 3.
-    float64: gemm_kernel on v_mfma_f64_16x16x4_f64."""
+    float64: gemm_kernel on v_mfma_f64_16x16x4_f64.
+    12 timed launches behind 1 untimed: behind the idle gap of the operand set-up the launch time ramps down (r03 trace: 11.9 | 11.5, 11.2, 11.0 ms)
+    as the clocks come back up; three launches reported the ramp."""
     from mxfusion_amd import ops
     fl = 2.0 * M * M * SB
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -499,7 +504,7 @@ def mfma_roofline(M, SB, dtype, reps=3):
     return r
 
 
-def mfma_roofline_psi2(M, SB, reps=3):
+def mfma_roofline_psi2(M, SB, reps=12):
     """The second MFMA kernel of the float32 step: Psi2 = Kuf Kuf^T (M x M x SB, lower blocks only) on gemm_f16x2_wide_kernel (128 x 256
     tiles, B fragments straight from global memory).  Flops counted for the lower triangle incl. the diagonal blocks it computes in full."""
     from mxfusion_amd import ops
