@@ -761,6 +761,123 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+// ---- the block rows BELOW an outer panel (r03) ------------------------------------------------------------------------------------------
+// After the panel's own block rows are factored (potrf_tiles_kernel, the latency chain), every row below solves  L[i][0..npt) L11^T = A[i][0..npt)
+// against the FINISHED diagonal block L11.  potrf_tiles_kernel did that one 64 x 64 tile at a time, left-looking, the whole workgroup on one
+// tile: ~37 us per tile, 0.3 ms per outer panel at n = 8192 although a block row's matrix work is 25 us (these launches were 2.5 of
+// potrf(8192)'s 7.3 ms, and only rows / 64 <= 120 of the 256 CUs had a workgroup).  Here a workgroup of EIGHT waves keeps the block row's eight
+// tiles in registers, one per wave (64 x 64 float64 = 128 VGPRs in the accumulator layout), and goes RIGHT-looking:
+//   step k: the owner of tile k puts it into LDS (two buffers, alternating);  waves 0..3 solve  X L[k][k]^T = T  in place, 16 rows each, with
+//   the published inverses of L[k][k]'s four 16 x 16 diagonal blocks (the substitution of potrf_tiles_kernel);  X goes to global memory (it is
+//   L[i][k]);  every wave j > k updates its tile in place,  A[i][j] -= X L[j][k]^T,  the L[j][k] operand straight from global memory (L11 is
+//   2 MB: L2-resident, every workgroup reads the same tiles) three 16-column groups ahead of the MFMAs that use them.
+// Two barriers per step; the critical chain of a block row is npt x (solve + one tile update by one wave, 256 MFMAs).
+// MFMA conventions as potrf_tiles_kernel: A operand lane (li, lq) = P[m = li][k = lq], B operand = Q[n = li][k = lq], accumulator register r of
+// lane (li, lq) = element (row lq + 4 r, column li).
+__global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int row0,
+                                                         const double* __restrict__ inv_all) {
+    __shared__ double Tb[2][NB][NB + 1];
+    __shared__ double a[NB][NB + 1];          // L[k][k]
+    __shared__ double minv[4][16][17];        // the inverses of its four 16 x 16 diagonal blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int i = row0 + (int)blockIdx.x, b = blockIdx.y;
+    double* Ab = A + (int64_t)b * sA;
+    const double* invs = inv_all + (int64_t)b * npt * 1024;
+    const int64_t ri = c0 + (int64_t)i * NB;
+    const bool own = wave < npt;
+    const int64_t rjw = c0 + (int64_t)wave * NB;
+    pt_f64x4 acc[4][4];
+    if (own) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] = Ab[(ri + 16 * x + lq + 4 * r) * lda + rjw + 16 * y + li];
+    }
+    for (int k = 0; k < npt; ++k) {
+        const int64_t rk = c0 + (int64_t)k * NB;
+        double (*T)[NB + 1] = Tb[k & 1];
+        // operands that do not depend on this step's tile: requested in front of the barriers
+        double lv[8];                           // L[k][k], element e = tid + 512 u <-> (row e / 64, column e % 64); lower triangle
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, rr = e >> 6, cc = e & 63;
+            lv[u] = (cc <= rr) ? Ab[(rk + rr) * lda + rk + cc] : 0.0;
+        }
+        const double mv0 = invs[(int64_t)k * 1024 + tid], mv1 = invs[(int64_t)k * 1024 + 512 + tid];
+        const bool upd = own && wave > k;
+        const double* lj = Ab + (rjw + li) * lda + rk + lq;            // L[j = wave][k][n = li + 16 y][c = lq + 4 q]
+        // the update's B operand in groups of four k steps (16 columns of L[j][k]), three groups ahead of the MFMAs that use them
+        auto lgroup = [&](int g, double (&d)[4]) {           // group g = 4 y + qq: rows 16 y + li, columns 16 qq + 4 t + lq
+            const double* p = lj + (int64_t)16 * (g >> 2) * lda + 16 * (g & 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = p[4 * t];
+        };
+        double b0[4], b1[4], b2[4], b3[4];
+        if (upd) { lgroup(0, b0); lgroup(1, b1); lgroup(2, b2); }
+        if (wave == k) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[16 * x + lq + 4 * r][16 * y + li] = acc[x][y][r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + 512 * u; a[e >> 6][e & 63] = lv[u]; }
+        minv[tid >> 8][(tid >> 4) & 15][tid & 15] = mv0;
+        minv[2 + (tid >> 8)][(tid >> 4) & 15][tid & 15] = mv1;
+        __syncthreads();
+        if (wave < 4) {
+            // X L[k][k]^T = T, 16 rows per wave, in registers (accumulator layout of the TRANSPOSED tile: lane (li, lq), register r = element
+            // (row li, column lq + 4 r) of a 16 x 16 block): X_b = Y_b M_b^T with the published inverse M_b (4 MFMAs), then
+            // Y_b'' -= X_b L_b''b^T for the blocks to the right -- as potrf_tiles_kernel
+            pt_f64x4 mreg[4], tacc[4];
+            const int rw = wave * 16;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mreg[bb][r] = minv[bb][li][4 * r + lq]; tacc[bb][r] = T[rw + li][16 * bb + lq + 4 * r]; }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                pt_f64x4 xs = pt_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[bb][r], tacc[bb][r], xs, 0, 0, 0);
+#pragma unroll
+                for (int b2i = bb + 1; b2i < 4; ++b2i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tacc[b2i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[16 * b2i + li][16 * bb + 4 * r + lq], xs[r], tacc[b2i], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[rw + li][16 * bb + lq + 4 * r] = xs[r];
+            }
+        }
+        __syncthreads();
+        {   // L[i][k] = X to global memory, coalesced
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 512 * u, rr = e >> 6, cc = e & 63; Ab[(ri + rr) * lda + rk + cc] = T[rr][cc]; }
+        }
+        if (upd) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+#pragma unroll 1
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int g = 4 * y + qq;
+                    if (g + 3 < 16) lgroup(g + 3, b3);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+                            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[16 * x + li][16 * qq + 4 * t + lq], b0[t], acc[x][y], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { b0[t] = b1[t]; b1[t] = b2[t]; b2[t] = b3[t]; }
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info) {
     if (info && zero_info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
@@ -812,7 +929,10 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 double* pinv = mxf_potrf_inv(h, (size_t)npt * S * 1024);
                 if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
                 hipLaunchKernelGGL(potrf_tiles_kernel, dim3(na, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, 0, 0);
-                if (split)
+                static const int rows_env = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
+                if (split && rows_env) {       // r03: the rows below right-looking from registers (potrf_rows_kernel)
+                    hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbr - npt, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
+                } else if (split)
                     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr - npt, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, (int)npt, 1);
             }
         }
