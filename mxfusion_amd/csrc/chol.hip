@@ -772,6 +772,9 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 //   L[i][k]);  every wave j > k updates its tile in place,  A[i][j] -= X L[j][k]^T,  the L[j][k] operand straight from global memory (L11 is
 //   2 MB: L2-resident, every workgroup reads the same tiles) three 16-column groups ahead of the MFMAs that use them.
 // Two barriers per step; the critical chain of a block row is npt x (solve + one tile update by one wave, 256 MFMAs).
+// (Measured and dropped: this launch NEXT TO the panel's chain on a second auxiliary stream, following the chain's progress counters column
+//  by column -- it then ends 17 us after the chain, but the chain itself takes 0.30 - 0.36 instead of 0.19 ms (the followers' acquire fences
+//  and tile reads share its L2) and 120 mostly waiting workgroups hold CUs the look-ahead GEMM wants: potrf(8192) 7.18 vs 6.72 ms.)
 // MFMA conventions as potrf_tiles_kernel: A operand lane (li, lq) = P[m = li][k = lq], B operand = Q[n = li][k = lq], accumulator register r of
 // lane (li, lq) = element (row lq + 4 r, column li).
 __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int row0,
