@@ -914,7 +914,16 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     (void)hipStreamIsCapturing(st, &cap);
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
     hipStream_t ax = look ? h->potrf_aux : st;
-    bool pending_b = false;
+    bool pending_b = false, pending_h = false;
+    static const int split_rows_g = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
+    static const int rows_env_g = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
+    static const int head_split_env = MXF_KNOB("MXF_POTRF_HEAD_SPLIT", 1);  // 1: the next panel's rows-below head update on the auxiliary stream
+    // does the outer panel at c0 take the split form (chain launch + rows-below launch)?
+    auto is_split = [&](int64_t c0_) {
+        const int64_t pe_ = (c0_ + NBO < n) ? c0_ + NBO : n;
+        const int64_t nbr_ = (n - c0_) / NB, npt_ = (pe_ - c0_) / NB;
+        return panel_tiles && split_rows_g > 0 && nbr_ - npt_ >= split_rows_g;
+    };
     for (int64_t c0 = 0; c0 < n; c0 += NBO) {
         const int64_t pe = (c0 + NBO < n) ? c0 + NBO : n;   // panel end
         if constexpr (sizeof(T) == 8) {
@@ -924,15 +933,16 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 // rows below against the finished diagonal block, nothing to wait for (~90 us of MFMA work each).  In one launch those rows
                 // sit resident and mostly idle for the whole chain, one CU each, and the look-ahead GEMM next to them (whose 133 KB of LDS
                 // cannot share a CU with a tile workgroup) runs on what is left.
-                static const int split_rows = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
-                const bool split = split_rows > 0 && nbr - npt >= (unsigned)split_rows;
+                const bool split = is_split(c0);
                 const unsigned na = split ? npt : nbr;
                 int* progress = mxf_flags(h, (na + 1) * (unsigned)S);
                 if (!progress) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the workgroup hand-off counters");
                 double* pinv = mxf_potrf_inv(h, (size_t)npt * S * 1024);
                 if (!pinv) MXF_FAIL(h, -4, "mxf_potrf: cannot allocate the inverse-block scratch");
                 hipLaunchKernelGGL(potrf_tiles_kernel, dim3(na, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, 0, 0);
-                static const int rows_env = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
+                const int rows_env = rows_env_g;
+                // (the rows below this panel's diagonal block were updated on the auxiliary stream, next to the chain above)
+                if (pending_h) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0)); pending_h = false; }
                 if (split && rows_env) {       // r03: the rows below right-looking from registers (potrf_rows_kernel)
                     hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbr - npt, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
                 } else if (split)
@@ -960,17 +970,30 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
                 if (rc) return rc;
             } else {
-                if (look_env != 2) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // the panel's columns (L21) are final
-                // next outer panel's columns on the caller's stream: its diagonal block (lower) and the rows below it
+                // r03: when the NEXT panel takes the split form, only its diagonal block (what its chain launch reads) is updated on the caller's
+                // stream; the rows below it -- read by potrf_rows_kernel only, 0.2 ms later -- are updated on the auxiliary stream next to that
+                // chain (0.09 ms per panel off the serial path at n = 8192)
+                const bool head_aux = head_split_env && sizeof(T) == 8 && rows_env_g && is_split(pe);
+                if (look_env != 2 || head_aux) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // the panel's columns (L21) are final
+                // next outer panel's columns: its diagonal block (lower) and the rows below it
                 int rc = mxf_gemm_internal(h, dtype, 0, 1, pe2 - pe, pe2 - pe, K, -1.0, A + pe * lda + c0, lda, sA,
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
                 if (rc) return rc;
-                rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
-                                       A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, st);
-                if (rc) return rc;
-                if (look_env == 2) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // (2: the rest-update only starts once the head products are done)
+                if (head_aux) {
+                    MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_pa, 0));
+                    rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
+                                           A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, ax);
+                    if (rc) return rc;
+                    MXF_HIP(h, hipEventRecord(h->ev_ph, ax));
+                    pending_h = true;
+                } else {
+                    rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
+                                           A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, st);
+                    if (rc) return rc;
+                    if (look_env == 2) MXF_HIP(h, hipEventRecord(h->ev_pa, st));  // (2: the rest-update only starts once the head products are done)
+                    MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_pa, 0));
+                }
                 // the rest on the auxiliary stream, next to the next panel's factorisation
-                MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_pa, 0));
                 rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, n - pe2, K, -1.0, A + pe2 * lda + c0, lda, sA,
                                        A + pe2 * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe2, lda, sA, S, 1, ax);
                 if (rc) return rc;

@@ -55,7 +55,7 @@ struct mxf_ctx {
     hipStream_t side = nullptr;   // internal side streams: independent chains of the SVGP step run concurrently
     hipStream_t side2 = nullptr;
     hipStream_t potrf_aux = nullptr;                        // look-ahead stream of the blocked Cholesky (chol.hip)
-    hipEvent_t ev_pa = nullptr, ev_pb = nullptr;
+    hipEvent_t ev_pa = nullptr, ev_pb = nullptr, ev_ph = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
@@ -162,7 +162,8 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
 static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
     if (h->potrf_aux) return true;
     if (hipStreamCreateWithFlags(&h->potrf_aux, hipStreamNonBlocking) != hipSuccess) { h->potrf_aux = nullptr; return false; }
-    if (hipEventCreateWithFlags(&h->ev_pa, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pb, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&h->ev_pa, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pb, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ph, hipEventDisableTiming) != hipSuccess)
         return false;
     return true;
 }

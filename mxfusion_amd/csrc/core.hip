@@ -38,6 +38,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->potrf_aux) (void)hipStreamDestroy(h->potrf_aux);
     if (h->ev_pa) (void)hipEventDestroy(h->ev_pa);
     if (h->ev_pb) (void)hipEventDestroy(h->ev_pb);
+    if (h->ev_ph) (void)hipEventDestroy(h->ev_ph);
     delete h;
     return 0;
 }
