@@ -777,6 +777,7 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 //  and tile reads share its L2) and 120 mostly waiting workgroups hold CUs the look-ahead GEMM wants: potrf(8192) 7.18 vs 6.72 ms.)
 // MFMA conventions as potrf_tiles_kernel: A operand lane (li, lq) = P[m = li][k = lq], B operand = Q[n = li][k = lq], accumulator register r of
 // lane (li, lq) = element (row lq + 4 r, column li).
+static_assert(NBO / NB <= 8, "potrf_rows_kernel: one wave per tile of the panel, eight waves");
 __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int row0,
                                                          const double* __restrict__ inv_all) {
     __shared__ double Tb[2][NB][NB + 1];
