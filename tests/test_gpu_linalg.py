@@ -23,7 +23,10 @@ def _dev(a, dtype=torch.float64):
                                  # n % 64 == 0, 128 <= n <= 1024 in float64: the one-launch tile-dataflow kernel (batched)
                                  (3, 128), (2, 192), (1, 640), (2, 1024),
                                  # larger n % 64 == 0 in float64: the same kernel once per 512-column outer panel
-                                 (1, 1536), (2, 2048)])
+                                 (1, 1536), (2, 2048),
+                                 # 64 block rows below the first outer panel: chain launch + potrf_rows_kernel, the next panel's rows-below head
+                                 # update on the auxiliary stream (production knobs)
+                                 (1, 4608)])
 def test_potrf_trsm_trtri_logdet(dtype, tol, S, n):
     from mxfusion_amd import ops
     rng = np.random.RandomState(n)
