@@ -385,9 +385,14 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // shared barrier together, want the matrix pipe together and then wait for LDS / memory together.
 // BLO = false: the B operand enters through its HIGH plane only (B rounded to f16, A still exact: two products instead of three, half the B
 // fetch) -- for products that feed GRADIENTS only (the T of the SVGP step; DESIGN.md section 4 states the error this leaves in them).
-template <int XT, int NH, bool PP, bool BLO = true>
+// LSKIP (lower-only products): a wave whose 128 x 64 block lies strictly ABOVE the diagonal (the upper right quarter of a diagonal 256 x 256
+// tile: 2 of its 8 waves) runs a k loop WITHOUT its B loads and MFMAs -- it still fetches its share of the A slab and keeps every barrier.
+// (A branch around the MFMAs inside the one loop cost the kernel its schedule, see below; here the loop exists twice and the idle form is a
+//  separate instantiation, so the T product's kernel is untouched.)  The busiest SIMDs still carry two working waves: the gain is power.
+template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false>
 __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
+    static_assert(!LSKIP || (!PP && BLO), "the idle-wave loop mirrors the plain pipelined loop");
     constexpr int WBMt = 32 * XT * NH;             // A rows per tile
     constexpr int NU = 64 * XT * NH;               // 16-byte units of one plane's (WBMt x 16) slab
     constexpr int ND = XT / 4;                     // LDS-DMA requests per thread, plane and k block
@@ -538,6 +543,52 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         __builtin_amdgcn_s_setprio(0);                                                                                              \
         W_PHASE_END();                                                                                                              \
     } while (0)
+    bool idle = false;
+    if constexpr (LSKIP) idle = g.lower_only && (m0 + 32 * XT * wh + 32 * XT - 1) < (n0 + 64 * wq);      // wave-uniform
+    if (LSKIP && idle) {
+        if (kbeg < kend) {
+            // the same sequence of A requests, barriers and rendezvous as the working waves' loop below
+#define W_ISSUE_A(kb, SLOT)                                                                                                         \
+            do {                                                                                                                    \
+                _Pragma("unroll") for (int u_ = 0; u_ < ND; ++u_) {                                                                 \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + u_ * (NTH / 2) * 16 + (kb) * g.M * 16), \
+                                                     (__attribute__((address_space(3))) void*)(&smem[SLOT][0][wave * 64 + NTH * u_]), 16, 0, 0); \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da + u_ * (NTH / 2) * 16 + g.pA + (kb) * g.M * 16), \
+                                                     (__attribute__((address_space(3))) void*)(&smem[SLOT][1][wave * 64 + NTH * u_]), 16, 0, 0); \
+                }                                                                                                                   \
+            } while (0)
+#define W_WAITL(NSTR) do { asm volatile("s_waitcnt vmcnt(" NSTR ")" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+            const int64_t klast = kend - 1;
+            int64_t kb = kbeg;
+            for (int i = (int)((kend - kbeg) % 3); i > 0; --i, ++kb) {
+                W_ISSUE_A(kb, 0);
+                W_WAITL("0");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kb < kend) {
+                W_ISSUE_A(kb, 0);
+                W_ISSUE_A(kb + 1, 1);
+                if constexpr (XT == 4) W_WAITL("2"); else W_WAITL("4");
+                int trip = 0, sync_ix = 0;
+                for (; kb < kend; kb += 3) {
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3) {
+                        const int64_t k2_ = kb + s3 + 2 < kend ? kb + s3 + 2 : klast;
+                        if (s3 == 0) W_ISSUE_A(k2_, 2); else if (s3 == 1) W_ISSUE_A(k2_, 0); else W_ISSUE_A(k2_, 1);
+                        if constexpr (XT == 4) W_WAITL("2"); else W_WAITL("4");
+                    }
+                    if (g.sync_period > 0 && ++trip == g.sync_period) {
+                        trip = 0;
+                        if (sync_ix < g.sync_slots) wg_rendezvous(g.sync + split * g.sync_slots + sync_ix, (unsigned)g.sync_n, patience);
+                        ++sync_ix;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#undef W_WAITL
+#undef W_ISSUE_A
+        }
+    } else
     if (kbeg < kend) {
         const int64_t klast = kend - 1;
         int64_t kb = kbeg;
@@ -641,6 +692,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_wide_kernel_256w4(SplitArgs
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g) { wide_body<4, 2, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256lo(SplitArgs g) { wide_body<4, 2, false, true, true>(g); }
 
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
@@ -777,9 +829,11 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
             }
         }
         static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
+        static const int lskip_env = (int)MXF_KNOB("MXF_SPLIT_LSKIP", 1);  // lower-only products: the waves above the diagonal idle (see wide_body)
         static const int bhi_env = (int)MXF_KNOB("MXF_SPLIT_BHI", 0);      // experiment: B through its high plane only, blocked-output products
         if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (NH == 2 && lower_only && lskip_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256lo, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (XT == 8) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256w4, dim3((unsigned)grid), dim3(256), 0, st, g);
         else hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128, dim3((unsigned)grid), dim3(256), 0, st, g);
