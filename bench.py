@@ -525,7 +525,7 @@ def mfma_roofline_psi2(M, SB, reps=12):
     torch.cuda.empty_cache()
     fl = 2.0 * (M * (M + 1) / 2.0) * SB
     traffic, traffic_src = _pmc_traffic('gemm_psi2_pmc') if (M == 1024 and SB == 2097152) else (None, None)
-    return {"bound": "mfma", "kernel": "gemm_f16x2_wide_kernel_256 (lower blocks, split-K) %dx%dx%d" % (M, M, SB), "achieved": fl / ms / 1e9,
+    return {"bound": "mfma", "kernel": "gemm_f16x2_wide_kernel_256lo (lower blocks, split-K; waves above the diagonal idle) %dx%dx%d" % (M, M, SB), "achieved": fl / ms / 1e9,
             "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / (2500.0 / 3.0), "traffic": traffic, "traffic_source": traffic_src,
             "ms_per_launch": ms, "algorithmic_flops": fl}
 
