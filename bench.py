@@ -628,12 +628,11 @@ def main():
         Float32Guard.enabled = False
 
     def guard_report():
-        """float32 validity of what was timed: the largest cond_1(Kuu + jitter I) the training calls published, and whether the SVGP module
-        switched its streaming stage to float64 (it does above 3e3)."""
-        from mxfusion_amd import ops
+        """float32 validity of what was timed: the largest cond_1(Kuu + jitter I) the training calls published and the level every SVGP
+        module ended on (explicit-inverse float32 up to 3e3, whitened float32 up to 5e6, float64 above: DESIGN.md section 5)."""
         from mxfusion_amd.modules.gp_modules._fused import Float32Guard
         torch.cuda.synchronize()
-        return {"kuu_cond_max": ops.svgp_cond_nowait(), "float32_fallback_active": bool(Float32Guard.active), "float32_guard": bool(Float32Guard.enabled)}
+        return Float32Guard.report(torch.device('cuda', torch.cuda.current_device()))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world != max(1, args.gpus) and not args.force_dist:

@@ -63,6 +63,22 @@ int mxf_svgp_last_cond(mxf_handle h, double* cond1_out);
  * clears it after the read.  A caller polls it every step for free and lags by at most the calls still in flight -- the float32 guard of
  * mxfusion_amd's SVGP module (automatic switch of the streaming stage to float64 above ~3e3) is built on it.  No reference counterpart. */
 int mxf_svgp_cond_nowait(mxf_handle h, double* cond1_max_out, int reset);
+/* Float32 streaming form of the NEXT mxf_svgp_logpdf / _sampled training calls on this handle, and the slot (0 <= cond_slot < 64) they
+ * publish their condition number into.  MXF_SVGP_EXPLICIT (default): T = H0 Kuf with the explicit inverse H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1
+ * (two full-width split GEMMs; error ~ cond 2^-24).  MXF_SVGP_WHITENED: the factorised form the reference evaluates
+ * (svgp_regression.py:83-92: trsm with the Cholesky factor) on the split GEMMs -- V = L^-1 Kuf (triangular product, written directly as
+ * f16 planes), Phi = V V^T, T = L^-T (I - A_s A_s^T) V, U = (L^-1 mu)^T V -- three full-width products; every operand is bounded by
+ * |L^-1| ~ sqrt(cond) and |v_n|^2 <= k_nn, so the float32 error grows like sqrt(cond) 2^-24 (ELBO 1e-7 at cond_2 1e5, 1e-6 at 4e6).
+ * Applies to float32 training calls (want_grad) on shapes mxf_svgp_whitened_ok accepts; such a call on another shape fails with -3.
+ * float64 calls ignore the form.  No reference counterpart (the reference has one dtype and one form).                                   */
+enum { MXF_SVGP_EXPLICIT = 0, MXF_SVGP_WHITENED = 1 };
+int mxf_svgp_configure(mxf_handle h, int form, int cond_slot);
+/* 1 if the whitened float32 form covers this call shape (M % 128 == 0, S B % 256 == 0, Q <= 16, P <= 8, sampled X or S == 1), else 0 */
+int mxf_svgp_whitened_ok(int dtype, int S, int64_t B, int64_t M, int Q, int P, int64_t strideS_X);
+/* One slot's condition words without synchronising: the LAST value a finished call published into it and the running maximum (either
+ * pointer may be NULL); reset != 0 clears both after the read.  A module instance that owns a slot sees its own Kuu only, whatever other
+ * SVGP modules run on the same handle (mxf_svgp_cond_nowait = the maximum over all slots).                                               */
+int mxf_svgp_cond_slot(mxf_handle h, int slot, double* last_out, double* max_out, int reset);
 
 /* out[0] = sum_i g[i] if the n values agree to 1e-6 relative, NaN otherwise.  The fused composites return the gradients of
  * gscale * sum_s logL[s] with ONE weight: the reverse-mode bridge uses this to scale them by the upstream gradient of mean_S(logL)
@@ -155,6 +171,18 @@ int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, 
 int mxf_f16x2_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* maxword, void* stream);
 int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
                           const void* B_planes, const void* B_maxword, double beta, void* C, int64_t ldc, int lower_only, void* stream);
+/* Chained split products (the whitened SVGP tier, svgp_regression.py:83-92 in factorised float32 form):
+ * mxf_gemm_f16x2_planes_out writes alpha * A B^T DIRECTLY as the two f16 planes (hi + lo, UNSCALED: the caller picks alpha so that the
+ * largest magnitude sits near 2^13..2^14; as an operand of the next product its maxword is a word holding 8192.0f = scale 1) of the (M x N) operand whose contraction
+ * index is its column -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16 -- ready to be the operand of the next product; M % 128 == 0,
+ * N % 256 == 0.  a_lower != 0: A is lower triangular (A[m][k] = 0 for k > m), the k loop of a row tile stops at its last row.
+ * mxf_f16x2_planes_transpose turns the planes of an (R x K) operand into those of its transpose (K x R) (R, K multiples of 64; 4 bytes
+ * read + 4 written per element, HBM bound); U != NULL: the same pass forms U[k] = scale[0] * sum_r a[r] x(r, k) (a: R floats, scale: one
+ * float, both on the device).                                                                                                            */
+int mxf_gemm_f16x2_planes_out(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
+                              const void* B_planes, const void* B_maxword, void* C_planes, int a_lower, void* stream);
+int mxf_f16x2_planes_transpose(mxf_handle h, int64_t R, int64_t K, const void* planes_in, void* planes_out, const void* a, const void* scale,
+                               void* U, void* stream);
 
 /* The two halves of mxf_gemm_f32x3 for callers that reuse split operands (the SVGP step splits Kuf once for two products):
  * mxf_f32x3_split writes the three bf16 planes of an (R x K) float32 matrix (k16-blocked, see gemm_split.hip) into `planes`

@@ -59,6 +59,10 @@ SIGNATURES = {
                        _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_last_cond': [_c.POINTER(_d)],
     'mxf_svgp_cond_nowait': [_c.POINTER(_d), _i],
+    'mxf_svgp_configure': [_i, _i],
+    'mxf_svgp_cond_slot': [_i, _c.POINTER(_d), _c.POINTER(_d), _i],
+    'mxf_gemm_f16x2_planes_out': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    'mxf_f16x2_planes_transpose': [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_comm_unique_id': [_vp],
     'mxf_comm_init': [_i, _i, _vp],
     'mxf_allreduce_sum': [_i, _vp, _i64, _vp],
@@ -73,6 +77,7 @@ PLAIN = {  # entry points without the (handle, ...) -> int shape
     'mxf_workspace_bytes': ([_vp], _i64),
     'mxf_workspace_generation': ([_vp], _i64),
     'mxf_f32x3_plane_elems': ([_i64, _i64], _i64),
+    'mxf_svgp_whitened_ok': ([_i, _i, _i64, _i64, _i, _i, _i64], _i),
 }
 ALL_SYMBOLS = sorted(list(SIGNATURES) + list(PLAIN))
 
@@ -137,6 +142,28 @@ def svgp_cond_nowait(device_index, reset=False):
     out = _d(0.0)
     call('mxf_svgp_cond_nowait', handle(device_index), ctypes.byref(out), int(bool(reset)))
     return float(out.value)
+
+
+FORM_EXPLICIT, FORM_WHITENED = 0, 1
+COND_SLOTS = 64
+
+
+def svgp_configure(device_index, form, slot):
+    """Float32 streaming form (FORM_EXPLICIT / FORM_WHITENED) and condition slot of the next SVGP training calls of this (thread, device)
+    handle (mxf_svgp_configure)."""
+    call('mxf_svgp_configure', handle(device_index), int(form), int(slot))
+
+
+def svgp_cond_slot(device_index, slot, reset=False):
+    """(last, running max) of the condition numbers the finished training calls published into `slot` -- no synchronisation
+    (mxf_svgp_cond_slot)."""
+    last, mx = _d(0.0), _d(0.0)
+    call('mxf_svgp_cond_slot', handle(device_index), int(slot), ctypes.byref(last), ctypes.byref(mx), int(bool(reset)))
+    return float(last.value), float(mx.value)
+
+
+def svgp_whitened_ok(dtype, S, B, M, Q, P, stride_x):
+    return bool(load().mxf_svgp_whitened_ok(int(dtype), int(S), int(B), int(M), int(Q), int(P), int(stride_x)))
 
 
 def svgp_last_cond(device_index):

@@ -61,7 +61,9 @@ struct mxf_ctx {
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
     double* cond_dev = nullptr; // [ |Kuu + jitter I|_1, |(Kuu + jitter I)^-1|_1 ] of the last SVGP training call (mxf_svgp_last_cond)
-    double* cond_host = nullptr; // pinned, device-visible host word: running MAX of the condition numbers the training calls published (mxf_svgp_cond_nowait)
+    double* cond_host = nullptr; // pinned, device-visible host words, MXF_COND_SLOTS x [running MAX, last] of the condition numbers the training calls published into their slot (mxf_svgp_cond_nowait / mxf_svgp_cond_slot)
+    int svgp_form = 0;         // float32 streaming form of the next SVGP training calls (mxf_svgp_configure): 0 explicit inverse, 1 whitened
+    int cond_slot = 0;         // the slot the next SVGP training calls publish their condition number into
     void* bwd_acc = nullptr;   // scratch of the MFMA reverse pass (gram_bwd.hip): float64 row-side sums [M][16] + 16, scaled coordinates
     size_t bwd_acc_bytes = 0;
     void* comm = nullptr;      // RCCL communicator of mxf_comm_init (comm.hip); nullptr on single-GPU handles
@@ -73,6 +75,19 @@ struct mxf_ctx {
     unsigned* gsync = nullptr; // zero-initialised rendezvous counters of the wide split GEMMs (pacing hints only; gemm_split.hip); each use leaves 0 behind
     unsigned gsync_cursor = 0;
 };
+constexpr int MXF_COND_SLOTS = 64;
+// the condition words of the SVGP training call: device accumulators + the pinned host slots (allocated on first use)
+static inline bool mxf_cond_init(mxf_ctx* h) {
+    if (!h->cond_dev) {
+        if (hipMalloc((void**)&h->cond_dev, 4 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; return false; }
+        if (hipMemset(h->cond_dev, 0, 4 * sizeof(double)) != hipSuccess) return false;
+    }
+    if (!h->cond_host) {
+        if (hipHostMalloc((void**)&h->cond_host, 2 * MXF_COND_SLOTS * sizeof(double), hipHostMallocMapped) != hipSuccess) { h->cond_host = nullptr; return false; }
+        for (int i = 0; i < 2 * MXF_COND_SLOTS; ++i) h->cond_host[i] = 0.0;
+    }
+    return true;
+}
 constexpr unsigned MXF_NGSYNC = 1u << 18;
 // a fresh run of `count` zeroed rendezvous counters (rotating: a run is reused only after 2^18 / count later launches have been queued --
 // by then the launch that used it has long left them at zero); nullptr = none available (the caller then launches without rendezvous)

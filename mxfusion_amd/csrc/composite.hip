@@ -71,6 +71,14 @@ __global__ __launch_bounds__(256) void dot_kernel(int64_t n, const T* __restrict
     s = block_sum<double>(s, red);
     if (threadIdx.x == 0) atomic_add(out, s * scale);
 }
+// out += sum_ij A[i][j] * B[j][i]   (n x n, float64; tr(A B))
+__global__ __launch_bounds__(256) void dot_t_kernel(int64_t n, const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += (int64_t)gridDim.x * blockDim.x) s += A[i] * B[(i % n) * n + i / n];
+    s = block_sum<double>(s, red);
+    if (threadIdx.x == 0) atomic_add(out, s);
+}
 // copy lower triangle to upper (tiled transpose through LDS)
 template <typename T>
 __global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA) {
@@ -366,19 +374,31 @@ template <typename T>
 __global__ void svgp_finalize_kernel(int S, int64_t B, int64_t M, int P, const double* __restrict__ scal, const double* __restrict__ noise,
                                      const double* __restrict__ var, const double* __restrict__ sldL, const double* __restrict__ sldLs,
                                      const double* __restrict__ trKiSu, const double* __restrict__ muw, double scaling, double a1,
-                                     T* __restrict__ logL, double* __restrict__ dnoise, double* __restrict__ dvar_direct) {
+                                     T* __restrict__ logL, double* __restrict__ dnoise, double* __restrict__ dvar_direct,
+                                     const double* __restrict__ qfix = nullptr) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const double s2 = noise[0], beta = 1.0 / s2, vk = var[0];
     const double negKL = 0.5 * P * ((double)M + 2.0 * sldLs[0] - 2.0 * sldL[0] - trKiSu[0]) - 0.5 * muw[0];
+    // whitened tier: sum_n q_n over ALL samples = tr((I - A_s A_s^T) Phi), formed in float64 from Phi = V V^T (qfix = [c tr Phi, c tr(Su L^-T Phi L^-1)],
+    // c = P a1 beta / 2).  The reverse pass's own per-sample sums q_n = k_n . T_n multiply a recomputed float32 k_n by |T| ~ sqrt(cond): they
+    // keep the split between the samples, their total is replaced (the mean over samples -- the only reduction the reference applies,
+    // factor_graph.py:233 -- then carries the accurate total).
+    double qshift = 0;
+    if (qfix) {
+        double qs = 0;
+        for (int s = 0; s < S; ++s) qs += scal[2 * s];
+        qshift = ((qfix[0] - qfix[1]) / (0.5 * P * a1 * beta) - qs) / (double)S;
+    }
     double dn = 0;
     for (int s = 0; s < S; ++s) {
-        const double Q0 = scal[2 * s], E2 = scal[2 * s + 1];
+        const double Q0 = scal[2 * s] + qshift, E2 = scal[2 * s + 1];
         const double l = -0.5 * (double)B * P * (LOG2PI + log(s2)) - 0.5 * P * beta * (double)B * vk - 0.5 * beta * E2 + 0.5 * P * beta * Q0;
         logL[s] = (T)(scaling * l + negKL);
         dn += 0.5 * (double)B * P / beta - 0.5 * P * (double)B * vk - 0.5 * E2 + 0.5 * P * Q0;
     }
     if (dnoise) dnoise[0] = a1 * (-beta * beta) * dn;
-    if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * P * beta * (double)B);
+    // (whitened tier: the reverse pass's kernel-variance gradient contains P beta sum_n q_n / variance through Kuf -- the same total, corrected the same way)
+    if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * P * beta * (double)B) + a1 * P * beta * qshift * (double)S / vk;
 }
 
 // materialised-Gram mode (any kernel with an autograd-capable K on the host: Add / Multiply / Linear ... ): the caller passes
@@ -534,16 +554,22 @@ __global__ __launch_bounds__(256) void norm1_sym_kernel(int64_t n, const double*
 
 // the training call's first launch on the caller's stream: its status words (LAPACK info of the two factorisations, the split scale word)
 // cleared in ONE launch instead of a hipMemsetAsync each in front of the kernels of the critical chain (~10 us apiece there)
-__global__ void svgp_init_kernel(int* __restrict__ info, int* __restrict__ info2) {
+__global__ void svgp_init_kernel(int* __restrict__ info, int* __restrict__ info2, double* __restrict__ cond_dev) {
     if (threadIdx.x == 0 && info) info[0] = 0;
-    if (threadIdx.x < 4) info2[threadIdx.x] = 0;
+    if (threadIdx.x < 8) info2[threadIdx.x] = 0;
+    // the condition accumulators of THIS call (its norm kernels fold in with atomicMax): cleared here and not only by the previous call's
+    // last launch -- a call that returned early (an error between its norm kernels and cond_publish_kernel) must not leak its norms
+    if (threadIdx.x < 2) cond_dev[threadIdx.x] = 0.0;
 }
+// sigma = sqrt(variance) as a float word (the whitened tier's planes hold V / sigma * 2^14: |v_n|^2 <= k_nn = variance)
+__global__ void svgp_sigma_kernel(const float* __restrict__ var, float* __restrict__ sig) { if (threadIdx.x == 0) sig[0] = sqrtf(var[0]); }
 
 // the training call's last launch: cond_1(Kuu + jitter I) = |K|_1 |K^-1|_1 of this call folded into the running maximum the host can read
 // without synchronising (pinned, device-visible memory; mxf_svgp_cond_nowait)
-__global__ void cond_publish_kernel(double* __restrict__ cond_dev, double* __restrict__ host_max) {
+__global__ void cond_publish_kernel(double* __restrict__ cond_dev, double* __restrict__ host_slot /* [0] running max, [1] last */) {
     const double c = cond_dev[0] * cond_dev[1];
-    if (c > *host_max) *host_max = c;
+    if (c > host_slot[0]) host_slot[0] = c;
+    host_slot[1] = c;
     __threadfence_system();
     cond_dev[2] = cond_dev[0]; cond_dev[3] = cond_dev[1];       // kept for mxf_svgp_last_cond
     cond_dev[0] = 0.0; cond_dev[1] = 0.0;                       // the next call's norm kernels accumulate with atomicMax: no memset in front of them
@@ -599,7 +625,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     auto acc = [&](size_t n, size_t es) { need += mxf_align(n * es); };
     acc(M * Q, 8); acc(lsn, 8); acc(1, 8); acc(1, 8); acc(MP, 8); acc(MM, 8); acc(M, 8);   // f64 copies of the parameters
     for (int i = 0; i < 9; ++i) acc(MM, 8);   // L, Linv, Ki, Su(Ls), Lsinv, Sui, KiSu, H0, tmp
-    acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(4, sizeof(int));
+    acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(8, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB, sizeof(T));
     // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
@@ -611,7 +637,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const float* split_var = split_mode == MXF_SPLIT_F16X2 ? (const float*)var : nullptr;
     const size_t pl_big = mxf_split_plane_elems(M, SB), pl_h0 = mxf_split_plane_elems(M, M);     // == mxf_split_plane_elems(SB, M)
     const size_t gp_scr = use_split ? mxf_gram_planes_scratch_bytes(SB, SB, Q) : 0;      // upper bound for either orientation
+    // float32 streaming form (mxf_svgp_configure): the whitened tier runs on the f16x2 split kernels' wide forms only
+    const bool whiten = sizeof(T) == 4 && want_grad && h->svgp_form == MXF_SVGP_WHITENED;
+    if (whiten && !(use_split && split_mode == MXF_SPLIT_F16X2 && (M % 128) == 0 && (SB % 256) == 0))
+        MXF_FAIL(h, -3, "mxf_svgp_logpdf: the whitened float32 form needs M %% 128 == 0, S B %% 256 == 0, Q <= 16, homoscedastic noise (see mxf_svgp_whitened_ok)");
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
+    if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); }
     else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
@@ -621,7 +652,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     D* mud = cv.take<D>(MP); D* Wd = cv.take<D>(MM); D* sd = cv.take<D>(M);
     D* Lm = cv.take<D>(MM); D* Linv = cv.take<D>(MM); D* Ki = cv.take<D>(MM); D* Su = cv.take<D>(MM); D* Lsinv = cv.take<D>(MM);
     D* Sui = cv.take<D>(MM); D* KiSu = cv.take<D>(MM); D* H0 = cv.take<D>(MM); D* tmp = cv.take<D>(MM);
-    D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(4);
+    D* wd = cv.take<D>(MP); D* sc = cv.take<D>(16); D* scal = cv.take<D>(2 * (size_t)S); int* info2 = cv.take<int>(8);
     T* Aext = cv.take<T>((size_t)(M + P) * M); T* wT = cv.take<T>(MP);
     T* Text = cv.take<T>((size_t)(M + P) * SB); T* qbuf = cv.take<T>((size_t)SB);
     unsigned short* plKfu = nullptr; unsigned short* plH0 = nullptr; unsigned short* plKuf = nullptr;
@@ -630,6 +661,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (use_split) { plKfu = cv.take<unsigned short>(3 * pl_big); plH0 = cv.take<unsigned short>(3 * pl_h0); plKuf = cv.take<unsigned short>(3 * pl_big);
                      gscr0 = (float*)cv.take<char>(gp_scr); gscr1 = (float*)cv.take<char>(gp_scr); }
     else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
+    unsigned short* plLi = nullptr; D* ad = nullptr; T* aT = nullptr; float* sigf = nullptr;
+    if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     D* G = nullptr; D* T1 = nullptr; D* AKi = nullptr; D* T2 = nullptr; D* dKuu = nullptr; D* dSu = nullptr;
     D* Gw = nullptr; D* dmud = nullptr; D* dZc = nullptr; D* dlsc = nullptr; D* dvc = nullptr;
@@ -644,7 +677,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // (everything the Kuu chain does not need itself -- noise, mu, W, diag(s), the scalar accumulators -- is prepared on the second side
     //  stream, where Su is formed; the main stream waits for that stream's ev_su before it first touches them)
     MXF_STAGE(h, "start", st);
-    hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2);
+    if (!mxf_cond_init(h)) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words");
+    double* cond_slot = h->cond_host + 2 * h->cond_slot;
+    hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2, h->cond_dev);
+    if (whiten) hipLaunchKernelGGL(svgp_sigma_kernel, dim3(1), dim3(64), 0, st, (const float*)var, sigf);
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
     int rc;
@@ -684,6 +720,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
     if (use_mat) {
         MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
+    } else if (whiten) {
+        // whitened tier: only the Kfu planes (operand (n, k = m) of V = L^-1 Kuf); they need nothing from the core, so they are written
+        // first; V, its transposition (+ U = a^T V) and Phi = V V^T follow on this stream once L^-1 exists (below, after the Kuu chain
+        // has been queued)
+        rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
+                                      (int64_t)pl_big, gscr1, sd_, split_mode);
+        if (rc) return rc;
+        MXF_STAGE(h, "Kfu planes (sd)", sd_);
     } else if (use_split) {
         // float32 training step: the Grams are written directly as split planes (two scaled f16 terms = 4 bytes per element, never as f32):
         // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
@@ -699,7 +743,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     }
     if (!use_split) MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));          // Kuf ready: the T GEMM waits for it
-    if (want_grad && !het) {
+    if (want_grad && !het && !whiten) {
         // Psi2 = Kuf Kuf^T depends on neither the core nor the T GEMM nor the reverse pass: it starts at once on the side stream,
         // lower blocks only, split-K.  float32: from the split planes of Kuf (gemm_split.hip); float64 / fallback: from the TRANSPOSED
         // Gram Kfu (S*B x M, rows = contiguous lines) as a TN GEMM (the NT form on Kuf reads 256 K-strided streams per workgroup).
@@ -744,14 +788,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
     // condition number of Kuu + jitter I (1-norm), for the float32 validity check of mxf_svgp_last_cond: |Kuu|_1 here, |Ki|_1 below
-    if (!h->cond_dev) {
-        if (hipMalloc((void**)&h->cond_dev, 4 * sizeof(double)) != hipSuccess) { h->cond_dev = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words"); }
-        MXF_HIP(h, hipMemset(h->cond_dev, 0, 4 * sizeof(double)));
-    }
-    if (!h->cond_host) {
-        if (hipHostMalloc((void**)&h->cond_host, sizeof(double), hipHostMallocMapped) != hipSuccess) { h->cond_host = nullptr; MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the pinned condition word"); }
-        *h->cond_host = 0.0;
-    }
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
@@ -759,6 +795,23 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
     MXF_STAGE(h, "trtri Kuu", st);
+    unsigned* limax = (unsigned*)(info2 + 4);           // bit pattern of max |L^-1| (whitened tier; word cleared by svgp_init_kernel)
+    if (whiten) {
+        // L^-1 as f16x2 planes (the A operand of V = L^-1 Kuf); Aext is free until Hh is formed
+        hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)Linv, M, Aext, M);
+        rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, limax, st, false);
+        if (rc) return rc;
+        rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plLi, st, MXF_SPLIT_F16X2, limax);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                                   // L^-1 planes ready
+        // side stream: V = L^-1 Kuf, written as the planes of the (m, k = n) operand holding V / sigma * 2^14 (|v_n|^2 <= k_nn = sigma^2):
+        // acc = (s_L L^-1) (Kfu / sigma^2 2^14)^T  ->  acc sigma / s_L.  L^-1 is lower triangular: a row tile's k loop stops at its last row.
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
+        rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, 0, split_mode, sigf, 1,
+                                     (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1);
+        if (rc) return rc;
+        MXF_STAGE(h, "V = Linv Kuf (sd)", sd_);
+    }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
@@ -767,8 +820,33 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
+    if (whiten) {
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Linv, M, 0, mud, P, 0, 0.0, ad, P, 0, 1, 0, st);   // a = L^-1 mu
+        if (rc) return rc;
+        hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)ad, MP, aT, MP);
+    }
     MXF_STAGE(h, "Ki, w", st);
-    if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w ready: the Kfu planes + U pass may start
+    if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w (and a) ready: the Kfu planes + U pass / the transposition + U pass may start
+    if (whiten) {
+        // side stream: V planes -> planes of the (n, k = m) operand (into the Kfu planes' slot: V = L^-1 Kuf has consumed them) and, for one
+        // output column, U = a^T V in the same pass; P > 1: U from the transposed planes (one more read of them)
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
+        rc = mxf_planes_transpose_internal(h, M, SB, plKuf, (int64_t)pl_big, plKfu, (int64_t)pl_big, (const float*)aT, sigf, 1.f / 16384.f,
+                                           P == 1 ? (float*)(Text + M * SB) : nullptr, sd_);
+        if (rc) return rc;
+        if (P > 1) {
+            hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plKfu,
+                               (int64_t)pl_big, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
+        }
+        MXF_STAGE(h, "V^T planes + U (sd)", sd_);
+        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
+        // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T
+        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                     psi2_rb, split_mode, split_var, 1, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_STAGE(h, "Phi (sd)", sd_);
+    }
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
@@ -788,7 +866,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_STAGE(h, "Su^-1 (s2)", s2_);
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
-    if (use_split) {
+    if (use_split && !whiten) {
         // Kfu planes (operand (n, k = m) of the T GEMM) + the row U = w^T Kuf in ONE pass, behind the Su chain on the second side stream:
         // HBM-write bound.  (r03, tests/probes/svgp_stages.py: the pass starts when w = Kuu^-1 mu exists, and the Kuu chain -- potrf, trtri,
         // Ki -- shares the chip with the Kuf planes pass and Psi2 and finishes just after Psi2: 0.9 / 1.4 / 1.6 ms at 4 samples against 0.6
@@ -803,9 +881,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su formed (second side stream)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, Su, M, 0, 0.0, KiSu, M, 0, 1, 0, st);
     if (rc) return rc;
+    if (whiten) {
+        // Hh = L^-T (I - A_s A_s^T) = L^-T - Ki Su L^-T   (T = Hh V; |Hh| ~ sqrt(cond) where |H0| ~ cond)
+        hipLaunchKernelGGL((transpose_convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)Linv, M, H0, M);
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, -1.0, KiSu, M, 0, Linv, M, 0, 1.0, H0, M, 0, 1, 0, st);
+        if (rc) return rc;
+    } else {
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, H0, MM);     // H0 <- Ki (a plain kernel: the runtime's copy engine path costs ~10x as much next to busy queues)
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
+    }
     hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
     // A_ext = [H0 ; w^T] in the streaming dtype
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
@@ -825,7 +910,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_STAGE(h, "H0 planes", st);
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
-    if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
+    if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
+        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
+                                     sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
+    else if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr, nullptr, t_blocked,
                                      (unsigned*)(info2 + 3));       // max |T| for the reverse pass (word cleared by svgp_init_kernel)
@@ -862,9 +950,24 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (want_grad && !het) {
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu (main)
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
+        if (whiten) {
+            // G = d/dH0 = P a1 beta / 2 Psi2 with Psi2 = L Phi L^T in float64: the core's reverse mode then forms Ki G Ki = c L^-T Phi L^-1 --
+            // the float32 error of Phi is amplified by |L^-1|^2 ~ cond, that of a float32 Psi2 by |Ki|^2 ~ cond^2
+            hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, T2);
+            rc = mxf_tril_copy_internal(h, M, Lm, AKi, sd_);
+            if (rc) return rc;
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, AKi, M, 0, T2, M, 0, 0.0, dKuu, M, 0, 1, 0, sd_);
+            if (rc) return rc;
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, dKuu, M, 0, AKi, M, 0, 0.0, G, M, 0, 1, 0, sd_);
+            if (rc) return rc;
+        } else
         hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
         rc = su_reverse(sd_, true);
         if (rc) return rc;
+        if (whiten) {      // c tr(Phi) and c tr(Su L^-T Phi L^-1) = tr((Ki Su) (Ki G)): the accurate total of the q_n (svgp_finalize_kernel)
+            hipLaunchKernelGGL((trace_kernel<D>), dim3(1), dim3(256), 0, sd_, M, (const D*)T2, M, (int64_t)0, sc + 6);
+            hipLaunchKernelGGL(dot_t_kernel, dim3(dotgrid(MM)), dim3(256), 0, sd_, M, (const D*)KiSu, (const D*)tmp, sc + 7);
+        }
         MXF_STAGE(h, "Su reverse (sd)", sd_);
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs
     }
@@ -890,7 +993,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((svgp_het_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, M, P, (const D*)scal, (const D*)(sc + 0), (const D*)(sc + 1),
                            (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
         MXF_LAUNCH_CHECK(h);
-        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host); return 0; }
+        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot); return 0; }
         // G' = 1/2 a1 Kuf diag(bs) Kuf^T (-> Psi2 slot), Gw = Kuf (a1 beta.e) (-> R slot), Kuf-side reverse mode from dKuf = Text
         rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Ksc, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
         if (rc) return rc;
@@ -922,10 +1025,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_STAGE(h, "reverse pass", st);
     if (!het) {
+        if (whiten) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Phi and the core's Su part (side stream): the value needs tr(C Phi)
         hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
-                           (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir);
+                           (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir,
+                           whiten ? (const D*)(sc + 6) : (const D*)nullptr);
         MXF_LAUNCH_CHECK(h);
-        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host); return 0; }
+        if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot); return 0; }
     }
 
     if (het) {
@@ -972,7 +1077,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
     MXF_STAGE(h, "core reverse", st);
-    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host);
+    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
     MXF_STAGE(h, "end", st);
     MXF_STAGE_DUMP(h);

@@ -51,9 +51,37 @@ extern "C" int64_t mxf_workspace_generation(mxf_handle h) { return h ? h->ws_gen
 
 extern "C" int mxf_svgp_cond_nowait(mxf_handle h, double* cond1_max_out, int reset) {
     if (!h || !cond1_max_out) return -1;
-    *cond1_max_out = h->cond_host ? *(volatile double*)h->cond_host : 0.0;      // no synchronisation: whatever the finished calls have published
-    if (reset && h->cond_host) *(volatile double*)h->cond_host = 0.0;
+    double m = 0.0;      // no synchronisation: whatever the finished calls have published, over every slot
+    if (h->cond_host)
+        for (int i = 0; i < MXF_COND_SLOTS; ++i) {
+            const double v = *(volatile double*)(h->cond_host + 2 * i);
+            m = v > m ? v : m;
+            if (reset) { *(volatile double*)(h->cond_host + 2 * i) = 0.0; *(volatile double*)(h->cond_host + 2 * i + 1) = 0.0; }
+        }
+    *cond1_max_out = m;
     return 0;
+}
+
+extern "C" int mxf_svgp_configure(mxf_handle h, int form, int cond_slot) {
+    if (!h) return -1;
+    if (form != MXF_SVGP_EXPLICIT && form != MXF_SVGP_WHITENED) MXF_FAIL(h, -2, "mxf_svgp_configure: unknown form %d", form);
+    if (cond_slot < 0 || cond_slot >= MXF_COND_SLOTS) MXF_FAIL(h, -2, "mxf_svgp_configure: slot %d outside [0, %d)", cond_slot, MXF_COND_SLOTS);
+    h->svgp_form = form; h->cond_slot = cond_slot;
+    return 0;
+}
+
+extern "C" int mxf_svgp_cond_slot(mxf_handle h, int slot, double* last_out, double* max_out, int reset) {
+    if (!h) return -1;
+    if (slot < 0 || slot >= MXF_COND_SLOTS) MXF_FAIL(h, -2, "mxf_svgp_cond_slot: slot %d outside [0, %d)", slot, MXF_COND_SLOTS);
+    if (max_out) *max_out = h->cond_host ? *(volatile double*)(h->cond_host + 2 * slot) : 0.0;
+    if (last_out) *last_out = h->cond_host ? *(volatile double*)(h->cond_host + 2 * slot + 1) : 0.0;
+    if (reset && h->cond_host) { *(volatile double*)(h->cond_host + 2 * slot) = 0.0; *(volatile double*)(h->cond_host + 2 * slot + 1) = 0.0; }
+    return 0;
+}
+
+extern "C" int mxf_svgp_whitened_ok(int dtype, int S, int64_t B, int64_t M, int Q, int P, int64_t strideS_X) {
+    const int64_t SB = (strideS_X == 0 ? 1 : (int64_t)S) * B;
+    return (dtype == MXF_F32 && S > 0 && B > 0 && (M % 128) == 0 && M >= 128 && (SB % 256) == 0 && Q <= 16 && P <= 8 && !(S > 1 && strideS_X == 0)) ? 1 : 0;
 }
 
 extern "C" int mxf_svgp_last_cond(mxf_handle h, double* cond1_out) {

@@ -139,6 +139,11 @@ struct SplitArgs {
     // group, loop trips between two rendezvous (0 = one per work item, at its start: group = sync_n consecutive work items), counters per k split
     unsigned* sync; int sync_n, sync_period, sync_slots;
     unsigned* maxout;                    // wide kernels, plain (beta = 0, unsplit) products: atomicMax of the bit pattern of max |C| (nullptr: none)
+    // c_blk == 2 (wide kernels, CPL instantiations): C is written as TWO f16 PLANES (hi + lo of alpha * acc) in the 16-column-block order --
+    // i.e. directly as the (row, k = col) operand of a following split product (the whitened SVGP tier: V = L^-1 Kuf feeds Phi = V V^T)
+    unsigned short* Cp; int64_t pC;
+    int64_t rot_div;
+    int a_lower;                         // A is lower triangular (A[m][k] = 0 for k > m): a row tile's k loop ends at its last row
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
@@ -389,7 +394,7 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // tile: 2 of its 8 waves) runs a k loop WITHOUT its B loads and MFMAs -- it still fetches its share of the A slab and keeps every barrier.
 // (A branch around the MFMAs inside the one loop cost the kernel its schedule, see below; here the loop exists twice and the idle form is a
 //  separate instantiation, so the T product's kernel is untouched.)  The busiest SIMDs still carry two working waves: the gain is power.
-template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false>
+template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false, bool CPL = false>
 __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
     static_assert(!LSKIP || (!PP && BLO), "the idle-wave loop mirrors the plain pipelined loop");
@@ -419,10 +424,14 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         tile_m = row; tile_n = t;
     } else {
         tile_m = t % g.tm; tile_n = t / g.tm;       // the row tiles of one column tile are neighbours: they share the B columns in L2
+        // triangular A: row tile r carries (r + 1) / tm of the work, and a persistent workgroup would meet the SAME row tile in every
+        // round (its items are a multiple of tm apart) -- rotate the row tile with the round
+        if constexpr (CPL) { if (g.a_lower && g.rot_div > 0) tile_m = (tile_m + tile_n / g.rot_div) % g.tm; }
     }
     const int64_t m0 = tile_m * WBMt, n0 = tile_n * WBN;
     const int64_t kbeg = split * g.kchunk;
-    const int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
+    int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
+    if constexpr (CPL) { if (g.a_lower) { const int64_t kl = (m0 + WBMt + 15) / 16; kend = kl < kend ? kl : kend; } }
     if (g.sync && g.sync_period == 0) wg_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
     // (Measured and dropped, r03: skipping the MFMAs of the waves / 32 x 32 fragments that lie strictly above the diagonal of a lower-only
     //  product -- 10 % / 17 % of Psi2's matrix work.  Any branch around the MFMA block costs the kernel its schedule: 231 -> 251 VGPRs with
@@ -650,6 +659,40 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     const bool atomic = g.atomic != 0;
     // D = B A^T: accumulator register r of tile (x, y) is C[m0 + 32 XT wh + 32 x + (lane & 31)][n0 + 64 wq + 32 y + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (CPL) {
+        // planes output: lane (li, lk) holds columns 8 q + 4 lk .. + 3 of quad q.  v_permlane32_swap trades quad q + 1 of the lanes lk = 0 for
+        // quad q of the lanes lk = 1: afterwards lane lk owns EIGHT consecutive columns 8 (q + lk) .. + 7 (q even) = one 16-byte unit per
+        // plane, and a store instruction covers 32 rows x 32 bytes = 1 KB contiguous of the 16-column block.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int x = 0; x < XT; ++x) {
+            const int64_t row = m0 + 32 * XT * wh + 32 * x + li;
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {          // d = 0, 1: quad q; d = 2, 3: quad q + 1
+                        const f32x2 v = {alpha * c[x][y][4 * q + 2 * d], alpha * c[x][y][4 * q + 2 * d + 1]};
+                        const f16x2 fh = __builtin_convertvector(v, f16x2);
+                        const f16x2 fl = __builtin_convertvector(v - __builtin_convertvector(fh, f32x2), f16x2);
+                        hi[d] = __builtin_bit_cast(unsigned, fh); lo[d] = __builtin_bit_cast(unsigned, fl);
+                    }
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi[d]), "+v"(hi[2 + d]));
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[d]), "+v"(lo[2 + d]));
+                    }
+                    const int64_t col = n0 + 64 * wq + 32 * y + 8 * (q + lk);
+                    unsigned short* p = g.Cp + ((col >> 4) * g.M + row) * 16 + (col & 15);
+                    const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+                    *reinterpret_cast<u32x4*>(p) = vh;
+                    *reinterpret_cast<u32x4*>(p + g.pC) = vl;
+                }
+        }
+    } else
 #pragma unroll
     for (int x = 0; x < XT; ++x) {
         const int64_t row = m0 + 32 * XT * wh + 32 * x + li;
@@ -693,6 +736,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256lo(SplitArgs g) { wide_body<4, 2, false, true, true>(g); }
+// planes-output forms (c_blk == 2; the whitened SVGP tier's V = L^-1 Kuf)
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pl(SplitArgs g) { wide_body<4, 2, false, true, false, true>(g); }
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128pl(SplitArgs g) { wide_body<4, 1, false, true, false, true>(g); }
 
 __global__ void split_scale_kernel(float* C, int64_t M, int64_t N, int64_t ldc, float beta, int lower_only) {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
@@ -734,10 +780,16 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked,
-                            unsigned* maxout) {
+                            unsigned* maxout, unsigned short* Cplanes, int64_t pC, int a_lower) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
     g.c_blk = c_blocked; g.maxout = nullptr;
+    g.Cp = Cplanes; g.pC = pC; g.a_lower = a_lower; g.rot_div = 0;
+    if (Cplanes) {
+        if (mode != MXF_SPLIT_F16X2 || (M % 128) != 0 || (N % WBN) != 0 || beta != 0.0 || lower_only || c_blocked)
+            MXF_FAIL(h, -2, "mxf_gemm_split: the planes output needs the f16x2 format, M %% 128 == 0, N %% 256 == 0, beta == 0 and a full product");
+        g.c_blk = 2;
+    } else if (a_lower) MXF_FAIL(h, -2, "mxf_gemm_split: a_lower is implemented for the planes output only");
     if (c_blocked && (N % 16 != 0 || beta != 0.0 || lower_only || ldc != N)) MXF_FAIL(h, -2, "mxf_gemm_split: the blocked output layout needs N %% 16 == 0, ldc == N, beta == 0 and a full product");
     g.ad0 = ad0; g.pow0 = pow0; g.maxbits = maxbits; g.maxbits2 = maxbits2;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K16 = (K + 15) / 16;
@@ -753,13 +805,14 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     // (rows are 64 bytes apart) and for the small square Psi2, 16-byte pieces 4 N bytes apart for a wide row-major C -- the T shape then
     // takes 16.7 ms instead of 13.4 on the 128 x 128 kernel, blocked it takes 12.3.  (Before the kernel walked its work items persistently
     // the blocked T lost 1.9 ms on it as well.)
-    const bool wide = wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % 128) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
-                      (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N);
+    const bool wide = Cplanes != nullptr ||
+                      (wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % 128) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
+                       (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N));
     // rows per tile of the wide kernel: 256 when the shape allows, else 128 (four waves, two workgroups per CU).  MXF_SPLIT_XT: 4 = always
     // 128; 8 = 256 rows by four 512-register waves (one per SIMD); 16 (default) = 256 rows by eight waves, two row halves (two per SIMD)
     static const int xt_env = (int)MXF_KNOB("MXF_SPLIT_XT", 16);
-    const int XT = (wide && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
-    const int NH = (wide && xt_env == 16 && (M % 256) == 0) ? 2 : 1;
+    const int XT = (wide && !Cplanes && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
+    const int NH = (wide && (xt_env == 16 || Cplanes) && (M % 256) == 0) ? 2 : 1;
     const int64_t WBMh = 32 * XT * NH;
     int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
@@ -776,7 +829,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     // sized for the four-per-CU kernel: ~216 workgroups, one per CU on 216 CUs, whichever kernel runs.
     const int64_t slots = wide ? (reserve_cus >= 128 ? (int64_t)(256 - reserve_cus) * 4 : (int64_t)(256 - reserve_cus) * (WBMh == 256 ? 1 : 2))
                                : (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
-    if (tiles < slots && g.K16 >= 16) {
+    if (tiles < slots && g.K16 >= 16 && !Cplanes) {
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
         const int64_t maxsplit = g.K16 / 8 > 0 ? g.K16 / 8 : 1;
@@ -808,7 +861,9 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         // one k split (split-K products); 2 = full products: all workgroups of an XCD, once per work item
         static const int sync_env = (int)MXF_KNOB("MXF_SPLIT_SYNC", 1);
         static const int sync_period_env = (int)MXF_KNOB("MXF_SPLIT_SYNC_PERIOD", 16);
-        if (sync_env && !lower_only && splitk == 1 && g.nwg % 8 == 0 && g.nwg >= 16) {
+        if (Cplanes && a_lower) {
+            g.rot_div = (grid / 8) / tm > 0 ? (grid / 8) / tm : 1;       // (no rendezvous: the row tiles of a strip carry unequal work)
+        } else if (sync_env && !lower_only && splitk == 1 && g.nwg % 8 == 0 && g.nwg >= 16) {
             const int64_t q = g.nwg / 8, per_xcd = grid / 8;        // work items / resident workgroups per XCD
             int64_t n = sync_env == 2 ? per_xcd : tm;
             // a group = n consecutive work items of one XCD's run, taken in the same persistent round by n different workgroups
@@ -831,7 +886,9 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
         static const int lskip_env = (int)MXF_KNOB("MXF_SPLIT_LSKIP", 1);  // lower-only products: the waves above the diagonal idle (see wide_body)
         static const int bhi_env = (int)MXF_KNOB("MXF_SPLIT_BHI", 0);      // experiment: B through its high plane only, blocked-output products
-        if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
+        if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (Cplanes) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128pl, dim3((unsigned)grid), dim3(256), 0, st, g);
+        else if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2 && lower_only && lskip_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256lo, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256, dim3((unsigned)grid), dim3(512), 0, st, g);

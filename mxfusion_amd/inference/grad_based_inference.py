@@ -42,11 +42,10 @@ class GradBasedInference(Inference):
     F32_COND_LIMIT = 3e3
 
     def _check_float32_validity(self):
-        """The float32 streaming form of the SVGP bound applies Kuu^-1 explicitly: its rounding error grows like cond(Kuu + jitter I) 2^-24
-        (ELBO agreement with float64: 3e-6 at cond 1.4e3, 2e-3 at 5e4).  The SVGP module guards itself while it runs
-        (modules/gp_modules/_fused.py: Float32Guard -- above the limit the streaming stage switches to float64 automatically); this records
-        what happened for the caller: `last_kuu_condition` (largest condition number the run's calls published) and
-        `float32_fallback_active`."""
+        """The float32 forms of the SVGP bound are valid up to a condition number of Kuu + jitter I each (explicit inverse: 3e3, whitened:
+        5e6; modules/gp_modules/_fused.py: Float32Guard moves every SVGP module between them and float64 by itself while it runs).  This
+        records what happened for the caller: `last_kuu_condition` (largest condition number the run's calls published),
+        `float32_fallback_active` (some module ended on float64), `float32_tiers` (the level of every module)."""
         if config.torch_dtype(self.dtype) != torch.float32 or not torch.cuda.is_available():
             return
         from ..modules.gp_modules.svgp_regression import SVGPRegression
@@ -57,20 +56,21 @@ class GradBasedInference(Inference):
             ctx = torch.device(ctx)
         if isinstance(ctx, torch.device) and ctx.type != 'cuda':
             return
-        from .. import ops
         from ..modules.gp_modules._fused import Float32Guard
         try:                                   # a diagnostic: it must never fail a finished run
             torch.cuda.synchronize()
-            cond = max(ops.svgp_cond_nowait(ctx), ops.svgp_last_cond(ctx))
+            rep = Float32Guard.report(ctx)
         except Exception:                      # noqa: BLE001
             return
+        cond = rep['kuu_cond_max']
         self.last_kuu_condition = cond
-        self.float32_fallback_active = bool(Float32Guard.active)
+        self.float32_fallback_active = bool(rep['float32_fallback_active'])
+        self.float32_tiers = rep['float32_tiers']
         if cond > self.F32_COND_LIMIT and not Float32Guard.enabled:
             import warnings
-            warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e after this float32 run: beyond ~%.0e the float32 streaming SVGP bound '
-                          'loses accuracy (error ~ cond * 2^-24) and the automatic float64 fallback is disabled; run the inference with '
-                          'dtype=\'float64\'.' % (cond, self.F32_COND_LIMIT))
+            warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e after this float32 run: beyond ~%.0e the explicit-inverse float32 SVGP '
+                          'bound loses accuracy (error ~ cond * 2^-24) and the automatic switch to the whitened / float64 forms is disabled; '
+                          'enable Float32Guard or run the inference with dtype=\'float64\'.' % (cond, self.F32_COND_LIMIT))
 
 
 class GradTransferInference(GradBasedInference):

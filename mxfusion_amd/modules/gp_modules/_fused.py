@@ -1,7 +1,7 @@
 """autograd bridges to the fused C-ABI composites (value + reverse mode in one call)."""
 import torch
 
-from ... import ops
+from ... import _lib, ops
 
 
 def _uniform_weight(g):
@@ -58,78 +58,178 @@ class GPLogPdfFn(torch.autograd.Function):
 
 
 class Float32Guard(object):
-    """Validity of the float32 streaming form of the SVGP bound.  The float32 training call applies
-    H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1 explicitly, so its rounding error grows like cond_1(Kuu + jitter I) 2^-24: 5e-8 ... 5e-6 on the ELBO up to
-    cond ~ 1.4e3, 2e-3 at 5e4 (tests/probes/f32_accuracy.py) -- beyond LIMIT the 1e-5 parity bar is out of reach in float32.  (A factorised
-    float32 form was costed instead of guessed: the cancellation sits in k_n^T (H0 k_n) itself, so only q_n = v_n^T (I - A_s A_s^T) v_n with
-    v_n = L^-1 k_n avoids it, which needs three full-width GEMMs plus two passes over them, ~2.5x the step, against the reference's own
-    remedy -- float64, svgp_regression.py:83-92 solves in the model's dtype -- at 5.8x.)
+    """Validity of the float32 forms of the SVGP bound -- three levels, PER MODULE.
 
-    Every training call publishes its condition number into pinned host memory as its last launch (mxf_svgp_cond_nowait); the guard polls
-    that word before each float32 call -- no synchronisation, it lags by the calls still in flight -- and once the limit is crossed every
-    further float32 SVGP call of the process runs its streaming stage in FLOAT64 (inputs widened, outputs narrowed; same C-ABI call with
-    dtype = f64), with one warning.  The first training call of a process is checked synchronously, so a model that STARTS ill-conditioned is
-    never evaluated in float32 at all."""
+      EXPLICIT  cond_1(Kuu + jitter I) <= LIMIT            T = H0 Kuf with the explicit inverse H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1: two full-width
+                                                           split GEMMs, the fastest form; rounding error ~ cond 2^-24 (ELBO 5e-8 .. 5e-6 up to
+                                                           cond ~ 1.4e3, 2e-3 at 5e4: tests/probes/f32_accuracy.py)
+      WHITENED  LIMIT < cond <= LIMIT_WHITENED (5e6)       the factorised form the reference evaluates (svgp_regression.py:83-92) on the split
+                                                           GEMMs: V = L^-1 Kuf, Phi = V V^T, T = L^-T (I - A_s A_s^T) V (mxf_svgp_configure,
+                                                           csrc/whiten.hip): three full-width products, error ~ sqrt(cond) 2^-24
+      F64       above, or where the whitened form does     the streaming stage in float64 (inputs widened, outputs narrowed; same C-ABI call with
+                not cover the call (shape, combination     dtype = f64) -- the reference's own remedy
+                kernels, no-grad evaluations)
+
+    Every SVGP call publishes cond_1 of ITS Kuu into the condition slot its owner holds (pinned host memory, written by the call's last
+    launch); the owner polls the slot before its next call -- no synchronisation, it lags by the calls still in flight -- and moves
+    between the levels (up at once, down with a factor-4 hysteresis).  The first call of an owner is checked synchronously, so a model
+    that STARTS ill-conditioned is never evaluated in a form that cannot hold the 1e-5 bar.  One instance per module algorithm object: a
+    two-layer model whose second layer is ill-conditioned keeps its first layer on the fast form.  Calls without an owner share
+    Float32Guard.default."""
+    EXPLICIT, WHITENED, F64 = 0, 1, 2
+    NAMES = ('explicit-inverse float32', 'whitened float32', 'float64')
     LIMIT = 3e3
-    enabled = True
-    active = False          # sticky: the float64 fallback is on
-    _checked_first = False
+    LIMIT_WHITENED = 5e6
+    HYSTERESIS = 0.25
+    enabled = True          # class-wide switch (bench.py --no-f32-guard, tests): False = always the explicit float32 form
+    default = None
+    _instances = None
+    _counter = 0
+
+    def __init__(self, name='svgp'):
+        import weakref
+        cls = Float32Guard
+        if cls._instances is None:
+            cls._instances = weakref.WeakSet()
+        cls._counter += 1
+        self.slot = 1 + (cls._counter - 1) % (_lib.COND_SLOTS - 1)      # slot 0: calls that never configured one
+        self.name = name
+        self.tier = self.EXPLICIT
+        self.cond_max = 0.0         # largest condition number this owner has seen
+        self.cond_last = 0.0
+        self._checked_first = False
+        self.switches = 0
+        cls._instances.add(self)
+
+    # ---- class-level views (reports, tests, backwards compatibility) ----------------------------------------------------------------
+    @classmethod
+    def instances(cls):
+        return list(cls._instances) if cls._instances is not None else []
 
     @classmethod
     def reset(cls):
-        cls.active, cls._checked_first = False, False
+        """Every owner back to the explicit form, un-checked; the slots are cleared on their next poll."""
+        for g in cls.instances():
+            g.tier, g._checked_first, g.cond_max, g.cond_last, g.switches = cls.EXPLICIT, False, 0.0, 0.0, 0
+            g._stale = True
 
     @classmethod
-    def _trip(cls, cond):
-        if not cls.active:
+    def report(cls, dev=None):
+        """What the guards have seen.  dev given: fold in what the finished calls have published first (the caller has synchronised)."""
+        if dev is not None:
+            for g in cls.instances():
+                last, mx = _lib.svgp_cond_slot(ops._device_index(dev), g.slot, reset=False)
+                if mx > 0 and not getattr(g, '_stale', False):
+                    g.cond_max, g.cond_last = max(g.cond_max, mx), last
+        gs = [g for g in cls.instances() if g.cond_max > 0]
+        return {'kuu_cond_max': max([g.cond_max for g in gs] or [0.0]),
+                'float32_fallback_active': any(g.tier == cls.F64 for g in gs),
+                'float32_whitened_active': any(g.tier == cls.WHITENED for g in gs),
+                'float32_tiers': {('%s#%d' % (g.name, g.slot)): cls.NAMES[g.tier] for g in gs},
+                'float32_guard': bool(cls.enabled)}
+
+    # ---- per owner -------------------------------------------------------------------------------------------------------------------
+    def _target(self, cond):
+        t = self.tier
+        up = self.EXPLICIT if cond <= self.LIMIT else (self.WHITENED if cond <= self.LIMIT_WHITENED else self.F64)
+        if up > t:
+            return up
+        down = self.EXPLICIT if cond <= self.HYSTERESIS * self.LIMIT else (self.WHITENED if cond <= self.HYSTERESIS * self.LIMIT_WHITENED else self.F64)
+        return min(t, down)
+
+    def _move(self, cond):
+        self.cond_last = cond
+        self.cond_max = max(self.cond_max, cond)
+        t = self._target(cond)
+        if t != self.tier:
             import warnings
-            warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e exceeds %.0e: the float32 streaming form of the SVGP bound loses '
-                          'accuracy there (error ~ cond * 2^-24); its streaming stage runs in float64 from now on.' % (cond, cls.LIMIT))
-        cls.active = True
-
-    @classmethod
-    def use_f64(cls, dev):
-        """Called before a float32 training call; True -> run it in float64."""
-        if not cls.enabled:
-            return False
-        if not cls.active:
-            c = ops.svgp_cond_nowait(dev)
-            if c > cls.LIMIT:
-                cls._trip(c)
-        return cls.active
-
-    @classmethod
-    def after_first_call(cls, dev):
-        """Synchronous check after the very first float32 training call; True -> its result must be recomputed in float64."""
-        if not cls.enabled or cls._checked_first:
-            return False
-        cls._checked_first = True
-        c = ops.svgp_last_cond(dev)
-        if c > cls.LIMIT:
-            cls._trip(c)
+            if t > self.tier:
+                warnings.warn('mxfusion_amd: cond_1(Kuu + jitter I) = %.2e of %s: the %s form of the SVGP bound loses accuracy there; its '
+                              'streaming stage runs in %s from now on.' % (cond, self.name, self.NAMES[self.tier], self.NAMES[t]))
+            self.tier = t
+            self.switches += 1
             return True
         return False
+
+    def poll(self, dev):
+        """Before a call: fold in what this owner's finished calls have published since the last poll (no synchronisation)."""
+        idx = ops._device_index(dev)
+        last, mx = _lib.svgp_cond_slot(idx, self.slot, reset=True)
+        if getattr(self, '_stale', False):          # after reset(): whatever was published before does not count
+            self._stale = False
+            return
+        if mx > 0:
+            self._move(mx)
+
+    def form(self, dev, whitened_ok):
+        """The level this call runs at (enabled guards only; the caller holds float32 CUDA inputs)."""
+        if not Float32Guard.enabled:
+            return self.EXPLICIT
+        self.poll(dev)
+        if self.tier == self.WHITENED and not whitened_ok:
+            return self.F64
+        return self.tier
+
+    def configure(self, dev, tier):
+        _lib.svgp_configure(ops._device_index(dev), _lib.FORM_WHITENED if tier == self.WHITENED else _lib.FORM_EXPLICIT, self.slot)
+
+    def first_call_needs_rerun(self, dev, ran_at, whitened_ok):
+        """Synchronous check after an owner's very first call; True -> its result must be recomputed at the (higher) level now set."""
+        if not Float32Guard.enabled or self._checked_first:
+            return False
+        self._checked_first = True
+        c = ops.svgp_last_cond(dev)
+        _lib.svgp_cond_slot(ops._device_index(dev), self.slot, reset=True)
+        self._move(c)
+        need = self.F64 if (self.tier == self.WHITENED and not whitened_ok) else self.tier
+        return need > ran_at
+
+
+def _guarded(guard, dev, is_f32, whitened_ok, run):
+    """Run `run(tier)` under `guard`: picks the level, configures the handle (form + condition slot), re-runs an owner's first call when its
+    synchronous check asks for a higher level.  run(tier) evaluates the call in float32 (EXPLICIT / WHITENED) or widened to float64 (F64)."""
+    g = guard if guard is not None else Float32Guard.default
+    if not is_f32:
+        g.configure(dev, g.EXPLICIT)
+        return run(g.EXPLICIT)
+    tier = g.form(dev, whitened_ok)
+    g.configure(dev, tier)
+    r = run(tier)
+    if g.first_call_needs_rerun(dev, tier, whitened_ok):
+        tier = g.F64 if (g.tier == g.WHITENED and not whitened_ok) else g.tier
+        g.configure(dev, tier)
+        r = run(tier)
+    return r
+
+
+def _narrow(r):
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in r.items()}
 
 
 class SVGPLogPdfFn(torch.autograd.Function):
     """mxf_svgp_logpdf.  Gradients are produced for mean_S(logL) (the only reduction the reference applies to a
-    module's log-pdf, factor_graph.py:233) and scaled by sum(grad_output) in backward."""
+    module's log-pdf, factor_graph.py:233) and scaled by sum(grad_output) in backward.  `guard`: the owner's Float32Guard (None = the
+    shared default)."""
 
     @staticmethod
-    def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
-        want = any(ctx.needs_input_grad[4:])
+    def forward(ctx, guard, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
+        want = any(ctx.needs_input_grad[5:])
         S = max(X.shape[0], Y.shape[0])
 
-        def run(cast):
+        def run(tier):
+            cast = (lambda t: t.double()) if tier == Float32Guard.F64 else (lambda t: t)
             a = [cast(t) for t in (X, Y, Z[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0], sdiag[0], ls.reshape(-1), var.reshape(-1))]
-            return ops.svgp_logpdf(kind, *a, ard, jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
-        guard = want and X.is_cuda and X.dtype == torch.float32
-        if guard and Float32Guard.use_f64(X.device):
-            r = {k: (v.float() if v.is_floating_point() else v) for k, v in run(lambda t: t.double()).items()}
+            r = ops.svgp_logpdf(kind, *a, ard, jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+            return _narrow(r) if tier == Float32Guard.F64 else r
+        if X.is_cuda:
+            is_f32 = X.dtype == torch.float32
+            homo = noise.numel() == 1
+            # the whitened form covers float32 TRAINING calls of the streaming (homoscedastic) path on split-capable shapes
+            wok = is_f32 and want and homo and _lib.svgp_whitened_ok(_lib.F32, S, X.shape[-2], Z.shape[-2], X.shape[-1], Y.shape[-1],
+                                                                      0 if X.shape[0] == 1 else X.shape[-2] * X.shape[-1])
+            r = _guarded(guard, X.device, is_f32, wok, run)
         else:
-            r = run(lambda t: t)
-            if guard and Float32Guard.after_first_call(X.device):
-                r = {k: (v.float() if v.is_floating_point() else v) for k, v in run(lambda t: t.double()).items()}
+            r = run(Float32Guard.EXPLICIT)
         if want:
             ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'], r['dls'], r['dvar'])
             ctx.shapes = tuple(t.shape for t in (X, Y, Z, noise, mu, W, sdiag, ls, var))
@@ -139,21 +239,32 @@ class SVGPLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = _uniform_weight(g)
-        return (None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:], c)
+        return (None, None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[5:], c)
 
 
 class SVGPSampledLogPdfFn(torch.autograd.Function):
     """mxf_svgp_logpdf_sampled: ONE call for S samples of any of the operands (sampled hyper-parameters, inducing inputs, q(u); the
     reference broadcasts them to S, runtime_variable.py:96-118).  The call returns per-sample gradients; an operand that was shared
-    (sample axis 1) receives their sum."""
+    (sample axis 1) receives their sum.  Every sample publishes the condition number of its own Kuu into the owner's slot (the guard acts
+    on their maximum)."""
 
     @staticmethod
-    def forward(ctx, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
-        want = any(ctx.needs_input_grad[4:])
+    def forward(ctx, guard, kind, ard, jitter, scaling, X, Y, Z, noise, mu, W, sdiag, ls, var):
+        want = any(ctx.needs_input_grad[5:])
         ins = (X, Y, Z, noise, mu, W, sdiag, ls, var)
         S = max(t.shape[0] for t in ins)
-        r = ops.svgp_logpdf_sampled(kind, X, Y, Z, noise.reshape(noise.shape[0], 1), mu, W, sdiag, ls, var.reshape(var.shape[0], 1), ard, jitter=jitter,
-                                    scaling=scaling, gscale=1.0 / S, want_grad=want)
+
+        def run(tier):
+            cast = (lambda t: t.double()) if tier == Float32Guard.F64 else (lambda t: t)
+            r = ops.svgp_logpdf_sampled(kind, cast(X), cast(Y), cast(Z), cast(noise.reshape(noise.shape[0], 1)), cast(mu), cast(W), cast(sdiag), cast(ls),
+                                        cast(var.reshape(var.shape[0], 1)), ard, jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+            return _narrow(r) if tier == Float32Guard.F64 else r
+        if X.is_cuda:
+            is_f32 = X.dtype == torch.float32
+            wok = is_f32 and want and _lib.svgp_whitened_ok(_lib.F32, 1, X.shape[-2], Z.shape[-2], X.shape[-1], Y.shape[-1], 0)   # (one sample per inner call)
+            r = _guarded(guard, X.device, is_f32, wok, run)
+        else:
+            r = run(Float32Guard.EXPLICIT)
         if want:
             keys = ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')
             ctx.grads = tuple(r[k].reshape((S,) + tuple(t.shape[1:])) if t.shape[0] == S else r[k].sum(0).reshape(t.shape) for k, t in zip(keys, ins))
@@ -164,19 +275,28 @@ class SVGPSampledLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = _uniform_weight(g)
-        return (None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:], c)
+        return (None, None, None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[5:], c)
 
 
 class SVGPMatLogPdfFn(torch.autograd.Function):
     """mxf_svgp_logpdf_mat: the bound from materialised Kuu / Kuf / Kdiag (one sample of the inputs: unit sample axes) for S >= 1 samples of Y;
-    the gradients of mean_S(logL) flow on into the kernels' own reverse mode (combination kernels)."""
+    the gradients of mean_S(logL) flow on into the kernels' own reverse mode (combination kernels).  This path has the explicit float32
+    form and float64 only: above Float32Guard.LIMIT the guard widens it (the Grams it receives stay float32 values)."""
 
     @staticmethod
-    def forward(ctx, jitter, scaling, Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag):
-        want = any(ctx.needs_input_grad[2:])
+    def forward(ctx, guard, jitter, scaling, Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag):
+        want = any(ctx.needs_input_grad[3:])
         S = Y.shape[0]
-        r = ops.svgp_logpdf_mat(Kuu[0], Kuf[0], Kdiag[0], Y if S > 1 else Y[0], noise[0] if noise.dim() == 3 else noise.reshape(-1), mu[0], W[0],
-                                sdiag[0], jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+
+        def run(tier):
+            cast = (lambda t: t.double()) if tier == Float32Guard.F64 else (lambda t: t)
+            r = ops.svgp_logpdf_mat(cast(Kuu[0]), cast(Kuf[0]), cast(Kdiag[0]), cast(Y if S > 1 else Y[0]), cast(noise[0] if noise.dim() == 3 else noise.reshape(-1)),
+                                    cast(mu[0]), cast(W[0]), cast(sdiag[0]), jitter=jitter, scaling=scaling, gscale=1.0 / S, want_grad=want)
+            return _narrow(r) if tier == Float32Guard.F64 else r
+        if Kuu.is_cuda:
+            r = _guarded(guard, Kuu.device, Kuu.dtype == torch.float32, False, run)
+        else:
+            r = run(Float32Guard.EXPLICIT)
         if want:
             ctx.grads = (r['dKuu'], r['dKuf'], r['dKdiag'], r['dY'], r['dnoise'], r['dmu'], r['dW'], r['dSdiag'])
             ctx.shapes = tuple(t.shape for t in (Kuu, Kuf, Kdiag, Y, noise, mu, W, sdiag))
@@ -187,7 +307,7 @@ class SVGPMatLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = _uniform_weight(g)          # gradients were produced for mean_S(logL) (gscale = 1/S): scale by sum(grad_output), as SVGPLogPdfFn does
-        return (None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[2:], c)
+        return (None, None, None) + _scaled(ctx.grads, ctx.shapes, ctx.needs_input_grad[3:], c)
 
 
 class SGPLogPdfFn(torch.autograd.Function):
@@ -209,3 +329,6 @@ class SGPLogPdfFn(torch.autograd.Function):
         c = g.sum()
         out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[3:])]
         return (None, None, None) + tuple(out)
+
+
+Float32Guard.default = Float32Guard('svgp (shared default)')

@@ -34,6 +34,14 @@ class SVGPRegressionLogPdf(VariationalInference):
         self.log_pdf_scaling = 1
         self.jitter = jitter
 
+    def _f32_guard(self):
+        """This algorithm object's float32 validity guard (one per module: its own condition slot and level, _fused.Float32Guard)."""
+        g = getattr(self, '_guard', None)
+        if g is None:
+            from ._fused import Float32Guard
+            g = self._guard = Float32Guard(getattr(getattr(self.model, 'F', None), 'name', None) or 'svgp')
+        return g
+
     PMAX = 8     # output columns per fused call (register tile of the composites); wider Y is processed in column blocks
 
     def compute(self, F, variables):
@@ -77,17 +85,17 @@ class SVGPRegressionLogPdf(VariationalInference):
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
         scaling = float(self.log_pdf_scaling)
         if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
-            logL, info = SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
+            logL, info = SVGPLogPdfFn.apply(self._f32_guard(), kind, ard, float(self.jitter), scaling, X, Y, *shared)
         elif noise_var.numel() == noise_var.shape[0] and Y.shape[-1] <= self.PMAX:
             # sampled hyper-parameters / inducing inputs / q(u) (runtime_variable.py:96-118 broadcast semantics): ONE fused call with a sample
             # stride per operand (mxf_svgp_logpdf_sampled; the reference's test_log_pdf_w_samples_* pattern, svgpregression_test.py:142-167)
-            logL, info = SVGPSampledLogPdfFn.apply(kind, ard, float(self.jitter), scaling, X, Y, *shared)
+            logL, info = SVGPSampledLogPdfFn.apply(self._f32_guard(), kind, ard, float(self.jitter), scaling, X, Y, *shared)
             info = ops.merge_info(*info.reshape(-1, 1))
         else:
             # sampled parameters together with per-point / per-output noise: one heteroscedastic call per sample
             S = max(_S(t) for t in (X, Y) + shared)
             pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
-            outs = [SVGPLogPdfFn.apply(kind, ard, float(self.jitter), scaling, pick(X, s), pick(Y, s), *[pick(t, s) for t in shared])
+            outs = [SVGPLogPdfFn.apply(self._f32_guard(), kind, ard, float(self.jitter), scaling, pick(X, s), pick(Y, s), *[pick(t, s) for t in shared])
                     for s in range(S)]
             logL = torch.cat([o[0] for o in outs])
             info = ops.merge_info(*[o[1] for o in outs])
@@ -104,12 +112,12 @@ class SVGPRegressionLogPdf(VariationalInference):
         ops_in = (Kuu, Kuf, Kdiag, Y, noise_var, mu, S_W, S_diag)
         if all(_S(t) == 1 for t in (Kuu, Kuf, Kdiag, noise_var, mu, S_W, S_diag)):
             # shared inputs and parameters, Y possibly sampled (a hidden layer of a deep GP): ONE call for all samples of Y
-            logL, info = SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *ops_in)
+            logL, info = SVGPMatLogPdfFn.apply(self._f32_guard(), float(self.jitter), float(self.log_pdf_scaling), *ops_in)
             self._last_info = info
             return logL * 1.0
         S = max(_S(t) for t in ops_in)
         pick = lambda t, s: t[s:s + 1] if _S(t) > 1 else t
-        outs = [SVGPMatLogPdfFn.apply(float(self.jitter), float(self.log_pdf_scaling), *[pick(t, s) for t in ops_in]) for s in range(S)]
+        outs = [SVGPMatLogPdfFn.apply(self._f32_guard(), float(self.jitter), float(self.log_pdf_scaling), *[pick(t, s) for t in ops_in]) for s in range(S)]
         self._last_info = ops.merge_info(*[o[1] for o in outs])
         return torch.cat([o[0] for o in outs])
 

@@ -136,6 +136,36 @@ def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, 
     return out
 
 
+def gemm_f16x2_planes_out(A_split, B_split, M, N, K, alpha=1.0, a_lower=False):
+    """alpha A B^T written directly as the two f16 planes (unscaled hi + lo) of the (M x N) operand whose contraction index is its column
+    (mxf_gemm_f16x2_planes_out: chained split products; M % 128 == 0, N % 256 == 0).  Returns the int16 planes tensor."""
+    (pa, wa), (pb, wb) = A_split, B_split
+    n = _lib.load().mxf_f32x3_plane_elems(M, N)
+    out = torch.empty(2 * n, dtype=torch.int16, device=pa.device)
+    _lib.call('mxf_gemm_f16x2_planes_out', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), _p(out), int(bool(a_lower)), _stream())
+    return out
+
+
+def f16x2_planes_transpose(planes, R, K, a=None, scale=None):
+    """Planes of an (R x K) operand -> planes of its transpose (K x R) (mxf_f16x2_planes_transpose); with a (R,) and scale (1,) float32 also
+    U[k] = scale * sum_r a[r] x(r, k).  Returns planes_T or (planes_T, U)."""
+    n = _lib.load().mxf_f32x3_plane_elems(K, R)
+    out = torch.empty(2 * n, dtype=torch.int16, device=planes.device)
+    U = torch.empty(K, dtype=torch.float32, device=planes.device) if a is not None else None
+    _lib.call('mxf_f16x2_planes_transpose', _h(planes), R, K, _p(planes), _p(out), _p(_c(a)) if a is not None else None,
+              _p(_c(scale)) if scale is not None else None, _p(U), _stream())
+    return out if U is None else (out, U)
+
+
+def planes_to_dense(planes, R, K):
+    """Decode two f16 planes (k16-blocked, element (r, k) at ((k // 16) * R + r) * 16 + k % 16) to the float64 matrix hi + lo (test helper)."""
+    K16 = (K + 15) // 16
+    n = K16 * R * 16
+    v = planes.view(torch.float16)
+    dec = lambda q: v[q * n:(q + 1) * n].view(K16, R, 16).permute(1, 0, 2).reshape(R, K16 * 16)[:, :K].double()
+    return dec(0) + dec(1)
+
+
 def f32x3_split(X):
     """Three-term bf16 split planes of a 2-D float32 matrix (operand format of gemm_f32x3_planes); returns an int16 tensor."""
     X = _c(X)

@@ -412,7 +412,7 @@ def test_fused_bridges_reject_non_uniform_sample_weights():
     Y, Z = _dev(rng.rand(1, B, 1)), _dev(rng.rand(1, M, Q)).requires_grad_(True)
     args = (_dev([[0.1]]), _dev(rng.randn(1, M, 1) * 0.1), _dev(rng.randn(1, M, M) * 0.05), _dev(rng.rand(1, M) + 0.5), _dev(np.ones((1, Q))),
             _dev([[1.0]]))
-    logL, _ = SVGPLogPdfFn.apply('rbf', True, 1e-6, 1.0, X, Y, Z, *args)
+    logL, _ = SVGPLogPdfFn.apply(None, 'rbf', True, 1e-6, 1.0, X, Y, Z, *args)
     gX, gZ = torch.autograd.grad(logL.mean(), (X, Z), retain_graph=True)          # the reference's reduction: fine
     assert torch.isfinite(gX).all() and torch.isfinite(gZ).all()
     w = _dev([1.0, 2.0, 3.0])

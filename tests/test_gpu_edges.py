@@ -107,7 +107,7 @@ def test_wide_inputs_beyond_the_tiled_kernels():
     total = 0
     for p0 in range(0, P, 8):
         sl = slice(p0, min(p0 + 8, P))
-        total = total + SVGPLogPdfFn.apply('rbf', True, 1e-6, 1.0, dv['X'], _t(Y[..., sl]), dv['Z'], dv['noise'], dv['qm'][..., sl], dv['qW'], dv['qd'],
+        total = total + SVGPLogPdfFn.apply(None, 'rbf', True, 1e-6, 1.0, dv['X'], _t(Y[..., sl]), dv['Z'], dv['noise'], dv['qm'][..., sl], dv['qW'], dv['qd'],
                                            dv['ls'], _t(var))[0]
     assert np.allclose(total.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-9)
     total.mean().backward()

@@ -1,7 +1,8 @@
-"""The float32 guard of the SVGP training call: above cond_1(Kuu + jitter I) ~ 3e3 the float32 streaming form cannot
-hold north_star's 1e-5 on the ELBO (its error grows like cond 2^-24: 2e-3 at 5e4), so the module switches its streaming stage to float64 BY
-ITSELF -- first call checked synchronously, later calls through the condition number every finished call publishes into pinned host memory
-(mxf_svgp_cond_nowait, no synchronisation).  Checked against the ORACLE at length-scale 3 (cond ~ 5e4), B = 8192, M = 1024."""
+"""The float32 guard of the SVGP module (modules/gp_modules/_fused.py: Float32Guard): three levels PER MODULE --
+explicit-inverse float32 up to cond_1(Kuu + jitter I) = 3e3, WHITENED float32 (the reference's factorised form, svgp_regression.py:83-92, on
+the split GEMMs) up to 5e6, float64 above or where the whitened form does not apply (no-grad evaluations, combination kernels).  The first
+call of an owner is checked synchronously; later calls through the condition number every finished call publishes into the owner's slot
+of pinned host memory (mxf_svgp_cond_slot, no synchronisation).  Checked against the ORACLE at B = 8192, M = 1024."""
 import warnings
 
 import numpy as np
@@ -23,56 +24,100 @@ def _inputs(ell, seed=0):
     return dict(X=X, Y=Y[None], Z=Z[None], noise=np.array([[0.02]]), qm=qm[None], qW=qW[None], qd=qd[None], ls=np.full((1, Q), ell), var=np.array([[1.0]]))
 
 
-def _oracle(a):
-    T = O.T
-    return float(O.svgp_log_pdf(O.RBF(8, ARD=True), T(a['X']), T(a['Y']), T(a['Z']), T(a['noise']), T(a['qm']), T(a['qW']), T(a['qd']),
-                                {'rbf_lengthscale': T(a['ls']), 'rbf_variance': T(a['var'])}, jitter=1e-6)[0])
+_ORACLE = {}
 
 
-def _module_call(a):
-    """The module's bridge (SVGPRegressionLogPdf.compute -> SVGPLogPdfFn) in float32 with the reverse mode requested, as a training step calls it."""
+def _oracle(a, ell):
+    if ell not in _ORACLE:
+        T = O.T
+        _ORACLE[ell] = float(O.svgp_log_pdf(O.RBF(8, ARD=True), T(a['X']), T(a['Y']), T(a['Z']), T(a['noise']), T(a['qm']), T(a['qW']), T(a['qd']),
+                                            {'rbf_lengthscale': T(a['ls']), 'rbf_variance': T(a['var'])}, jitter=1e-6)[0])
+    return _ORACLE[ell]
+
+
+def _module_call(a, guard=None, grad=True):
+    """The module's bridge (SVGPRegressionLogPdf.compute -> SVGPLogPdfFn) in float32, as a training step (grad) or an evaluation calls it."""
     from mxfusion_amd.modules.gp_modules._fused import SVGPLogPdfFn
-    t = {k: torch.as_tensor(v, dtype=torch.float32).cuda().requires_grad_(k not in ('Y',)) for k, v in a.items()}
-    logL, info = SVGPLogPdfFn.apply('rbf', True, 1e-6, 1.0, t['X'], t['Y'], t['Z'], t['noise'], t['qm'], t['qW'], t['qd'], t['ls'], t['var'])
-    logL.sum().backward()
+    t = {k: torch.as_tensor(v, dtype=torch.float32).cuda().requires_grad_(grad and k not in ('Y',)) for k, v in a.items()}
+    logL, info = SVGPLogPdfFn.apply(guard, 'rbf', True, 1e-6, 1.0, t['X'], t['Y'], t['Z'], t['noise'], t['qm'], t['qW'], t['qd'], t['ls'], t['var'])
+    if grad:
+        logL.sum().backward()
+        assert t['Z'].grad.dtype == torch.float32
     torch.cuda.synchronize()
-    assert int(info.abs().sum()) == 0 and logL.dtype == torch.float32 and t['Z'].grad.dtype == torch.float32
+    assert int(info.abs().sum()) == 0 and logL.dtype == torch.float32
     return float(logL[0])
 
 
-def test_ill_conditioned_start_is_never_evaluated_in_float32():
+def test_ill_conditioned_start_is_never_evaluated_in_a_form_that_cannot_hold_it():
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard
-    from mxfusion_amd import ops
+    G = Float32Guard
+    # cond_1 ~ 1e6: the explicit form fails, the whitened float32 form holds north_star's bar -- through the float32 API, first call
     a = _inputs(3.0)
-    ref = _oracle(a)
+    ref = _oracle(a, 3.0)
+    g = G('t1')
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
-        got = _module_call(a)
-    assert Float32Guard.active and any('float64' in str(x.message) for x in w)
-    assert ops.svgp_last_cond() > Float32Guard.LIMIT
-    assert abs(got - ref) <= 1e-5 * abs(ref), (got, ref)                 # north_star's bar, at cond ~ 5e4, through the float32 API
-    # the plain float32 call (guard bypassed) is what the guard protects from: it misses the bar there
-    Float32Guard.reset()
-    Float32Guard.enabled = False
-    try:
-        raw = _module_call(a)
-    finally:
-        Float32Guard.enabled = True
-    assert abs(raw - ref) > 1e-5 * abs(ref)
-
-
-def test_guard_trips_without_synchronising_when_training_leaves_the_float32_range():
-    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
-    from mxfusion_amd import ops
-    good, bad = _inputs(1.0), _inputs(3.0)
-    ref_good, ref_bad = _oracle(good), _oracle(bad)
+        got = _module_call(a, g)
+    assert g.tier == G.WHITENED and any('whitened' in str(x.message) for x in w), (g.tier, g.cond_max)
+    assert G.LIMIT < g.cond_max < G.LIMIT_WHITENED
+    assert abs(got - ref) <= 1e-5 * abs(ref), (got, ref)
+    # cond_1 ~ 3e7: float64
+    a4 = _inputs(4.0)
+    ref4 = _oracle(a4, 4.0)
+    g4 = G('t2')
     with warnings.catch_warnings(record=True):
         warnings.simplefilter('always')
-        g = _module_call(good)                                           # first call: checked synchronously, well conditioned
-        assert not Float32Guard.active and abs(g - ref_good) <= 1e-5 * abs(ref_good)
-        assert 0 < ops.svgp_cond_nowait() < Float32Guard.LIMIT
-        _module_call(bad)                                                # the parameters have drifted: this call still runs in float32 ...
-        assert ops.svgp_cond_nowait() > Float32Guard.LIMIT               # ... and publishes its condition number
-        b = _module_call(bad)                                            # the next one sees it (no host sync needed) and runs in float64
-    assert Float32Guard.active
-    assert abs(b - ref_bad) <= 1e-5 * abs(ref_bad), (b, ref_bad)
+        got4 = _module_call(a4, g4)
+    assert g4.tier == G.F64 and g4.cond_max > G.LIMIT_WHITENED
+    assert abs(got4 - ref4) <= 1e-5 * abs(ref4), (got4, ref4)
+    # the plain float32 call (guard bypassed) is what the guard protects from: it misses the bar at both
+    G.enabled = False
+    try:
+        raw = _module_call(a, G('t3'))
+    finally:
+        G.enabled = True
+    assert abs(raw - ref) > 1e-5 * abs(ref)
+    rep = G.report()
+    assert rep['float32_fallback_active'] and rep['float32_whitened_active'] and rep['kuu_cond_max'] > G.LIMIT_WHITENED
+
+
+def test_guard_moves_without_synchronising_and_comes_back():
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
+    good, bad = _inputs(1.0), _inputs(3.0)
+    ref_good, ref_bad = _oracle(good, 1.0), _oracle(bad, 3.0)
+    g = G('drift')
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        v = _module_call(good, g)                                        # first call: checked synchronously, well conditioned
+        assert g.tier == G.EXPLICIT and abs(v - ref_good) <= 1e-5 * abs(ref_good) and 0 < g.cond_max < G.LIMIT
+        _module_call(bad, g)                                             # the parameters have drifted: this call still runs in the explicit form ...
+        assert g.tier == G.EXPLICIT
+        b = _module_call(bad, g)                                         # ... the next one sees what it published (no host sync) and runs whitened
+        assert g.tier == G.WHITENED and abs(b - ref_bad) <= 1e-5 * abs(ref_bad), (g.tier, b, ref_bad)
+        _module_call(good, g)                                            # back to a benign Kuu: one whitened call publishes it ...
+        v2 = _module_call(good, g)                                       # ... and the owner returns to the fast form
+        assert g.tier == G.EXPLICIT and abs(v2 - ref_good) <= 1e-5 * abs(ref_good)
+    assert g.switches == 2
+
+
+def test_guard_is_per_module_and_covers_evaluations():
+    """Two owners on one handle (the two layers of a deep GP): the ill-conditioned one moves to the whitened form, the other stays on the
+    fast form (the r03 guard was process-wide and sticky).  A no-grad evaluation above the limit runs in float64."""
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
+    good, bad = _inputs(1.0, seed=1), _inputs(3.0)
+    ref_bad = _oracle(bad, 3.0)
+    g1, g2 = G('layer1'), G('layer2')
+    assert g1.slot != g2.slot
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        for _ in range(3):
+            _module_call(good, g1)
+            b = _module_call(bad, g2)
+        assert g1.tier == G.EXPLICIT and g2.tier == G.WHITENED
+        assert g1.cond_max < G.LIMIT < g2.cond_max
+        assert abs(b - ref_bad) <= 1e-5 * abs(ref_bad)
+        ev = _module_call(bad, g2, grad=False)                           # evaluation: no whitened form -> float64
+        assert abs(ev - ref_bad) <= 1e-5 * abs(ref_bad)
+        g3 = G('eval-first')
+        ev3 = _module_call(bad, g3, grad=False)                          # ... also as an owner's very first call
+        assert abs(ev3 - ref_bad) <= 1e-5 * abs(ref_bad) and g3.tier == G.WHITENED

@@ -139,7 +139,7 @@ def test_deep_gp_layers_at_config5_size_against_the_oracle():
         Kuf = kern.K(None, Zg, Xd, **par)
         Kd = kern.Kdiag(None, Xd, **par)
         nz, m_, W_, s_ = (d(a)[None].requires_grad_(True) for a in (noise, qm1, qW, qd))
-        logL, info = SVGPMatLogPdfFn.apply(1e-6, 1.0, Kuu, Kuf, Kd, d(H)[None], nz, m_, W_, s_)
+        logL, info = SVGPMatLogPdfFn.apply(None, 1e-6, 1.0, Kuu, Kuf, Kd, d(H)[None], nz, m_, W_, s_)
         logL.mean().backward()
         torch.cuda.synchronize()
         assert int(info.abs().sum()) == 0

@@ -67,7 +67,7 @@ def test_module_with_sampled_noise_and_kernel_parameters_is_one_call(monkeypatch
     a = _problem(S, ('noise', 'ls', 'var'), seed=3, P=1)
     ref, g = _oracle(a, S, 1.0)
     t = {k: torch.as_tensor(v, dtype=torch.float64).cuda().requires_grad_(True) for k, v in a.items()}
-    logL, info = _fused.SVGPSampledLogPdfFn.apply('rbf', True, 1e-6, 1.0, t['X'], t['Y'], t['Z'], t['noise'], t['qm'], t['qW'], t['qd'], t['ls'], t['var'])
+    logL, info = _fused.SVGPSampledLogPdfFn.apply(None, 'rbf', True, 1e-6, 1.0, t['X'], t['Y'], t['Z'], t['noise'], t['qm'], t['qW'], t['qd'], t['ls'], t['var'])
     logL.mean().backward()
     torch.cuda.synchronize()
     assert len(calls) == 1

@@ -1,0 +1,127 @@
+"""The WHITENED float32 tier of the SVGP training call (mxf_svgp_configure(MXF_SVGP_WHITENED); csrc/whiten.hip, composite.hip): the
+factorised form the reference evaluates (svgp_regression.py:83-92: trsm with the Cholesky factor) on the split GEMMs --
+V = L^-1 Kuf (triangular product written directly as f16 planes), Phi = V V^T, T = L^-T (I - A_s A_s^T) V, U = (L^-1 mu)^T V.
+Checked against the ORACLE where the explicit-inverse float32 form fails (cond_1(Kuu) 1e6 .. 3e7), and piecewise (the chained split
+products) against float64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _dev(a, dt=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dt).cuda()
+
+
+@pytest.mark.parametrize('M,N,K,lower', [(256, 512, 256, False), (256, 512, 256, True), (128, 256, 128, True), (512, 768, 512, True), (384, 256, 384, False)])
+def test_planes_output_product_and_transposition(M, N, K, lower):
+    """mxf_gemm_f16x2_planes_out: alpha A B^T as f16 planes == the float64 product to f32 accuracy (also with a triangular A whose k loop
+    is cut short); mxf_f16x2_planes_transpose: the planes of the transpose hold the same values, and its fused U = scale a^T X."""
+    from mxfusion_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K))
+    if lower:
+        A = np.tril(A)
+    Bm = rng.uniform(0, 1, (N, K)) ** 3
+    ref = A @ Bm.T
+    alpha = 8192.0 / np.abs(ref).max()
+    pl = ops.gemm_f16x2_planes_out(ops.f16x2_split(_dev(A)), ops.f16x2_split(_dev(Bm)), M, N, K, alpha=alpha, a_lower=lower)
+    got = ops.planes_to_dense(pl, M, N).cpu().numpy() / alpha
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 3e-6, err
+    a = rng.standard_normal(M).astype(np.float32)
+    plT, U = ops.f16x2_planes_transpose(pl, M, N, a=_dev(a), scale=_dev([0.5]))
+    gotT = ops.planes_to_dense(plT, N, M).cpu().numpy()
+    assert np.array_equal(gotT, ops.planes_to_dense(pl, M, N).cpu().numpy().T)
+    Uref = 0.5 * a.astype(np.float64) @ (got * alpha)
+    assert np.abs(U.cpu().numpy() - Uref).max() <= 1e-5 * np.abs(Uref).max()
+    # the planes feed a following split product: Phi = X X^T
+    w = torch.full((1,), 8192.0, dtype=torch.float32).cuda().view(torch.int32)      # a max word in [2^13, 2^14) = scale 1: the planes are unscaled
+    Phi = ops.gemm_f16x2_planes((pl, w), (pl, w), M, M, N).cpu().numpy()
+    Pref = (got * alpha) @ (got * alpha).T
+    assert np.abs(np.tril(Phi) - np.tril(Pref)).max() <= 3e-6 * np.abs(Pref).max()
+
+
+def _inputs(B, M, Q, P, ell, S=1, seed=0, kind='rbf'):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-3., 3., (S, B, Q))
+    Y = np.sin(X[0] @ rng.standard_normal((Q, P))) + 0.05 * rng.standard_normal((B, P))
+    Z = rng.uniform(-3., 3., (M, Q))
+    qm, qW, qd = 0.3 * rng.standard_normal((M, P)), 0.4 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
+    return dict(X=X, Y=Y[None], Z=Z, noise=np.array([0.02]), qm=qm, qW=qW, qd=qd, ls=np.full(Q, ell), var=np.array([1.3]))
+
+
+def _oracle(a, kind='rbf'):
+    T = O.T
+    k = {'rbf': O.RBF, 'matern52': O.Matern52, 'matern32': O.Matern32, 'matern12': O.Matern12}[kind](a['X'].shape[-1], ARD=True)
+    names = ('X', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    lv = {n: T(a[n]).clone().requires_grad_(True) for n in names}
+    logL = O.svgp_log_pdf(k, lv['X'], T(a['Y']), lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {k.name + '_lengthscale': lv['ls'][None], k.name + '_variance': lv['var'][None]}, jitter=1e-6)
+    g = torch.autograd.grad(logL.mean(), [lv[n] for n in names])
+    return logL.detach().numpy(), dict(zip(('dX', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar'), [x.numpy() for x in g]))
+
+
+def _run(a, form, kind='rbf', dt=torch.float32):
+    from mxfusion_amd import _lib, ops
+    _lib.svgp_configure(torch.cuda.current_device(), form, 5)
+    try:
+        d = lambda x: _dev(x, dt)
+        S = a['X'].shape[0]
+        r = ops.svgp_logpdf(kind, d(a['X']), d(a['Y']), d(a['Z']), d(a['noise']), d(a['qm']), d(a['qW']), d(a['qd']), d(a['ls']), d(a['var']), True,
+                            jitter=1e-6, gscale=1.0 / S, want_grad=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.svgp_configure(torch.cuda.current_device(), _lib.FORM_EXPLICIT, 0)
+    assert int(r['info'].abs().sum()) == 0
+    return {k: v.double().cpu().numpy() for k, v in r.items()}
+
+
+def _nrm(a, b):
+    return float(np.linalg.norm(a.ravel() - b.ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+@pytest.mark.parametrize('B,M,Q,P,S,kind', [(512, 128, 8, 1, 1, 'rbf'), (256, 256, 3, 1, 2, 'rbf'), (512, 128, 8, 2, 1, 'rbf'), (768, 128, 12, 1, 1, 'rbf'),
+                                            (512, 256, 8, 1, 1, 'matern52'), (256, 128, 5, 3, 2, 'matern32')])
+def test_whitened_form_matches_the_oracle_small(B, M, Q, P, S, kind):
+    """Values and all gradients of the whitened float32 call against the oracle's autograd, across the launch shapes (one / several output
+    columns: fused / separate U; Q <= 8 / > 8: blocked / row-major T; 128- and 256-row tiles; sampled inputs), at a length-scale where Kuu
+    is moderately ill-conditioned."""
+    from mxfusion_amd import _lib
+    a = _inputs(B, M, Q, P, 2.0 if Q > 4 else 0.6, S=S, seed=B + M + Q + P, kind=kind)
+    ref, gref = _oracle(a, kind)
+    got = _run(a, _lib.FORM_WHITENED, kind)
+    assert np.abs(got['logL'] - ref).max() <= 1e-5 * np.abs(ref).max(), (got['logL'], ref)
+    for k, g in gref.items():
+        assert _nrm(got[k], g) <= 2e-3, (k, _nrm(got[k], g))
+    # and the float64 call is untouched by the configured form
+    g64 = _run(a, _lib.FORM_WHITENED, kind, torch.float64)
+    assert np.abs(g64['logL'] - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('ell', [2.2, 3.0, 4.0])
+def test_whitened_form_holds_the_bar_where_the_explicit_form_fails(ell):
+    """B = 8192, M = 1024, Q = 8 (the inputs of test_gpu_f32_guard.py): cond_1(Kuu) ~ 3e4 / 1e6 / 3e7.  Whitened float32: ELBO to 1e-5 (north_star)
+    and every gradient to 1e-3 normwise against the oracle (5e-3 at 3e7, beyond the guard's whitened range); the explicit-inverse form misses the ELBO bar from ell = 3 on and its dW is two
+    digits worse already at 2.2 (Ki G Ki with a float32 Psi2: error ~ cond^2)."""
+    from mxfusion_amd import _lib, ops
+    a = _inputs(8192, 1024, 8, 1, ell, seed=0)
+    a['var'] = np.array([1.0])
+    ref, gref = _oracle(a)
+    w = _run(a, _lib.FORM_WHITENED)
+    cond = ops.svgp_last_cond()
+    e = _run(a, _lib.FORM_EXPLICIT)
+    rel_w, rel_e = abs(w['logL'][0] - ref[0]) / abs(ref[0]), abs(e['logL'][0] - ref[0]) / abs(ref[0])
+    errs_w = {k: _nrm(w[k], g) for k, g in gref.items()}
+    errs_e = {k: _nrm(e[k], g) for k, g in gref.items()}
+    print('ell %.1f cond_1 %.2e  ELBO rel: whitened %.2e explicit %.2e\n  whitened %s\n  explicit %s' % (
+        ell, cond, rel_w, rel_e, {k: '%.1e' % v for k, v in errs_w.items()}, {k: '%.1e' % v for k, v in errs_e.items()}))
+    assert rel_w <= 1e-5, (rel_w, rel_e)
+    for k, v in errs_w.items():      # (ell = 4, cond 3e7, lies beyond Float32Guard.LIMIT_WHITENED = 5e6: the guard would run float64 there)
+        assert v <= (1e-3 if ell <= 3.0 else 5e-3), (k, v, errs_e[k])
+    if ell >= 3.0:
+        assert rel_e > 1e-5
+    assert errs_w['dW'] < errs_e['dW']
