@@ -393,6 +393,55 @@ def time_steps_multi(infr, loop, data, steps, warmup, lr, distributed):
     return _finish_timing(t0, distributed) + (float(loss.detach()),)
 
 
+def set_trained_like(m, infr, Q, M, td):
+    """The parameters a 300-step optimisation of the bench model ends near (tests/probes/train_probe.py): length-scale 2.2 (cond_1(Kuu) ~ 1.4e3),
+    noise 0.02, a non-trivial q(u).  At the initial point (length-scale 1, qU_W = 0) 94 % of the f16 operand planes are zero and Kuu ~ I."""
+    rngq = np.random.default_rng(11)
+    qm_t, qW_t, qd_t = 0.3 * rngq.standard_normal((M, 1)), 0.4 * rngq.standard_normal((M, M)) / math.sqrt(M), rngq.uniform(0.05, 0.5, M)
+    gp_ = m.Y.factor
+    post_ = gp_._extra_graphs[0]
+    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=td).cuda()
+    infr.params[gp_.kernel.lengthscale] = tt(np.full(Q, 2.2))
+    infr.params[m.noise_var] = tt([0.02])
+    infr.params[post_.qU_mean], infr.params[post_.qU_cov_W], infr.params[post_.qU_cov_diag] = tt(qm_t), tt(qW_t), tt(qd_t)
+
+
+def step_breakdown(infr, loop, Yd, lr, M, SB):
+    """In-step durations of the training call's bulk kernels (HIP events inside the library on the stream each kernel runs on,
+    mxf_svgp_timing) over three further steps, and the rooflines they give: the Gram -> planes passes against HBM (4 bytes per covariance
+    written), the T and Psi2 / Phi products against the f16 matrix pipe / 3."""
+    from mxfusion_amd import _lib
+    from mxfusion_amd.inference.batch_loop import _Adam
+    dev = torch.cuda.current_device()
+    executor = infr.create_executor()
+    trainer = _Adam(infr.params, lr)
+    _lib.svgp_timing(dev, True)
+    acc, n = {}, 0
+    try:
+        for _ in range(3):
+            loop.step(executor, [Yd], infr.params)
+            trainer.step(batch_size=1)
+            for k, v in _lib.svgp_timing_read(dev).items():
+                acc[k] = acc.get(k, 0.0) + v
+            n += 1
+    finally:
+        _lib.svgp_timing(dev, False)
+    ms = {k: v / n for k, v in acc.items()}
+    out = {"step_breakdown_ms": {k: round(v, 4) for k, v in ms.items()}}
+    pb = 4.0 * M * SB                                # two f16 planes per covariance
+    for key, name in (('planes_a', 'first'), ('planes_b', 'second')):
+        if key in ms:
+            out.setdefault("roofline_planes", {})[name] = {"bound": "hbm", "achieved": pb / ms[key] / 1e6, "peak": 8000.0, "unit": "GB/s",
+                                                           "frac": pb / ms[key] / 1e6 / 8000.0, "ms_in_step": ms[key], "algorithmic_bytes": pb}
+    if "roofline_planes" in out:
+        out["roofline_planes"]["kernel"] = "gram_planes_lean_kernel (Gram written as two f16 planes; whitened form: second = planes transposition, 8 bytes per element)"
+    if 't_gemm' in ms:
+        f = 2.0 * M * M * SB
+        out["roofline_mfma_in_step"] = {"bound": "mfma", "kernel": "T product inside the step", "achieved": f / ms['t_gemm'] / 1e9, "peak": 2500.0 / 3,
+                                        "unit": "TFLOP/s", "frac": f / ms['t_gemm'] / 1e9 / (2500.0 / 3), "ms_in_step": ms['t_gemm']}
+    return out
+
+
 def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     from mxfusion_amd.inference.batch_loop import _Adam
     import torch.distributed as dist
@@ -593,6 +642,11 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
+    ap.add_argument('--f32-form', default='auto', choices=['auto', 'explicit', 'whitened', 'float64'],
+                    help="float32 SVGP calls: 'auto' = the per-module guard picks (explicit-inverse up to cond 3e3, whitened up to 5e6, float64 above); "
+                         "the others force one form for a measurement")
+    ap.add_argument('--trained-like', action='store_true', help='svgp workload: time the step at the trained-like parameters (length-scale 2.2, '
+                    'noise 0.02, non-trivial q(u)) instead of the initial point')
     ap.add_argument('--no-f32-guard', action='store_true', help='disable the automatic float64 fallback of the float32 SVGP step above cond_1(Kuu) 3e3 '
                                                                     '(DESIGN.md section 5): raw float32 timing of an ill-conditioned model')
     args = ap.parse_args()
@@ -626,6 +680,9 @@ def main():
     if args.no_f32_guard:
         from mxfusion_amd.modules.gp_modules._fused import Float32Guard
         Float32Guard.enabled = False
+    if args.f32_form != 'auto':
+        from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+        Float32Guard.force = {'explicit': Float32Guard.EXPLICIT, 'whitened': Float32Guard.WHITENED, 'float64': Float32Guard.F64}[args.f32_form]
 
     def guard_report():
         """float32 validity of what was timed: the largest cond_1(Kuu + jitter I) the training calls published and the level every SVGP
@@ -736,6 +793,8 @@ def main():
         return
     m, q, infr, loop, qX = build(N, Q, M, S_local, args.dtype, X, Y, Z, distributed, use_graph=args.graph)
     td = torch.float32 if args.dtype == 'float32' else torch.float64
+    if args.trained_like:
+        set_trained_like(m, infr, Q, M, td)
     Yd = torch.as_tensor(Y, dtype=td).cuda()
     dt, last_loss = time_steps(infr, loop, Yd, args.steps, args.warmup, args.lr, distributed)
     rep = dist_report(world, args.steps, infr.params.flat.numel(), td)              # collective: every rank
@@ -755,6 +814,26 @@ def main():
     }
     out.update(rep)
     out.update(guard_report())
+    out["parameters"] = "trained-like (length-scale 2.2, noise 0.02, non-trivial q(u))" if args.trained_like else "initial point (length-scale 1, q(u) = N(0, I))"
+    out["f32_form"] = args.f32_form
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == 'float32':
+        out.update(step_breakdown(infr, loop, Yd, args.lr, M, N * S_local))
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == 'float32' and not args.trained_like and args.f32_form == 'auto':
+        # the regime the step is used in: the same step at trained-like parameters (explicit form: cond ~ 1.4e3 < 3e3), and in the
+        # whitened float32 form the guard selects above cond 3e3
+        from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+        nst = max(3, args.steps // 2)
+        set_trained_like(m, infr, Q, M, td)
+        dtt, _ = time_steps(infr, loop, Yd, nst, 2, args.lr, False)
+        out["ms_per_step_trained_like"] = dtt / nst * 1e3
+        out["trained_like"] = dict(guard_report(), **step_breakdown(infr, loop, Yd, args.lr, M, N * S_local))
+        Float32Guard.force = Float32Guard.WHITENED
+        try:
+            dtw, _ = time_steps(infr, loop, Yd, nst, 2, args.lr, False)
+            out["ms_per_step_whitened"] = dtw / nst * 1e3
+            out["whitened"] = step_breakdown(infr, loop, Yd, args.lr, M, N * S_local)
+        finally:
+            Float32Guard.force = None
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q
         torch.cuda.empty_cache()
@@ -775,8 +854,6 @@ def main():
         torch.cuda.empty_cache()
         from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
         eps64 = torch.randn(4, N, Q, dtype=torch.float64, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
-        rngq = np.random.default_rng(11)
-        qm_t, qW_t, qd_t = 0.3 * rngq.standard_normal((M, 1)), 0.4 * rngq.standard_normal((M, M)) / math.sqrt(M), rngq.uniform(0.05, 0.5, M)
         for key, trained in (("elbo_f32_vs_f64_rel", False), ("elbo_f32_vs_f64_rel_trained_like", True)):
             # the initial parameters of the timed run (length-scale 1: Kuu ~ I), and a trained-like set -- length-scale 2.2 (where a 300-step
             # optimisation of this model ends, tests/probes/train_probe.py; cond(Kuu + 1e-6 I) ~ 1.4e3), noise 0.02, a non-trivial q(u)
@@ -785,12 +862,7 @@ def main():
                 tdd = torch.float32 if dname == 'float32' else torch.float64
                 mm, qq, ii, ll, qx = build(N, Q, M, 4, dname, X, Y, Z, False)
                 if trained:
-                    gp_ = mm.Y.factor
-                    post_ = gp_._extra_graphs[0]
-                    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=tdd).cuda()
-                    ii.params[gp_.kernel.lengthscale] = tt(np.full(Q, 2.2))
-                    ii.params[mm.noise_var] = tt([0.02])
-                    ii.params[post_.qU_mean], ii.params[post_.qU_cov_W], ii.params[post_.qU_cov_diag] = tt(qm_t), tt(qW_t), tt(qd_t)
+                    set_trained_like(mm, ii, Q, M, tdd)
                 qx._rand_gen = MockRandomGenerator(eps64.to(tdd))     # identical injected noise in both precisions
                 ex = ii.create_executor()
                 # evaluated WITH the reverse mode requested: that is the call the timed step makes (float32: Grams as split planes, both big

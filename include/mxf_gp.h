@@ -79,6 +79,14 @@ int mxf_svgp_whitened_ok(int dtype, int S, int64_t B, int64_t M, int Q, int P, i
  * pointer may be NULL); reset != 0 clears both after the read.  A module instance that owns a slot sees its own Kuu only, whatever other
  * SVGP modules run on the same handle (mxf_svgp_cond_nowait = the maximum over all slots).                                               */
 int mxf_svgp_cond_slot(mxf_handle h, int slot, double* last_out, double* max_out, int reset);
+/* In-step durations of the bulk kernels of the LAST mxf_svgp_logpdf training call on this handle, measured with HIP events on the stream
+ * each kernel runs on (enable with mxf_svgp_timing(h, 1); off by default).  mxf_svgp_timing_read synchronises the device and fills
+ * ms_out[8] (-1 = not part of that call): [0] first Gram-planes pass (explicit form: Kuf planes; whitened: Kfu planes), [1] Psi2 / Phi
+ * product, [2] second planes pass (explicit: Kfu planes + U; whitened: transposition of V + U), [3] T product, [4] fused reverse pass,
+ * [5] the float64 core chain (Kuu ... H0 planes), [6] V = L^-1 Kuf (whitened), [7] the whole call on the caller's stream.
+ * bench.py divides algorithmic bytes / flops by these (roofline_planes, step_breakdown_ms).  No reference counterpart.                  */
+int mxf_svgp_timing(mxf_handle h, int enable);
+int mxf_svgp_timing_read(mxf_handle h, double* ms_out);
 
 /* out[0] = sum_i g[i] if the n values agree to 1e-6 relative, NaN otherwise.  The fused composites return the gradients of
  * gscale * sum_s logL[s] with ONE weight: the reverse-mode bridge uses this to scale them by the upstream gradient of mean_S(logL)

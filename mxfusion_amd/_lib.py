@@ -60,6 +60,8 @@ SIGNATURES = {
     'mxf_svgp_last_cond': [_c.POINTER(_d)],
     'mxf_svgp_cond_nowait': [_c.POINTER(_d), _i],
     'mxf_svgp_configure': [_i, _i],
+    'mxf_svgp_timing': [_i],
+    'mxf_svgp_timing_read': [_c.POINTER(_d)],
     'mxf_svgp_cond_slot': [_i, _c.POINTER(_d), _c.POINTER(_d), _i],
     'mxf_gemm_f16x2_planes_out': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     'mxf_f16x2_planes_transpose': [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -160,6 +162,20 @@ def svgp_cond_slot(device_index, slot, reset=False):
     last, mx = _d(0.0), _d(0.0)
     call('mxf_svgp_cond_slot', handle(device_index), int(slot), ctypes.byref(last), ctypes.byref(mx), int(bool(reset)))
     return float(last.value), float(mx.value)
+
+
+TIMING_KEYS = ('planes_a', 'psi2', 'planes_b', 't_gemm', 'reverse_pass', 'core_chain', 'v_gemm', 'call')
+
+
+def svgp_timing(device_index, enable):
+    call('mxf_svgp_timing', handle(device_index), int(bool(enable)))
+
+
+def svgp_timing_read(device_index):
+    """In-step durations (ms) of the last SVGP training call's bulk kernels (mxf_svgp_timing_read; synchronises); absent stages are dropped."""
+    buf = (_d * 8)()
+    call('mxf_svgp_timing_read', handle(device_index), buf)
+    return {k: float(buf[i]) for i, k in enumerate(TIMING_KEYS) if buf[i] >= 0}
 
 
 def svgp_whitened_ok(dtype, S, B, M, Q, P, stride_x):

@@ -44,7 +44,26 @@ struct mxf_stage_log {
 #define MXF_STAGE_DUMP(h) do { } while (0)
 #endif
 
+// In-step durations of the SVGP training call's bulk kernels (mxf_svgp_timing): HIP events around them on the stream each runs on -- what
+// bench.py's roofline entries for the in-step passes divide by.  Off by default (two event records per kernel when on).
+constexpr int MXF_NT = 8;
+struct mxf_timing {
+    bool on = false, made = false;
+    hipEvent_t ev[2 * MXF_NT];
+    bool used[MXF_NT] = {false, false, false, false, false, false, false, false};
+    bool init() {
+        if (made) return true;
+        for (int i = 0; i < 2 * MXF_NT; ++i) if (hipEventCreate(&ev[i]) != hipSuccess) return false;
+        made = true;
+        return true;
+    }
+};
+enum { MXF_T_PLANES_A = 0, MXF_T_PSI2 = 1, MXF_T_PLANES_B = 2, MXF_T_TGEMM = 3, MXF_T_BWD = 4, MXF_T_CHAIN = 5, MXF_T_VGEMM = 6, MXF_T_CALL = 7 };
+#define MXF_T0(h, i, s) do { if ((h)->tm.on) { (void)hipEventRecord((h)->tm.ev[2 * (i)], s); (h)->tm.used[i] = true; } } while (0)
+#define MXF_T1(h, i, s) do { if ((h)->tm.on) (void)hipEventRecord((h)->tm.ev[2 * (i) + 1], s); } while (0)
+
 struct mxf_ctx {
+    mxf_timing tm;
 #ifdef MXF_PROBES
     mxf_stage_log stages;
 #endif

@@ -679,6 +679,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_STAGE(h, "start", st);
     if (!mxf_cond_init(h)) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate the condition words");
     double* cond_slot = h->cond_host + 2 * h->cond_slot;
+    for (int i = 0; i < MXF_NT; ++i) h->tm.used[i] = false;
+    MXF_T0(h, MXF_T_CALL, st); MXF_T0(h, MXF_T_CHAIN, st);
     hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2, h->cond_dev);
     if (whiten) hipLaunchKernelGGL(svgp_sigma_kernel, dim3(1), dim3(64), 0, st, (const float*)var, sigf);
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
@@ -724,17 +726,21 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // whitened tier: only the Kfu planes (operand (n, k = m) of V = L^-1 Kuf); they need nothing from the core, so they are written
         // first; V, its transposition (+ U = a^T V) and Phi = V V^T follow on this stream once L^-1 exists (below, after the Kuu chain
         // has been queued)
+        MXF_T0(h, MXF_T_PLANES_A, sd_);
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
                                       (int64_t)pl_big, gscr1, sd_, split_mode);
         if (rc) return rc;
+        MXF_T1(h, MXF_T_PLANES_A, sd_);
         MXF_STAGE(h, "Kfu planes (sd)", sd_);
     } else if (use_split) {
         // float32 training step: the Grams are written directly as split planes (two scaled f16 terms = 4 bytes per element, never as f32):
         // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
         // (n, k = m): T GEMM and the w^T Kuf row) are then written (HBM bound) on the second side stream NEXT TO Psi2.
+        MXF_T0(h, MXF_T_PLANES_A, sd_);
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
                                       (int64_t)pl_big, gscr0, sd_, split_mode);
         if (rc) return rc;
+        MXF_T1(h, MXF_T_PLANES_A, sd_);
         MXF_STAGE(h, "Kuf planes (sd)", sd_);
         // (the Kfu planes -- operand (n, k = m) of the T GEMM -- are written later, on the second side stream, once w = Kuu^-1 mu exists:
         //  the same pass then also forms the row U = w^T Kuf)
@@ -755,6 +761,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         const int64_t ka_dflt = (use_split ? 192 : 128) * M;
         const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split && SB <= 2 * ka_dflt ? SB : ka_dflt);
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
+        MXF_T0(h, MXF_T_PSI2, sd_);
         if (use_split) {
             if (KA > 0) {
                 // 3 workgroups of the three-term kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs; the two-term
@@ -783,6 +790,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             }
         }
         hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_T1(h, MXF_T_PSI2, sd_);
         MXF_STAGE(h, "Psi2 (sd)", sd_);
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));
     }
@@ -807,9 +815,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // side stream: V = L^-1 Kuf, written as the planes of the (m, k = n) operand holding V / sigma * 2^14 (|v_n|^2 <= k_nn = sigma^2):
         // acc = (s_L L^-1) (Kfu / sigma^2 2^14)^T  ->  acc sigma / s_L.  L^-1 is lower triangular: a row tile's k loop stops at its last row.
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
+        MXF_T0(h, MXF_T_VGEMM, sd_);
         rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, 0, split_mode, sigf, 1,
                                      (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1);
         if (rc) return rc;
+        MXF_T1(h, MXF_T_VGEMM, sd_);
         MXF_STAGE(h, "V = Linv Kuf (sd)", sd_);
     }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
@@ -831,6 +841,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // side stream: V planes -> planes of the (n, k = m) operand (into the Kfu planes' slot: V = L^-1 Kuf has consumed them) and, for one
         // output column, U = a^T V in the same pass; P > 1: U from the transposed planes (one more read of them)
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
+        MXF_T0(h, MXF_T_PLANES_B, sd_);
         rc = mxf_planes_transpose_internal(h, M, SB, plKuf, (int64_t)pl_big, plKfu, (int64_t)pl_big, (const float*)aT, sigf, 1.f / 16384.f,
                                            P == 1 ? (float*)(Text + M * SB) : nullptr, sd_);
         if (rc) return rc;
@@ -838,13 +849,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plKfu,
                                (int64_t)pl_big, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
         }
+        MXF_T1(h, MXF_T_PLANES_B, sd_);
         MXF_STAGE(h, "V^T planes + U (sd)", sd_);
         MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
+        MXF_T0(h, MXF_T_PSI2, sd_);
         // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T
         rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
                                      psi2_rb, split_mode, split_var, 1, nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_T1(h, MXF_T_PSI2, sd_);
         MXF_STAGE(h, "Phi (sd)", sd_);
     }
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
@@ -872,9 +886,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // Ki -- shares the chip with the Kuf planes pass and Psi2 and finishes just after Psi2: 0.9 / 1.4 / 1.6 ms at 4 samples against 0.6
         // alone.  A stream of its own for this pass changes nothing: H0, hence the T GEMM, waits for the same chain.)
         MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
+        MXF_T0(h, MXF_T_PLANES_B, s2_);
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
                                       (int64_t)pl_big, gscr1, s2_, split_mode, (const float*)wT, P, (float*)(Text + M * SB), SB);
         if (rc) return rc;
+        MXF_T1(h, MXF_T_PLANES_B, s2_);
         MXF_STAGE(h, "Kfu planes + U (s2)", s2_);
         MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // Kfu planes and U ready: the T GEMM / the reverse pass wait for it
     }
@@ -907,9 +923,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st, split_mode, split_mode == MXF_SPLIT_F16X2 ? h0max : nullptr);
         if (rc) return rc;
     }
+    MXF_T1(h, MXF_T_CHAIN, st);
     MXF_STAGE(h, "H0 planes", st);
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
+    MXF_T0(h, MXF_T_TGEMM, st);
     if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
@@ -920,6 +938,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
+    MXF_T1(h, MXF_T_TGEMM, st);
     MXF_STAGE(h, "T", st);
     if (use_split) {
         // (U = w^T Kuf was written by the Kfu planes pass)
@@ -1017,12 +1036,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (dX) MXF_HIP(h, hipMemsetAsync(dX, 0, sizeof(T) * (size_t)SB * Q, st));
         MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
+        MXF_T0(h, MXF_T_BWD, st);
         rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
                                          dY, dY_shared, R, scal, st, t_blocked,
                                          (use_split && split_mode == MXF_SPLIT_F16X2) ? (const unsigned*)(info2 + 2) : nullptr,
                                          (const unsigned*)(info2 + 3));
         if (rc) return rc;
     }
+    if (want_grad && !het) MXF_T1(h, MXF_T_BWD, st);
     MXF_STAGE(h, "reverse pass", st);
     if (!het) {
         if (whiten) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Phi and the core's Su part (side stream): the value needs tr(C Phi)
@@ -1079,6 +1100,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_STAGE(h, "core reverse", st);
     hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
+    MXF_T1(h, MXF_T_CALL, st);
     MXF_STAGE(h, "end", st);
     MXF_STAGE_DUMP(h);
     MXF_LAUNCH_CHECK(h);

@@ -24,6 +24,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->flags) (void)hipFree(h->flags);
     if (h->gsync) (void)hipFree(h->gsync);
     if (h->pinv) (void)hipFree(h->pinv);
+    if (h->tm.made) for (int i = 0; i < 2 * MXF_NT; ++i) (void)hipEventDestroy(h->tm.ev[i]);
     if (h->cond_dev) (void)hipFree(h->cond_dev);
     if (h->cond_host) (void)hipHostFree(h->cond_host);
     if (h->bwd_acc) (void)hipFree(h->bwd_acc);
@@ -76,6 +77,27 @@ extern "C" int mxf_svgp_cond_slot(mxf_handle h, int slot, double* last_out, doub
     if (max_out) *max_out = h->cond_host ? *(volatile double*)(h->cond_host + 2 * slot) : 0.0;
     if (last_out) *last_out = h->cond_host ? *(volatile double*)(h->cond_host + 2 * slot + 1) : 0.0;
     if (reset && h->cond_host) { *(volatile double*)(h->cond_host + 2 * slot) = 0.0; *(volatile double*)(h->cond_host + 2 * slot + 1) = 0.0; }
+    return 0;
+}
+
+extern "C" int mxf_svgp_timing(mxf_handle h, int enable) {
+    if (!h) return -1;
+    if (enable && !h->tm.init()) MXF_FAIL(h, -4, "mxf_svgp_timing: cannot create events");
+    h->tm.on = enable != 0;
+    for (int i = 0; i < MXF_NT; ++i) h->tm.used[i] = false;
+    return 0;
+}
+
+extern "C" int mxf_svgp_timing_read(mxf_handle h, double* ms_out) {
+    if (!h || !ms_out) return -1;
+    for (int i = 0; i < MXF_NT; ++i) ms_out[i] = -1.0;
+    if (!h->tm.made) return 0;
+    MXF_HIP(h, hipDeviceSynchronize());
+    for (int i = 0; i < MXF_NT; ++i) {
+        if (!h->tm.used[i]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->tm.ev[2 * i], h->tm.ev[2 * i + 1]) == hipSuccess) ms_out[i] = (double)ms;
+    }
     return 0;
 }
 

@@ -50,8 +50,12 @@ class BatchInferenceLoop(GradLoop):
         self.use_graph = use_graph
         self._gstate = None
 
+    def _make_trainer(self, param_dict, learning_rate, optimizer):
+        """gluon.Trainer seam (batch_loop.py:29-44): the fused HIP optimiser over the flat buffer; CPU tests of the loop swap it."""
+        return _Adam(param_dict, learning_rate, optimizer)
+
     def run(self, infr_executor, data, param_dict, ctx, optimizer='adam', learning_rate=1e-3, max_iter=1000, n_prints=10, verbose=False):
-        trainer = _Adam(param_dict, learning_rate, optimizer)
+        trainer = self._make_trainer(param_dict, learning_rate, optimizer)
         iter_step = max(max_iter // n_prints, 1)
         for i in range(max_iter):
             loss = self.step(infr_executor, data, param_dict)

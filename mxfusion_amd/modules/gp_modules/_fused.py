@@ -82,6 +82,7 @@ class Float32Guard(object):
     LIMIT_WHITENED = 5e6
     HYSTERESIS = 0.25
     enabled = True          # class-wide switch (bench.py --no-f32-guard, tests): False = always the explicit float32 form
+    force = None            # measurements (bench.py --f32-form): every float32 call at this level, whatever its condition number
     default = None
     _instances = None
     _counter = 0
@@ -166,6 +167,9 @@ class Float32Guard(object):
         if not Float32Guard.enabled:
             return self.EXPLICIT
         self.poll(dev)
+        if Float32Guard.force is not None:
+            self._checked_first = True
+            return self.F64 if (Float32Guard.force == self.WHITENED and not whitened_ok) else Float32Guard.force
         if self.tier == self.WHITENED and not whitened_ok:
             return self.F64
         return self.tier

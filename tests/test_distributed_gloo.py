@@ -92,6 +92,73 @@ def test_sharded_samples_allreduce_equals_unsharded():
         assert abs(mean_loss - ref_loss) < 1e-10 * abs(ref_loss)
 
 
+# ---- world 8, 4 samples per rank: what the 8-GPU run of BASELINE.json configs[2] does -------------------------------
+def _problem8():
+    rng = np.random.RandomState(8)
+    N, Q, M, S = 10, 2, 3, 32
+    Y = rng.rand(N, 1)
+    eps = rng.randn(S, N, Q)
+    sizes = dict(qX_mean=(N, Q), qX_var=(N, Q), noise_var=(1,), lengthscale=(Q,), variance=(1,), qU_mean=(M, 1), qU_cov_W=(M, M),
+                 qU_cov_diag=(M,), Z=(M, Q))
+    flat = torch.as_tensor(rng.randn(sum(int(np.prod(s)) for s in sizes.values())) * 0.3, dtype=torch.float64)
+    return Y, eps, sizes, flat
+
+
+def _batch_loop_cls():
+    from mxfusion_amd.inference import DistributedBatchInferenceLoop
+
+    class Loop(DistributedBatchInferenceLoop):
+        def _make_trainer(self, param_dict, learning_rate, optimizer):
+            return _CpuAdam(param_dict, learning_rate)
+    return Loop
+
+
+def _worker8(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    Y, eps, sizes, flat = _problem8()
+    S = eps.shape[0]
+    shard = eps[rank * (S // world):(rank + 1) * (S // world)]          # 4 MC samples per rank
+    params = _Params(flat + (0.25 * rank))                              # replicas must start from rank 0's parameters (the loop broadcasts)
+    loop = _batch_loop_cls()()
+    loop.run(_executor(Y, shard, sizes, params), [None], params, None, learning_rate=0.05, max_iter=3)
+    q.put((rank, params.flat.detach().clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_world_8_four_samples_per_rank_equals_the_32_sample_single_process_run():
+    """DistributedBatchInferenceLoop.run (the PRODUCT loop: broadcast of the start parameters, per-step all-reduce of the flat gradient, optimiser
+    step) with world 8 and 4 MC samples per rank == BatchInferenceLoop.run with all 32 samples in one process: parameters after 3 Adam
+    steps agree to 1e-10 on every rank."""
+    from mxfusion_amd.inference import BatchInferenceLoop
+    Y, eps, sizes, flat = _problem8()
+
+    class Single(BatchInferenceLoop):
+        def _make_trainer(self, param_dict, learning_rate, optimizer):
+            return _CpuAdam(param_dict, learning_rate)
+    params = _Params(flat)
+    Single().run(_executor(Y, eps, sizes, params), [None], params, None, learning_rate=0.05, max_iter=3)
+    ref = params.flat.detach().numpy()
+    assert np.abs(ref - flat.numpy()).max() > 1e-2
+
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in outs) == list(range(world))
+    for rank, got in outs:
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-10), (rank, np.abs(got - ref).max())
+
+
 # ---- minibatches x sample sharding (BASELINE.json configs[3]): the PRODUCT loop (DistributedMinibatchInferenceLoop.run) end to end ------
 class _CpuAdam(object):
     """MXNet Adam on the flat CPU leaf (the product's trainer is the HIP kernel mxf_adam_step; the loop's trainer seam swaps it here)."""
