@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
 // norms (optional): norms[s][row] = sum_q out[s][row][q]^2 (the QT threads of a row are neighbouring lanes)
 template <typename T, int QT, int KIND>
 __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __restrict__ ls, int64_t sls, int ard, int64_t N, int Q,
-                                int64_t pad, T* __restrict__ out, T* __restrict__ norms = nullptr) {
+                                int64_t pad, T* __restrict__ out, T* __restrict__ norms = nullptr, int raw = 0) {
     const int s = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pad * QT) return;
@@ -355,7 +355,7 @@ __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __
     T v = (T)0;
     if (row < N && q < Q) {
         const T l = ls[(int64_t)s * sls + (ard ? q : 0)];
-        const T m = (KIND == MXF_K_LINEAR) ? t_sqrt<T>(l) : coord_scale<T, KIND>() / l;
+        const T m = raw ? (T)1 : ((KIND == MXF_K_LINEAR) ? t_sqrt<T>(l) : coord_scale<T, KIND>() / l);      // raw: the padded copy only
         v = X[(int64_t)s * sX + row * Q + q] * m;
     }
     out[(int64_t)s * pad * QT + i] = v;
@@ -610,12 +610,25 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
 // Measured (tests/probes/planes_lean.sh, planes_store.hip): 1.82 / 1.69 ms for the two 8.6 GB passes of the bench step, the same as the staged
 // kernel -- neither the LDS staging nor the VALU count (16 -> 14 instructions per covariance here) is what bounds them; the store-only twin
 // of the same pattern takes 1.45 - 1.65 ms alone, memset 1.36 ms; PLAIN instead of non-temporal stores: 2.1 - 2.4 ms inside the step.
-template <int QT, int KIND, int PT>
+// ACC (r04): the squared distance as sum_q ((x_q - z_q)^2) (c / l_q)^2 from the RAW coordinates -- difference first, scale after -- instead of
+// the difference of pre-scaled coordinates: the rounding of x / l (2^-24 |x / l|) no longer enters r^2 of NEAR pairs, the ones that carry the
+// covariance.  At length-scale 0.2 on [-2, 2] (a deep GP's hidden layer) the pre-scaled form's Gram error, amplified by |T| ~ sqrt(cond) in
+// q_n = k_n . T_n, was 2/3 of the whitened tier's ELBO error (3.9e-5 -> 4e-6 relative; tests/test_gpu_f32_guard.py two-layer case).
+// One more packed multiply per two coordinates.
+template <int QT, int KIND, int PT, bool ACC = false>
 __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                               const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
                                                               int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
-                                                              int64_t ldU) {
+                                                              int64_t ldU, const float* __restrict__ ls = nullptr, int ard = 0, int Q = 0) {
     const int lane = threadIdx.x;
+    float s2[QT];
+    if constexpr (ACC) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const float m = q < Q ? coord_scale<float, KIND>() / ls[ard ? q : 0] : 0.f;      // wave-uniform: scalar loads
+            s2[q] = m * m;
+        }
+    }
     const int64_t r0 = (int64_t)blockIdx.x * 64, r = r0 + lane;
     float z[QT];
 #pragma unroll
@@ -647,7 +660,8 @@ __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t
                     const f32x2 xx = {xk[nl * QT + q], xk[nl * QT + q + 1]};
                     const f32x2 zz = {z[q], z[q + 1]};
                     const f32x2 d = xx - zz;
-                    acc2 = __builtin_elementwise_fma(d, d, acc2);
+                    if constexpr (ACC) { const f32x2 ss = {s2[q], s2[q + 1]}; acc2 = __builtin_elementwise_fma(d * d, ss, acc2); }
+                    else acc2 = __builtin_elementwise_fma(d, d, acc2);
                 }
                 const float red = acc2.x + acc2.y;
                 const float kv = (FULL || kb * 16 + nl < Kn) ? cov_from<float, KIND>(red, 16384.f) : 0.f;
@@ -720,16 +734,23 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     //  mapping below writes whole lines per instruction)
     // r03: the one-wave form for the f16x2 planes (probe builds: MXF_PLANES_LEAN=0 selects the staged kernel)
     const bool lean = mode == MXF_SPLIT_F16X2 && MXF_KNOB("MXF_PLANES_LEAN", 1) != 0;
+    const int raw = (lean && MXF_KNOB("MXF_PLANES_ACC", 1) != 0) ? 1 : 0;       // difference-then-scale distances (gram_planes_lean_kernel ACC)
     int kbpb = fuse_u ? (int)K16 : (int)MXF_KNOB("MXF_PLANES_KB", 8);
     while (!fuse_u && (K16 + kbpb - 1) / kbpb > 65535) kbpb *= 2;
     dim3 lgrid((unsigned)((R + 63) / 64), (unsigned)((K16 + kbpb - 1) / kbpb));
 #define GO(QTV)                                                                                                                       \
     do {                                                                                                                              \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padr * QTV + 255) / 256), 1), dim3(256), 0, st, Xmin, (int64_t)0, ls, \
-                           (int64_t)0, ard, R, Q, padr, buf);                                                                         \
+                           (int64_t)0, ard, R, Q, padr, buf, (float*)nullptr, raw);                                                   \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
-                           (int64_t)0, ard, Kn, Q, padk, bmaj);                                                                       \
-        if (lean && fuse_u && Pw == 1)                                                                                         \
+                           (int64_t)0, ard, Kn, Q, padk, bmaj, (float*)nullptr, raw);                                                 \
+        if (lean && raw && fuse_u && Pw == 1)                                                                                         \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+        else if (lean && raw && fuse_u)                                                                                               \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+        else if (lean && raw)                                                                                                         \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+        else if (lean && fuse_u && Pw == 1)                                                                                           \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
         else if (lean && fuse_u)                                                                                                      \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
