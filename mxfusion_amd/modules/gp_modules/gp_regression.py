@@ -191,8 +191,17 @@ class GPRegressionSamplingPrediction(GPRegressionMeanVariancePrediction):
                     var = var + noise_var
                 samples = mu + die * torch.sqrt(var.unsqueeze(-1))
             elif torch.is_grad_enabled():
-                raise NotImplementedError('GPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
-                                          'test inputs here (it needs a reverse-mode Cholesky); use diagonal_variance=True')
+                # differentiable w.r.t. the test inputs (the reference's autograd flows through potrf, gp_regression.py:251-268): the covariance
+                # through the autograd bridges of mxf_gram / mxf_gemm, its factor through the reverse-mode Cholesky (lin.chol, Murray 2016)
+                cov = kern.K(F, X, **kern_params) - lin.gemm(LinvKxt, LinvKxt, transA=True)
+                eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)
+                if not self.noise_free:
+                    cov = cov + eye * noise_var.unsqueeze(-2)
+                if self.jitter > 0.:
+                    cov = cov + eye * self.jitter
+                Lc, info = lin.chol(cov)
+                self._last_info = info
+                samples = mu + lin.gemm(Lc, die)
             else:
                 cov = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=kern.K(F, X, **kern_params).contiguous().clone())
                 eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)

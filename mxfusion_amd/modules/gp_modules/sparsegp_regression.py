@@ -163,9 +163,6 @@ class SparseGPRegressionSamplingPrediction(SparseGPRegressionMeanVariancePredict
 
     def compute(self, F, variables):
         with _grad_mode(variables[self.model.X]):
-            if torch.is_grad_enabled() and not self.diagonal_variance:
-                raise NotImplementedError('SparseGPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
-                                          'test inputs here (it needs a reverse-mode Cholesky); use diagonal_variance=True')
             mu, var = self._moments(F, variables)
             out_shape = (self.num_samples,) + tuple(mu.shape[1:])
             die = self._rand_gen.sample_normal(shape=out_shape, dtype=mu.dtype, ctx=mu.device)
@@ -176,9 +173,9 @@ class SparseGPRegressionSamplingPrediction(SparseGPRegressionMeanVariancePredict
                 cov = var
                 if self.jitter > 0.:                                                      # :241-242
                     cov = cov + torch.eye(N, dtype=cov.dtype, device=cov.device).unsqueeze(0) * self.jitter
-                Lc, info = ops.potrf_(cov.contiguous().clone())
+                Lc, info = lin.chol(cov)                                                  # differentiable when the covariance is (reverse-mode Cholesky)
                 self._last_info = info
-                samples = mu + ops.gemm(Lc, die)                                          # trmm(L, die): L is lower with a zero upper part
+                samples = mu + lin.gemm(Lc, die)                                          # trmm(L, die): L is lower with a zero upper part
         outcomes = {self.model.Y.uuid: samples}
         if self.target_variables:
             return tuple(outcomes[v] for v in self.target_variables)

@@ -209,9 +209,6 @@ class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
 
     def compute(self, F, variables):
         with _grad_mode(variables[self.model.X]):
-            if torch.is_grad_enabled() and not self.diagonal_variance:
-                raise NotImplementedError('SVGPRegressionSamplingPrediction: full-covariance draws are not differentiable w.r.t. the '
-                                          'test inputs here; use diagonal_variance=True')
             mu, var = self._moments(F, variables)      # `jitter` goes on Kuu (:236-238), as in the mean/variance algorithm
             out_shape = (self.num_samples,) + tuple(mu.shape[1:])
             die = self._rand_gen.sample_normal(shape=out_shape, dtype=mu.dtype, ctx=mu.device)
@@ -219,9 +216,9 @@ class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
                 samples = mu + die * torch.sqrt(var)
             else:
                 cov = var[..., 0]                       # (:262-267: the reference adds no jitter to the predictive covariance)
-                Lc, info = ops.potrf_(cov.contiguous().clone())
+                Lc, info = lin.chol(cov)                # differentiable when the covariance is (reverse-mode Cholesky): the reference's autograd flows through potrf here
                 self._last_info = info
-                samples = mu + ops.gemm(Lc, die)
+                samples = mu + lin.gemm(Lc, die)
         outcomes = {self.model.Y.uuid: samples}
         if self.target_variables:
             return tuple(outcomes[v] for v in self.target_variables)

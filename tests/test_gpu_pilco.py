@@ -180,3 +180,78 @@ def test_prediction_gradient_wrt_test_inputs(module):
     assert np.allclose(v.detach().cpu().numpy(), vr.detach().numpy().reshape(v.shape), rtol=1e-7, atol=1e-10)
     ((mr * O.T(w1)).sum() + (vr.reshape(w2.shape) * O.T(w2)).sum()).backward()
     assert np.allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize('module', ['gp', 'svgp', 'sgp'])
+def test_full_covariance_sampling_prediction_is_differentiable_wrt_test_inputs(module):
+    """mu + chol(cov + jitter I) eps with injected eps, differentiated w.r.t. the test inputs (the reference's autograd flows through
+    linalg.potrf there: gp_regression.py:251-268, svgp_regression.py:262-272, sparsegp_regression.py:236-249) == autograd through the oracle.
+    r03 raised NotImplementedError here (VERDICT r03 'missing' 6); the factor's reverse mode is lin.CholFn (Murray 2016)."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.modules.gp_modules import GPRegression, SVGPRegression, SparseGPRegression
+    from mxfusion_amd.modules.gp_modules.gp_regression import GPRegressionSamplingPrediction
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionSamplingPrediction
+    from mxfusion_amd.modules.gp_modules.sparsegp_regression import SparseGPRegressionSamplingPrediction
+    from mxfusion_amd.inference import GradBasedInference, MAP, TransferInference, SamplingAlgorithm
+    rng = np.random.RandomState(5)
+    X, Y = _data(rng, N=30)
+    Q, P, Mi = X.shape[1], Y.shape[1], 7
+    Z = X[rng.permutation(30)[:Mi]] + 0.01 * rng.randn(Mi, Q)
+    ls, var, noise = rng.rand(Q) + 0.5, np.array([1.3]), np.array([0.05])
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t(noise))
+    kern = RBF(input_dim=Q, ARD=True, variance=_t(var), lengthscale=_t(ls), dtype=DT)
+    ok = O.RBF(Q, ARD=True)
+    kp = {'rbf_lengthscale': O.T(ls)[None], 'rbf_variance': O.T(var)[None]}
+    if module == 'gp':
+        m.Y = GPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, shape=(m.N, P), dtype=DT)
+    else:
+        m.Z = Variable(shape=(Mi, Q), initial_value=_t(Z))
+        cls = SVGPRegression if module == 'svgp' else SparseGPRegression
+        m.Y = cls.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, P), dtype=DT)
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=1e-12)
+    gp = m.Y.factor
+    S, Nt, jit = 3, 5, 1e-6
+    Xt = rng.rand(1, Nt, Q)
+    eps = rng.randn(S, Nt, P)
+    xt = _t(Xt).requires_grad_(True)
+    acls, aname = {'gp': (GPRegressionSamplingPrediction, 'gp_predict'), 'svgp': (SVGPRegressionSamplingPrediction, 'svgp_predict'),
+                   'sgp': (SparseGPRegressionSamplingPrediction, 'sgp_predict')}[module]
+    alg = acls(gp._module_graph, gp._extra_graphs[0], [gp._module_graph.X], rand_gen=MockRandomGenerator(_t(eps)), noise_free=False,
+               diagonal_variance=False, jitter=jit)
+    gp.attach_prediction_algorithms(targets=gp.output_names, conditionals=gp.input_names, algorithm=alg, alg_name=aname)
+
+    class _Predict(SamplingAlgorithm):
+        def compute(self, F, variables):
+            variables[self.model.X] = xt
+            return self.model.Y.factor.predict(F, variables, targets=[self.model.Y], num_samples=S)[0]
+
+    tr = TransferInference(_Predict(model=m, observed=[m.X]), infr_params=infr.params, dtype=DT)
+    tr.initialize(X=_t(X))
+    ys = tr.create_executor()(_t(X))
+    ys = ys[0] if isinstance(ys, (tuple, list)) else ys
+    w = rng.randn(S, Nt, P)
+    (ys * _t(w)).sum().backward()
+    xr = O.T(Xt).clone().requires_grad_(True)
+    nz = O.T(noise)[None]
+    if module == 'gp':
+        post = O.gp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], nz, kp, return_posterior=True)[1]
+        ref = O.gp_predict_sample(ok, xr, nz, post[0][None], post[1][None], post[2][None], kp, O.T(eps), noise_free=False, diagonal_variance=False, jitter=jit)
+    elif module == 'svgp':
+        post = gp._extra_graphs[0]
+        qm, qW, qd = (infr.params[post.qU_mean].double().cpu(), infr.params[post.qU_cov_W].double().cpu(), infr.params[post.qU_cov_diag].double().cpu())
+        ref = O.svgp_predict_sample(ok, xr, O.T(Z)[None], nz, qm[None], qW[None], qd[None], kp, O.T(eps), jitter=jit, noise_free=False, diagonal_variance=False)
+    else:
+        post = O.sgp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], O.T(Z)[None], nz, kp, return_posterior=True)[1]
+        ref = O.sgp_predict_sample(ok, xr, O.T(Z)[None], nz, post[1][None], post[2][None], post[0][None], kp, O.T(eps), noise_free=False,
+                                   diagonal_variance=False, jitter=jit)
+    assert np.allclose(ys.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-7, atol=1e-9)
+    (ref * O.T(w)).sum().backward()
+    assert np.abs(xr.grad.numpy()).max() > 1e-3
+    assert np.allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-8)
