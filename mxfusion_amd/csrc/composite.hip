@@ -816,21 +816,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // acc = (s_L L^-1) (Kfu / sigma^2 2^14)^T  ->  acc sigma / s_L.  L^-1 is lower triangular: a row tile's k loop stops at its last row.
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
         MXF_T0(h, MXF_T_VGEMM, sd_);
-        rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, 0, split_mode, sigf, 1,
+        // (few samples per GPU: the Kuu chain on the caller's stream is the critical path -- both side-stream products leave it 40 CUs)
+        const bool few = SB <= 2 * 192 * M;
+        rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, few ? 40 : 0, split_mode, sigf, 1,
                                      (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1);
         if (rc) return rc;
         MXF_T1(h, MXF_T_VGEMM, sd_);
-        MXF_HIP(h, hipEventRecord(h->ev_v, sd_));                                                     // V planes ready
         MXF_STAGE(h, "V = Linv Kuf (sd)", sd_);
-        // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T follows at once on this stream; the transposition of V (HBM
-        // bound) runs NEXT TO it on the second side stream
-        MXF_T0(h, MXF_T_PSI2, sd_);
-        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                     psi2_rb, split_mode, split_var, 1, nullptr);
-        if (rc) return rc;
-        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
-        MXF_T1(h, MXF_T_PSI2, sd_);
-        MXF_STAGE(h, "Phi (sd)", sd_);
     }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
@@ -847,6 +839,33 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_STAGE(h, "Ki, w", st);
     if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w (and a) ready: the Kfu planes + U pass / the transposition + U pass may start
+    if (whiten) {
+        // side stream: V planes -> planes of the (n, k = m) operand (into the Kfu planes' slot: V = L^-1 Kuf has consumed them) and, for one
+        // output column, U = a^T V in the same pass; P > 1: U from the transposed planes (one more read of them).  The T product waits for
+        // this pass, so it comes BEFORE Phi (r04: next to Phi on another stream it took 2.7x as long and the step did not move at 32
+        // samples, +0.1 ms at 4).
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
+        MXF_T0(h, MXF_T_PLANES_B, sd_);
+        rc = mxf_planes_transpose_internal(h, M, SB, plKuf, (int64_t)pl_big, plKfu, (int64_t)pl_big, (const float*)aT, sigf, 1.f / 16384.f,
+                                           P == 1 ? (float*)(Text + M * SB) : nullptr, sd_);
+        if (rc) return rc;
+        if (P > 1) {
+            hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plKfu,
+                               (int64_t)pl_big, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
+        }
+        MXF_T1(h, MXF_T_PLANES_B, sd_);
+        MXF_STAGE(h, "V^T planes + U (sd)", sd_);
+        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
+        // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T: next to the T product
+        const bool few = SB <= 2 * 192 * M;
+        MXF_T0(h, MXF_T_PSI2, sd_);
+        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                     few ? 202 : psi2_rb, split_mode, split_var, 1, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_T1(h, MXF_T_PSI2, sd_);
+        MXF_STAGE(h, "Phi (sd)", sd_);
+    }
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
@@ -866,23 +885,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_STAGE(h, "Su^-1 (s2)", s2_);
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
-    if (whiten) {
-        // second side stream, behind the Su chain: V planes -> planes of the (n, k = m) operand (into the Kfu planes' slot: V = L^-1 Kuf has
-        // consumed them) and, for one output column, U = a^T V in the same pass; P > 1: U from the transposed planes (one more read of them)
-        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_v, 0));
-        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));                                            // a = L^-1 mu
-        MXF_T0(h, MXF_T_PLANES_B, s2_);
-        rc = mxf_planes_transpose_internal(h, M, SB, plKuf, (int64_t)pl_big, plKfu, (int64_t)pl_big, (const float*)aT, sigf, 1.f / 16384.f,
-                                           P == 1 ? (float*)(Text + M * SB) : nullptr, s2_);
-        if (rc) return rc;
-        if (P > 1) {
-            hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, s2_, M, SB, P, (const unsigned short*)plKfu,
-                               (int64_t)pl_big, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
-        }
-        MXF_T1(h, MXF_T_PLANES_B, s2_);
-        MXF_STAGE(h, "V^T planes + U (s2)", s2_);
-        MXF_HIP(h, hipEventRecord(h->ev_aux, s2_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
-    }
     if (use_split && !whiten) {
         // Kfu planes (operand (n, k = m) of the T GEMM) + the row U = w^T Kuf in ONE pass, behind the Su chain on the second side stream:
         // HBM-write bound.  (r03, tests/probes/svgp_stages.py: the pass starts when w = Kuu^-1 mu exists, and the Kuu chain -- potrf, trtri,

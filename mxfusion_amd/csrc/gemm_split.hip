@@ -855,7 +855,8 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         g.maxout = (splitk == 1 && beta == 0.0 && !lower_only) ? maxout : nullptr;       // (other paths leave the word as it is: the caller sees 0)
         // persistent: as many workgroups as fit the chip (the kernel's occupancy) walk the work items; fewer items than that: one each
         static const int64_t wide_grid_env = MXF_KNOB("MXF_SPLIT_WIDE_GRID", 0);
-        const int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? 256 : 512);
+        // (planes-output products honour reserve_cus: a caller that runs a latency-bound chain next to this product leaves it some CUs)
+        const int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? (Cplanes ? (256 - reserve_cus) / 8 * 8 : 256) : (Cplanes ? (256 - reserve_cus) / 8 * 8 * 2 : 512));
         const int64_t grid = (wide_grid >= 8 && g.nwg > wide_grid) ? wide_grid / 8 * 8 : g.nwg;
         // rendezvous groups (wg_rendezvous): MXF_SPLIT_SYNC 0 = none; 1 = the row tiles of one column strip (full products) / the tiles of
         // one k split (split-K products); 2 = full products: all workgroups of an XCD, once per work item

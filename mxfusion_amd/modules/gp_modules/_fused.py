@@ -126,7 +126,8 @@ class Float32Guard(object):
         return {'kuu_cond_max': max([g.cond_max for g in gs] or [0.0]),
                 'float32_fallback_active': any(g.tier == cls.F64 for g in gs),
                 'float32_whitened_active': any(g.tier == cls.WHITENED for g in gs),
-                'float32_tiers': {('%s#%d' % (g.name, g.slot)): cls.NAMES[g.tier] for g in gs},
+                'float32_tiers': {('%s#%d' % (g.name, g.slot)): cls.NAMES[g.tier if cls.force is None else cls.force] + ('' if cls.force is None else ' (forced)')
+                                  for g in gs},
                 'float32_guard': bool(cls.enabled)}
 
     # ---- per owner -------------------------------------------------------------------------------------------------------------------
