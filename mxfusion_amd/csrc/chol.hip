@@ -927,6 +927,11 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     };
     for (int64_t c0 = 0; c0 < n; c0 += NBO) {
         const int64_t pe = (c0 + NBO < n) ? c0 + NBO : n;   // panel end
+        //  the auxiliary stream's head update of THIS panel's rows-below is consumed here unconditionally, whatever form the
+        // panel takes: the dependency must not hinge on is_split() implying the tile path.  In the split tile form the wait is deferred to
+        // just in front of the rows kernel (the chain launch reads the diagonal block only) -- `defer` below.
+        const bool defer_h = pending_h && sizeof(T) == 8 && panel_tiles && is_split(c0);
+        if (pending_h && !defer_h) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0)); pending_h = false; }
         if constexpr (sizeof(T) == 8) {
             if (panel_tiles) {       // the whole outer panel in ONE launch (8 dependent panel steps + 7 left-looking GEMMs before)
                 const unsigned nbr = (unsigned)((n - c0) / NB), npt = (unsigned)((pe - c0) / NB);
@@ -1004,6 +1009,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         }
     }
     if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
+    if (pending_h) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0));      // (never pending here today: the last panel has no successor; kept so that the caller's stream always joins the auxiliary one)
     if (n > 1 && zero_upper) {      // (internal callers that only ever read the lower triangle skip this pass)
         if (n > 65535) MXF_FAIL(h, -3, "mxf_potrf: n too large");
         hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);

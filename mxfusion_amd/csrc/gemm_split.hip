@@ -394,7 +394,10 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // tile: 2 of its 8 waves) runs a k loop WITHOUT its B loads and MFMAs -- it still fetches its share of the A slab and keeps every barrier.
 // (A branch around the MFMAs inside the one loop cost the kernel its schedule, see below; here the loop exists twice and the idle form is a
 //  separate instantiation, so the T product's kernel is untouched.)  The busiest SIMDs still carry two working waves: the gain is power.
-template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false, bool CPL = false>
+// BFI (probe builds only, MXF_SPLIT_BF16MFMA=1): the SAME kernel with v_mfma_f32_32x32x16_bf16 on the same bits -- the numbers mean nothing,
+// the time does: it separates the operand FORMAT (11-bit f16 mantissas vs 8-bit bf16 ones toggling the multiplier array; the guide's MFMA
+// microbenchmark gives 2178 vs 2382 TF) from the schedule when this kernel is compared with the guide's bf16 GEMM template.
+template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false, bool CPL = false, bool BFI = false>
 __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
     static_assert(!LSKIP || (!PP && BLO), "the idle-wave loop mirrors the plain pipelined loop");
@@ -499,6 +502,8 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         asm volatile("" ::: "memory");                                                                                              \
     } while (0)
 #define HF(v) __builtin_bit_cast(f16x8, v)
+#define WMMA(a, b, c) (BFI ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0) \
+                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(a), HF(b), c, 0, 0, 0))
 #define W_COMPUTE(SLOT, BR)                                                                                                         \
     do {                                                                                                                            \
         u32x4 a_[XT][2];                                                                                                            \
@@ -509,15 +514,15 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     do {                                                                                                                            \
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
-                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][1]), c[x][y], 0, 0, 0);      /* hi' lo */   \
+                c[x][y] = WMMA(BR[y][0], a_[x][1], c[x][y]);                                                         /* hi' lo */   \
         if constexpr (BLO) {                                                                                                        \
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
-                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][1]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* lo' hi */   \
+                c[x][y] = WMMA(BR[y][1], a_[x][0], c[x][y]);                                                         /* lo' hi */   \
         }                                                                                                                           \
         _Pragma("unroll") for (int x = 0; x < XT; ++x)                                                                              \
             _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                           \
-                c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(BR[y][0]), HF(a_[x][0]), c[x][y], 0, 0, 0);      /* hi' hi */   \
+                c[x][y] = WMMA(BR[y][0], a_[x][0], c[x][y]);                                                         /* hi' hi */   \
     } while (0)
     // one k block `kk`: ring slot SLOT / registers BR hold it; block kk + 2 (clamped to the last block: the loop is branch-free, the
     // surplus requests of the last two steps re-read the last block and are never used) is requested into SLOT2 / BR2 -- free since the
@@ -646,6 +651,7 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
 #undef W_STEP_PP
 #undef W_PHASE_END
 #undef W_MFMAS
+#undef WMMA
 #undef HF
 #undef W_WAIT1
 #undef W_WAIT0
@@ -736,6 +742,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256lo(SplitArgs g) { wide_body<4, 2, false, true, true>(g); }
+#ifdef MXF_PROBES
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256bf(SplitArgs g) { wide_body<4, 2, false, true, false, false, true>(g); }
+#endif
 // planes-output forms (c_blk == 2; the whitened SVGP tier's V = L^-1 Kuf)
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pl(SplitArgs g) { wide_body<4, 2, false, true, false, true>(g); }
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128pl(SplitArgs g) { wide_body<4, 1, false, true, false, true>(g); }
@@ -887,6 +896,10 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         static const int pp_env = (int)MXF_KNOB("MXF_SPLIT_PP", 0);        // ping-pong phases of the two row halves (NH = 2)
         static const int lskip_env = (int)MXF_KNOB("MXF_SPLIT_LSKIP", 1);  // lower-only products: the waves above the diagonal idle (see wide_body)
         static const int bhi_env = (int)MXF_KNOB("MXF_SPLIT_BHI", 0);      // experiment: B through its high plane only, blocked-output products
+#ifdef MXF_PROBES
+        static const int bfi_env = (int)MXF_KNOB("MXF_SPLIT_BF16MFMA", 0);
+        if (bfi_env && NH == 2 && !Cplanes && !lower_only) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256bf, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
+#endif
         if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (Cplanes) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128pl, dim3((unsigned)grid), dim3(256), 0, st, g);
         else if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);

@@ -13,15 +13,29 @@ from collections import defaultdict
 
 def main(pattern, out, dirs):
     per = defaultdict(lambda: defaultdict(float))         # counter -> dispatch id -> value
+    dur = {}                                              # dispatch -> duration (ns), from the pass's own timestamps
     for d in dirs:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
                 if pattern in r['Kernel_Name']:
                     per[r['Counter_Name']][(f, r['Dispatch_Id'])] += float(r['Counter_Value'])
+                    if r.get('Start_Timestamp') and r.get('End_Timestamp'):
+                        dur[(f, r['Dispatch_Id'])] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
     res = {}
     for c, vals in per.items():
         v = list(vals.values())
         res[c] = {'mean': sum(v) / len(v), 'min': min(v), 'max': max(v), 'n': len(v)}
+    if 'GRBM_GUI_ACTIVE' in per:
+        # clock the kernel really ran at: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration of the same dispatch (the counter pass
+        # serialises kernels, so the duration is that of the kernel alone); matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GUI / 8)
+        ck = [v / 8.0 / dur[k] for k, v in per['GRBM_GUI_ACTIVE'].items() if k in dur and dur[k] > 0]
+        if ck:
+            res['clock_GHz'] = sum(ck) / len(ck)
+            res['duration_ms_in_pmc_pass'] = sum(dur[k] for k in per['GRBM_GUI_ACTIVE'] if k in dur) / len(ck) / 1e6
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in per:
+            bz = [per['SQ_VALU_MFMA_BUSY_CYCLES'][k] / 1024.0 / (v / 8.0) for k, v in per['GRBM_GUI_ACTIVE'].items() if k in per['SQ_VALU_MFMA_BUSY_CYCLES'] and v > 0]
+            if bz:
+                res['mfma_busy_frac'] = sum(bz) / len(bz)
     if 'WRITE_SIZE' in res and 'FETCH_SIZE' in res:
         res['hbm_traffic_bytes_per_launch'] = res['WRITE_SIZE']['mean'] * 1024 + 2 * res['FETCH_SIZE']['mean'] * 1024
     res['_kernel'] = pattern
