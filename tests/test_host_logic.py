@@ -149,3 +149,80 @@ def test_grad_transfer_parameters_fixed_model_trainable_policy_on_cpu():
     assert torch.allclose(policy.weight.detach(), w0 - 1.0)                                # ... is a step on the module's tensors
     p.zero_grad()
     assert float(p.flat.grad.abs().sum()) == 0 and policy.weight.grad.data_ptr() == p.flat.grad.data_ptr()
+
+
+# ---- the float32 guard's level logic (modules/gp_modules/_fused.py), with the library's condition slots replaced by a dict -----------------
+class _FakeSlots(object):
+    def __init__(self, monkeypatch):
+        from mxfusion_amd import _lib, ops
+        self.slots, self.last_cond, self.configured = {}, 0.0, []
+        monkeypatch.setattr(ops, '_device_index', lambda dev: 0)
+        monkeypatch.setattr(ops, 'svgp_last_cond', lambda dev=None: self.last_cond)
+        monkeypatch.setattr(_lib, 'svgp_configure', lambda dev, form, slot: self.configured.append((form, slot)))
+
+        def cond_slot(dev, slot, reset=False):
+            v = self.slots.get(slot, (0.0, 0.0))
+            if reset:
+                self.slots[slot] = (0.0, 0.0)
+            return v
+        monkeypatch.setattr(_lib, 'svgp_cond_slot', cond_slot)
+
+    def publish(self, guard, cond):           # what a finished call's last launch does
+        last, mx = self.slots.get(guard.slot, (0.0, 0.0))
+        self.slots[guard.slot] = (cond, max(mx, cond))
+        self.last_cond = cond
+
+
+def test_float32_guard_levels_first_call_and_hysteresis(monkeypatch):
+    import warnings
+    from mxfusion_amd import _lib
+    from mxfusion_amd.modules.gp_modules import _fused
+    G = _fused.Float32Guard
+    fake = _FakeSlots(monkeypatch)
+    g = G('unit')
+    ran = []
+
+    def call(cond, whitened_ok=True, is_f32=True):
+        def run(tier):
+            ran.append(tier)
+            fake.publish(g, cond)
+            return tier
+        return _fused._guarded(g, 'cuda', is_f32, whitened_ok, run)
+
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        # first call, ill-conditioned: runs explicit, the synchronous check re-runs it whitened
+        assert call(1e5) == G.WHITENED and ran == [G.EXPLICIT, G.WHITENED] and g.tier == G.WHITENED
+        assert fake.configured[-1] == (_lib.FORM_WHITENED, g.slot) and len(w) == 1
+        # further calls poll the slot (no synchronous check any more); a call the whitened form does not cover runs float64 without moving the owner
+        assert call(1e5) == G.WHITENED
+        assert call(1e5, whitened_ok=False) == G.F64 and g.tier == G.WHITENED
+        # beyond the whitened range: the call AFTER the one that published it moves up
+        assert call(1e8) == G.WHITENED
+        assert call(1e8) == G.F64 and g.tier == G.F64
+        # down only below a quarter of a limit, one level set at a time by what was published
+        assert call(0.5 * G.LIMIT_WHITENED) == G.F64            # (published 1e8 before this poll)
+        assert call(0.5 * G.LIMIT_WHITENED) == G.F64            # 2.5e6 > 0.25 * 5e6: stays
+        assert call(0.2 * G.LIMIT_WHITENED) == G.F64
+        assert call(0.2 * G.LIMIT_WHITENED) == G.WHITENED       # 1e6 < 1.25e6: whitened again
+        assert call(10.0) == G.WHITENED
+        assert call(10.0) == G.EXPLICIT
+        assert g.cond_max == 1e8 and g.switches == 4
+    # float64 inputs: the form is irrelevant, the slot is still configured; a disabled guard never leaves the explicit form
+    n = len(ran)
+    assert call(1e9, is_f32=False) == G.EXPLICIT and len(ran) == n + 1
+    monkeypatch.setattr(G, 'enabled', False)
+    g2 = G('off')
+    fake.last_cond = 1e9
+    assert _fused._guarded(g2, 'cuda', True, True, lambda t: t) == G.EXPLICIT and g2.tier == G.EXPLICIT
+    monkeypatch.setattr(G, 'enabled', True)
+    # a forced level (bench.py --f32-form)
+    monkeypatch.setattr(G, 'force', G.WHITENED)
+    g3 = G('forced')
+    assert _fused._guarded(g3, 'cuda', True, True, lambda t: t) == G.WHITENED
+    assert _fused._guarded(g3, 'cuda', True, False, lambda t: t) == G.F64
+    monkeypatch.setattr(G, 'force', None)
+    # two owners never share a slot while fewer than 63 exist, and the report names each
+    assert g.slot != g2.slot != g3.slot
+    rep = G.report()
+    assert rep['kuu_cond_max'] >= 1e8 and any('unit' in k for k in rep['float32_tiers'])
