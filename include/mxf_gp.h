@@ -139,6 +139,17 @@ int mxf_gram(mxf_handle h, int kind, int dtype, int S, int64_t N, int64_t N2, in
              const void* diag_add, int64_t strideS_diag, double jitter, int mode,
              void* K_out, int64_t ldk, int64_t strideS_K, void* stream);
 
+/* K = k1(X, X2) + k2(X, X2) (op = MXF_ACC_ADD) or k1 * k2 (MXF_ACC_MUL) for TWO stationary kernels on the same inputs in ONE pass and ONE
+ * write: AddKernel / MultiplyKernel._compute_K (kernels/add_kernel.py:44-68, multiply_kernel.py:44-67), which in the reference materialise
+ * every sub-kernel's Gram and combine them (three N x N2 passes for two kernels).  Both covariances are formed from the same coordinate
+ * differences (difference first, each kernel's length-scales after).  Arguments as mxf_gram, one (kind, lengthscale, ard, variance) set per
+ * kernel; diag_add / jitter on the diagonal of a square Gram; Q <= 16.  Its reverse mode is mxf_gram_bwd per sub-kernel (ADD: with dK;
+ * MUL: with dK * the other kernel's Gram).                                                                                              */
+int mxf_gram2(mxf_handle h, int kind1, int kind2, int op, int dtype, int S, int64_t N, int64_t N2, int Q, const void* X, int64_t strideS_X,
+              const void* X2, int64_t strideS_X2, const void* lengthscale1, int ard1, int64_t strideS_ls1, const void* variance1,
+              int64_t strideS_var1, const void* lengthscale2, int ard2, int64_t strideS_ls2, const void* variance2, int64_t strideS_var2,
+              const void* diag_add, int64_t strideS_diag, double jitter, void* K_out, int64_t ldk, int64_t strideS_K, void* stream);
+
 /* Reverse mode of mxf_gram for the stationary kinds (what MXNet autograd does through
  * stationary.py:92-106 + rbf.py:71-72 / matern.py): given dK (S,N,N2) accumulates
  *   dX (S,N,Q), dX2 (S,N2,Q) [NULL when X2==NULL: both roles flow into dX], dls (S, Q|1), dvar (S,1).

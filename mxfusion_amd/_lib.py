@@ -18,6 +18,8 @@ _vp, _i, _i64, _d = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double
 SIGNATURES = {
     'mxf_gram': [_i, _i, _i, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i64, _d, _i,
                  _vp, _i64, _i64, _vp],
+    'mxf_gram2': [_i, _i, _i, _i, _i, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i64, _d,
+                  _vp, _i64, _i64, _vp],
     'mxf_gram_bwd': [_i, _i, _i, _i64, _i64, _i, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _i64, _i64,
                      _vp, _vp, _vp, _vp, _vp],
     'mxf_gemm': [_i, _i, _i, _i64, _i64, _i64, _d, _vp, _i64, _i64, _vp, _i64, _i64, _d, _vp, _i64, _i64, _i, _vp],

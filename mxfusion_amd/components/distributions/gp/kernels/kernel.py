@@ -32,6 +32,39 @@ class _GramFn(torch.autograd.Function):
         return None, None, dX, dX2, dls, dvar
 
 
+class _Gram2Fn(torch.autograd.Function):
+    """k1 + k2 or k1 * k2 of two stationary kernels in ONE forward pass (mxf_gram2); the reverse mode is mxf_gram_bwd per sub-kernel --
+    with dK for a sum, with dK times the other kernel's Gram (recomputed: one mxf_gram each) for a product."""
+
+    @staticmethod
+    def forward(ctx, spec, X, X2, ls1, var1, ls2, var2):
+        ctx.spec = spec                               # (kind1, ard1, kind2, ard2, op)
+        ctx.save_for_backward(X, X2, ls1, var1, ls2, var2)
+        k1, a1, k2, a2, op = spec
+        return ops.gram2(k1, k2, op, X, X2, ls1, var1, a1, ls2, var2, a2)
+
+    @staticmethod
+    def backward(ctx, dK):
+        X, X2, ls1, var1, ls2, var2 = ctx.saved_tensors
+        k1, a1, k2, a2, op = ctx.spec
+        dK = dK.contiguous()
+        need = []
+        if ctx.needs_input_grad[1]:
+            need.append('X')
+        if X2 is not None and ctx.needs_input_grad[2]:
+            need.append('X2')
+        out = [None, None]          # dX, dX2
+        grads = []
+        for (kind, ard, ls, var, other, gi) in ((k1, a1, ls1, var1, (k2, a2, ls2, var2), 3), (k2, a2, ls2, var2, (k1, a1, ls1, var1), 5)):
+            nd = list(need) + (['ls'] if ctx.needs_input_grad[gi] else []) + (['var'] if ctx.needs_input_grad[gi + 1] else [])
+            dKi = dK if op == ops.ACC_ADD else dK * ops.gram(other[0], X, X2, other[2], other[3], other[1])
+            dX, dX2, dls, dvar = ops.gram_bwd(kind, X, X2, ls, var, ard, dKi, need=nd)
+            out[0] = dX if out[0] is None else (out[0] if dX is None else out[0] + dX)
+            out[1] = dX2 if out[1] is None else (out[1] if dX2 is None else out[1] + dX2)
+            grads += [dls, dvar]
+        return (None, out[0], out[1]) + tuple(grads)
+
+
 class Kernel(object):
     def __init__(self, input_dim, name, active_dims=None, dtype=None, ctx=None):
         self.input_dim = input_dim
@@ -126,6 +159,21 @@ class CombinationKernel(Kernel):
     def parameter_names(self):
         return list(self.parameters)
 
+    def _fused_pair(self, X, X2, params, op):
+        """Two stationary sub-kernels on the same active dimensions (the deep-GP config's Matern52 + RBF): ONE Gram pass with a two-kernel
+        epilogue (mxf_gram2) instead of one materialised Gram per sub-kernel plus the combining pass.  None when the pair does not qualify."""
+        ks = self.sub_kernels
+        if len(ks) != 2 or not X.is_cuda or any(getattr(k, '_kind', None) is None or not hasattr(k, 'ARD') for k in ks):
+            return None
+        if ks[0].active_dims != ks[1].active_dims:
+            return None
+        Xs, X2s = ks[0]._slice(X), ks[0]._slice(X2)
+        if Xs.shape[-1] > 16:
+            return None
+        p0, p1 = ks[0]._strip(params), ks[1]._strip(params)
+        spec = (ks[0]._kind, bool(ks[0].ARD), ks[1]._kind, bool(ks[1].ARD), op)
+        return _Gram2Fn.apply(spec, Xs, X2s, p0['lengthscale'], p0['variance'], p1['lengthscale'], p1['variance'])
+
 
 class AddKernel(CombinationKernel):
     def __init__(self, sub_kernels, name='add', dtype=None, ctx=None):
@@ -133,6 +181,9 @@ class AddKernel(CombinationKernel):
 
     def _compute_K(self, F, X, X2=None, **params):
         """add_kernel.py:44-68."""
+        K = self._fused_pair(X, X2, params, ops.ACC_ADD)
+        if K is not None:
+            return K
         K = self.sub_kernels[0].K(F, X, X2, **params)
         for k in self.sub_kernels[1:]:
             K = K + k.K(F, X, X2, **params)
@@ -151,6 +202,9 @@ class MultiplyKernel(CombinationKernel):
 
     def _compute_K(self, F, X, X2=None, **params):
         """multiply_kernel.py:44-67."""
+        K = self._fused_pair(X, X2, params, ops.ACC_MUL)
+        if K is not None:
+            return K
         K = self.sub_kernels[0].K(F, X, X2, **params)
         for k in self.sub_kernels[1:]:
             K = K * k.K(F, X, X2, **params)

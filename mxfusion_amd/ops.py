@@ -69,6 +69,24 @@ def gram(kind, X, X2, lengthscale, variance, ard, diag_add=None, jitter=0.0, out
     return out
 
 
+def gram2(kind1, kind2, op, X, X2, ls1, var1, ard1, ls2, var2, ard2, diag_add=None, jitter=0.0, out=None):
+    """k1(X, X2) + k2(X, X2) (op = ACC_ADD) or their product (ACC_MUL) for two stationary kernels in ONE pass and one write (mxf_gram2):
+    AddKernel / MultiplyKernel._compute_K (add_kernel.py:44-68, multiply_kernel.py:44-67).  Shapes as gram()."""
+    X, X2, ls1, var1, ls2, var2, diag_add = _c(X), _c(X2), _c(ls1), _c(var1), _c(ls2), _c(var2), _c(diag_add)
+    S = num_samples(X, X2, ls1, var1, ls2, var2, diag_add)
+    N, Q = X.shape[-2], X.shape[-1]
+    N2 = N if X2 is None else X2.shape[-2]
+    if out is None:
+        out = torch.empty((S, N, N2), dtype=X.dtype, device=X.device)
+    if N == 0 or N2 == 0:
+        return out
+    k = lambda kk: KIND[kk] if isinstance(kk, str) else kk
+    _lib.call('mxf_gram2', _h(X), k(kind1), k(kind2), op, _dt(X), S, N, N2, Q, _p(X), _ss(X), _p(X2), _ss(X2), _p(ls1), int(bool(ard1)), _ss(ls1),
+              _p(var1), _ss(var1), _p(ls2), int(bool(ard2)), _ss(ls2), _p(var2), _ss(var2), _p(diag_add), _ss(diag_add), float(jitter),
+              _p(out), out.stride(-2), out.stride(0) if out.dim() == 3 else 0, _stream())
+    return out
+
+
 def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
     """Batched C = alpha op(A) op(B) + beta C on (S|1, m, k) operands -- linalg.gemm2 / syrk."""
     A, B = _c(A), _c(B)

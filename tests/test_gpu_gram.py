@@ -95,3 +95,71 @@ def test_gram_diag_add_modes_and_static_kernels():
     assert np.allclose(K.cpu().numpy(), np.eye(50)[None] * var[0, 0])
     K = ops.gram('white', _dev(X, dt), _dev(X2, dt), None, _dev(var, dt), False)
     assert np.all(K.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-12), (torch.float32, 3e-6)])
+@pytest.mark.parametrize('N,N2,Q', [(50, 31, 4), (129, None, 8), (33, 300, 12), (1, 7, 1)])
+def test_gram2_two_kernel_epilogue_vs_oracle(dtype, tol, N, N2, Q):
+    """mxf_gram2: k1 + k2 and k1 * k2 of two stationary kernels in ONE pass (add_kernel.py:44-68, multiply_kernel.py:44-67) == the oracle's
+    sum / product of the two Grams, every pair of kinds, ARD mixed with isotropic, sampled inputs and parameters, ragged shapes, the
+    diagonal term of a square Gram."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(N + Q)
+    S = 2
+    X = rng.uniform(-2, 2, (S, N, Q))
+    X2 = None if N2 is None else rng.uniform(-2, 2, (1, N2, Q))
+    for k1 in KINDS:
+        for k2 in KINDS:
+            ls1, var1 = rng.rand(S, Q) + 0.5, rng.rand(1, 1) + 0.5
+            ls2, var2 = rng.rand(1, 1) + 0.5, rng.rand(S, 1) + 0.5
+            r1, r2 = _oracle_K(k1, X, X2, ls1, var1, True), _oracle_K(k2, X, X2, ls2, var2, False)
+            for op, ref in ((ops.ACC_ADD, r1 + r2), (ops.ACC_MUL, r1 * r2)):
+                dadd = rng.rand(S, 1) if N2 is None else None
+                K = ops.gram2(k1, k2, op, _dev(X, dtype), None if X2 is None else _dev(X2, dtype), _dev(ls1, dtype), _dev(var1, dtype), True,
+                              _dev(ls2, dtype), _dev(var2, dtype), False, diag_add=None if dadd is None else _dev(dadd, dtype), jitter=1e-3 if N2 is None else 0.0)
+                if N2 is None:
+                    ref = ref + np.eye(N)[None] * (dadd[:, :, None] + 1e-3)
+                err = np.abs(K.double().cpu().numpy() - ref)
+                if N2 is None:
+                    # the diagonal of a Matern Gram is v f(sqrt(clip(r^2, 1e-14))): the reference's expansion form |x|^2 + |z|^2 - 2 x.z leaves r^2 ~ 1e-14
+                    # of rounding there (sqrt -> 1e-7), the difference form an exact zero -- both clipped, equal to ~1e-7 only
+                    d = np.arange(N)
+                    assert err[:, d, d].max() <= 1e-6 * np.abs(ref).max(), (k1, k2, op)
+                    err[:, d, d] = 0
+                assert err.max() <= tol * max(1.0, np.abs(ref).max()), (k1, k2, op)
+
+
+@pytest.mark.parametrize('comb', ['add', 'mul'])
+def test_combination_kernel_classes_take_the_fused_pair_path_and_differentiate(comb):
+    """AddKernel / MultiplyKernel of two stationary kernels (the deep-GP config's Matern52 + RBF) through the kernel classes: value and the
+    gradients w.r.t. inputs and all four parameters == autograd through the oracle; the forward pass is ONE mxf_gram2 launch."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.components.distributions.gp.kernels import kernel as kmod
+    rng = np.random.RandomState(3)
+    dt = torch.float64
+    S, N, N2, Q = 2, 40, 23, 3
+    X, X2 = rng.uniform(-2, 2, (S, N, Q)), rng.uniform(-2, 2, (1, N2, Q))
+    ls1, v1, ls2, v2 = rng.rand(1, Q) + 0.5, rng.rand(1, 1) + 0.5, rng.rand(1, 1) + 0.5, rng.rand(1, 1) + 0.5
+    k = (Matern52(Q, ARD=True, dtype='float64') + RBF(Q, dtype='float64')) if comb == 'add' else (Matern52(Q, ARD=True, dtype='float64') * RBF(Q, dtype='float64'))
+    ok = (O.AddKernel if comb == 'add' else O.MultiplyKernel)([O.Matern52(Q, ARD=True), O.RBF(Q)])
+    names = ('X', 'X2', 'ls1', 'v1', 'ls2', 'v2')
+    dv = {n: _dev(a, dt).requires_grad_(True) for n, a in zip(names, (X, X2, ls1, v1, ls2, v2))}
+    ov = {n: O.T(a).clone().requires_grad_(True) for n, a in zip(names, (X, X2, ls1, v1, ls2, v2))}
+    pre = comb + '_'
+    calls = []
+    orig = kmod._Gram2Fn.apply
+    kmod._Gram2Fn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        K = k.K(None, dv['X'], dv['X2'], **{pre + 'matern52_lengthscale': dv['ls1'], pre + 'matern52_variance': dv['v1'], pre + 'rbf_lengthscale': dv['ls2'],
+                                            pre + 'rbf_variance': dv['v2']})
+    finally:
+        kmod._Gram2Fn.apply = orig
+    assert len(calls) == 1
+    Kr = ok.K(ov['X'], ov['X2'], **{pre + 'matern52_lengthscale': ov['ls1'], pre + 'matern52_variance': ov['v1'], pre + 'rbf_lengthscale': ov['ls2'],
+                                    pre + 'rbf_variance': ov['v2']})
+    assert np.allclose(K.detach().cpu().numpy(), Kr.detach().numpy(), atol=1e-12)
+    w = rng.randn(S, N, N2)
+    (K * _dev(w, dt)).sum().backward()
+    (Kr * O.T(w)).sum().backward()
+    for n in names:
+        assert np.allclose(dv[n].grad.cpu().numpy(), ov[n].grad.numpy(), rtol=1e-8, atol=1e-10), n
