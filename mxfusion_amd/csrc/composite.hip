@@ -541,6 +541,91 @@ __global__ void svgp_het_finalize_kernel(int S, int64_t M, int P, const double* 
     if (dvar_direct) dvar_direct[0] = -0.5 * a1 * sb;
 }
 
+// ---- streaming heteroscedastic bound (r04): per-row noise (B, 1), one output column, float32 split path ------------------------------------
+// svgp_regression.py:61-67 with noise (N, 1): beta_n = 1 / noise_n.  With nmin = min_n noise_n and the weights r_n = nmin beta_n <= 1:
+//   planes of Kuf diag(sqrt r)  ->  Psi2' = nmin sum_n beta_n k_n k_n^T           (the core's G = P a1 / 2 (1/nmin) Psi2': the homoscedastic code with noise := nmin)
+//   planes of diag(r) Kfu (+ U' = r U)  ->  T'' = T diag(r),  y' = r y            (the fused reverse pass with noise := nmin sees e'' = r e and forms exactly
+//                                                                                  a1 beta_n (w e_n + P T_n), sum_n beta_n q_n, dY = -a1 beta_n e_n, R = Kuf (beta e))
+// What the fused pass cannot deliver -- sum_n beta_n e_n^2 and the per-row noise gradient, which needs q_n per COLUMN -- comes from one
+// extra pass over the Kfu planes and T'' (het_stats_kernel).
+__global__ __launch_bounds__(256) void het_min_kernel(int64_t B, const float* __restrict__ noise, unsigned* __restrict__ minbits) {
+    __shared__ unsigned wm[4];
+    unsigned m = 0x7f800000u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) { const unsigned b = __builtin_bit_cast(unsigned, noise[i]); m = b < m ? b : m; }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t < m ? t : m; }
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < 4; ++w) m = wm[w] < m ? wm[w] : m; atomicMin(minbits, m); }      // positive floats order as their bits
+}
+__global__ __launch_bounds__(256) void het_prep_kernel(int64_t B, const float* __restrict__ noise, const unsigned* __restrict__ minbits, float* __restrict__ cs,
+                                                       float* __restrict__ rs, double* __restrict__ hs /* [0] sum log noise, [1] sum 1/noise */,
+                                                       float* __restrict__ nzf, double* __restrict__ noised) {
+    __shared__ double red[16];
+    const float nmin = __builtin_bit_cast(float, minbits[0]);
+    double sl = 0, sb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
+        const float nz = noise[i], r = nmin / nz;
+        rs[i] = r; cs[i] = sqrtf(r);
+        sl += log((double)nz); sb += 1.0 / (double)nz;
+    }
+    sl = block_sum<double>(sl, red); sb = block_sum<double>(sb, red);
+    if (threadIdx.x == 0) { atomic_add(hs + 0, sl); atomic_add(hs + 1, sb); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { nzf[0] = nmin; noised[0] = (double)nmin; }
+}
+__global__ void het_scale_y_kernel(int64_t n, int64_t B, const float* __restrict__ Y, const float* __restrict__ rs, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = Y[i] * rs[i % B];
+}
+// one wave per 16-column block: lane = (column c = lane % 16, row phase lane / 16); rows m = phase, phase + 4, ...: the T'' reads of one step
+// are 4 rows x 64 bytes contiguous.  q_n = (sum_m kpl_mn T''_mn) sigma^2 2^-14 / r_n^2, e_n = (y'_n - U'_n) / r_n.
+__global__ __launch_bounds__(256) void het_stats_kernel(int64_t SB, int64_t B, int64_t M, const unsigned short* __restrict__ pl, int64_t pstride,
+                                                        const float* __restrict__ Tb /* T'' in 16-column blocks, then U' at Tb + M * SB */,
+                                                        const float* __restrict__ ysc, int64_t sY, const float* __restrict__ noise,
+                                                        const float* __restrict__ rs, const float* __restrict__ var, double a1, int want_grad,
+                                                        float* __restrict__ dnoise, double* __restrict__ sbe2 /* [S] */) {
+    const int lane = threadIdx.x & 63, c = lane & 15, ph = lane >> 4;
+    const int64_t nb16 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (nb16 * 16 >= SB) return;
+    const int64_t n = nb16 * 16 + c;
+    float acc = 0.f;
+    typedef unsigned int hs_u32x2 __attribute__((ext_vector_type(2)));
+    for (int64_t mb = 0; mb < M; mb += 16) {          // (M % 16 == 0) rows mb + 4 ph .. + 3: one 8-byte piece of each plane, four T'' rows
+        const int64_t off = ((mb >> 4) * SB + n) * 16 + 4 * ph;
+        const hs_u32x2 vh = *reinterpret_cast<const hs_u32x2*>(pl + off), vl = *reinterpret_cast<const hs_u32x2*>(pl + pstride + off);
+        const float* tp = Tb + (nb16 * M + mb + 4 * ph) * 16 + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned wh = vh[i >> 1], wl = vl[i >> 1];
+            const unsigned short hb = (unsigned short)((i & 1) ? (wh >> 16) : (wh & 0xffffu)), lb = (unsigned short)((i & 1) ? (wl >> 16) : (wl & 0xffffu));
+            acc = fmaf((float)__builtin_bit_cast(_Float16, hb) + (float)__builtin_bit_cast(_Float16, lb), tp[i * 16], acc);
+        }
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    const int64_t nbr = n % B, s = n / B;
+    const double r = (double)rs[nbr], nz = (double)noise[nbr], beta = 1.0 / nz, vk = (double)var[0];
+    const double q = (double)acc * vk * (1.0 / 16384.0) / (r * r);
+    const double e = ((double)ysc[s * sY + nbr] - (double)Tb[M * SB + n]) / r;
+    double be2 = (ph == 0) ? beta * e * e : 0.0;
+    // the 16 columns of a block lie in one sample when B % 16 == 0 (host guarantees it): one atomic per wave
+    for (int o = 8; o > 0; o >>= 1) be2 += __shfl_xor(be2, o, 64);
+    if (lane == 0) atomic_add(sbe2 + s, be2);
+    if (want_grad && dnoise && ph == 0) atomic_add(dnoise + nbr, (float)(a1 * (0.5 * beta * beta * e * e - 0.5 * beta + 0.5 * (vk - q) * beta * beta)));
+}
+template <typename T>
+__global__ void svgp_finalize_hets_kernel(int S, int64_t B, int64_t M, const double* __restrict__ scal, const double* __restrict__ sbe2,
+                                          const double* __restrict__ hs, const double* __restrict__ noised /* nmin */, const double* __restrict__ var,
+                                          const double* __restrict__ sldL, const double* __restrict__ sldLs, const double* __restrict__ trKiSu,
+                                          const double* __restrict__ muw, double scaling, double a1, T* __restrict__ logL, double* __restrict__ dvar_direct) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double vk = var[0], bmax = 1.0 / noised[0];
+    const double negKL = 0.5 * ((double)M + 2.0 * sldLs[0] - 2.0 * sldL[0] - trKiSu[0]) - 0.5 * muw[0];
+    for (int s = 0; s < S; ++s) {
+        const double l = -0.5 * (sbe2[s] + (double)B * LOG2PI + hs[0]) - 0.5 * vk * hs[1] + 0.5 * bmax * scal[2 * s];
+        logL[s] = (T)(scaling * l + negKL);
+    }
+    if (dvar_direct) dvar_direct[0] = a1 * (double)S * (-0.5 * hs[1]);
+}
+
 // |A|_1 of a symmetric (n x n) float64 matrix: max over rows of the absolute row sum (= column sum), into *out as a double (non-negative
 // doubles order like unsigned 64-bit integers: one atomicMax per workgroup; *out must be zeroed)
 __global__ __launch_bounds__(256) void norm1_sym_kernel(int64_t n, const double* __restrict__ A, int64_t lda, double* __restrict__ out) {
@@ -611,7 +696,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (ysamp && sY != B * P) MXF_FAIL(h, -2, "mxf_svgp_logpdf: Y samples must be contiguous");
     // generic path: Kuf-side reverse mode through a materialised dKuf (not the streaming fused pass); also for Q > 16 inputs, which the
     // register-tiled fused reverse pass does not cover (gram_bwd.hip: generic kernel)
-    const bool het = nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16;
+    // r04: per-row noise (B, 1) with one output column on the float32 split path runs the STREAMING form (het_* kernels above); every other
+    // heteroscedastic shape keeps the generic (materialised dKuf) path
+    static const int het_stream_env = MXF_KNOB("MXF_SVGP_HET_STREAM", 1);
+    const int64_t SBh = ((sX == 0) ? (int64_t)1 : (int64_t)S) * B;
+    const bool het_stream = het_stream_env && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
+                            (B % 16 == 0) && (M % 16 == 0) && M >= 128 && h->svgp_form == MXF_SVGP_EXPLICIT && mxf_svgp_bwd_is_mfma(dtype, SBh, B, Q, P, X);
+    const bool het = (nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16) && !het_stream;
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
     if (S > 1 && sX == 0 && sY == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S > 1 with neither X nor Y sampled");
     const int SS = (sX == 0) ? 1 : S;   // samples that need their own columns
@@ -643,6 +734,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_FAIL(h, -3, "mxf_svgp_logpdf: the whitened float32 form needs M %% 128 == 0, S B %% 256 == 0, Q <= 16, homoscedastic noise (see mxf_svgp_whitened_ok)");
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
     if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); }
+    if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
     else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
@@ -663,6 +755,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
     unsigned short* plLi = nullptr; D* ad = nullptr; T* aT = nullptr; float* sigf = nullptr;
     if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); }
+    float* hcs = nullptr; float* hrs = nullptr; float* hys = nullptr; D* hhs = nullptr; D* hbe2 = nullptr; float* hnz = nullptr;
+    if (het_stream) { hcs = cv.take<float>(B); hrs = cv.take<float>(B); hys = cv.take<float>((size_t)(sY == 0 ? B : SB)); hhs = cv.take<D>(4); hbe2 = cv.take<D>(S); hnz = cv.take<float>(4); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     D* G = nullptr; D* T1 = nullptr; D* AKi = nullptr; D* T2 = nullptr; D* dKuu = nullptr; D* dSu = nullptr;
     D* Gw = nullptr; D* dmud = nullptr; D* dZc = nullptr; D* dlsc = nullptr; D* dvc = nullptr;
@@ -683,6 +777,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_T0(h, MXF_T_CALL, st); MXF_T0(h, MXF_T_CHAIN, st);
     hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2, h->cond_dev);
     if (whiten) hipLaunchKernelGGL(svgp_sigma_kernel, dim3(1), dim3(64), 0, st, (const float*)var, sigf);
+    if (het_stream) {       // nmin, the row weights, sum log noise / sum beta, y' = r y -- before the fork: both side streams read them
+        MXF_HIP(h, hipMemsetAsync(info2 + 5, 0x7f, sizeof(int), st));                 // 0x7f7f7f7f: a huge finite float, above any noise variance
+        MXF_HIP(h, hipMemsetAsync(hhs, 0, 4 * sizeof(D), st));
+        MXF_HIP(h, hipMemsetAsync(hbe2, 0, (size_t)S * sizeof(D), st));
+        const unsigned pg = (unsigned)((B + 255) / 256 > 256 ? 256 : (B + 255) / 256);
+        hipLaunchKernelGGL(het_min_kernel, dim3(pg), dim3(256), 0, st, B, (const float*)noise, (unsigned*)(info2 + 5));
+        hipLaunchKernelGGL(het_prep_kernel, dim3(pg), dim3(256), 0, st, B, (const float*)noise, (const unsigned*)(info2 + 5), hcs, hrs, hhs, hnz, noised);
+        const int64_t ny = sY == 0 ? B : SB;
+        hipLaunchKernelGGL(het_scale_y_kernel, dim3(gridn(ny)), dim3(256), 0, st, ny, B, (const float*)Y, (const float*)hrs, hys);
+    }
     if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
     int rc;
@@ -708,7 +812,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // second side stream, first thing: Su (H0 on the critical path needs it; its Cholesky comes later and is off the critical path)
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), s2_));
     MXF_HIP(h, hipMemsetAsync(scal, 0, 2 * (size_t)S * sizeof(D), s2_));
-    if (!het) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(1), dim3(256), 0, s2_, (int64_t)1, (int64_t)1, noise, (int64_t)1, noised, (int64_t)1);
+    if (!het && !het_stream) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(1), dim3(256), 0, s2_, (int64_t)1, (int64_t)1, noise, (int64_t)1, noised, (int64_t)1);
     hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MP)), dim3(256), 0, s2_, (int64_t)1, (int64_t)MP, mu, (int64_t)MP, mud, (int64_t)MP);
     hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(MM)), dim3(256), 0, s2_, (int64_t)1, (int64_t)MM, W, (int64_t)MM, Wd, (int64_t)MM);
     hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(M)), dim3(256), 0, s2_, (int64_t)1, (int64_t)M, sdiag, (int64_t)M, sd, (int64_t)M);
@@ -738,7 +842,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // (n, k = m): T GEMM and the w^T Kuf row) are then written (HBM bound) on the second side stream NEXT TO Psi2.
         MXF_T0(h, MXF_T_PLANES_A, sd_);
         rc = mxf_gram_planes_internal(h, kind, M, SB, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var, plKuf,
-                                      (int64_t)pl_big, gscr0, sd_, split_mode);
+                                      (int64_t)pl_big, gscr0, sd_, split_mode, nullptr, 0, nullptr, 0, het_stream ? (const float*)hcs : nullptr, nullptr, B);
         if (rc) return rc;
         MXF_T1(h, MXF_T_PLANES_A, sd_);
         MXF_STAGE(h, "Kuf planes (sd)", sd_);
@@ -893,7 +997,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux2, 0));
         MXF_T0(h, MXF_T_PLANES_B, s2_);
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
-                                      (int64_t)pl_big, gscr1, s2_, split_mode, (const float*)wT, P, (float*)(Text + M * SB), SB);
+                                      (int64_t)pl_big, gscr1, s2_, split_mode, (const float*)wT, P, (float*)(Text + M * SB), SB, nullptr,
+                                      het_stream ? (const float*)hrs : nullptr, B);
         if (rc) return rc;
         MXF_T1(h, MXF_T_PLANES_B, s2_);
         MXF_STAGE(h, "Kfu planes + U (s2)", s2_);
@@ -1042,7 +1147,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipMemsetAsync(R, 0, sizeof(T) * MP, st));
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
         MXF_T0(h, MXF_T_BWD, st);
-        rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, Y, sY, wT, noise, a1, dZ, dX, dls, dvar,
+        rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, het_stream ? (const T*)hys : Y, sY, wT,
+                                         het_stream ? (const T*)hnz : noise, a1, dZ, dX, dls, dvar,
                                          dY, dY_shared, R, scal, st, t_blocked,
                                          (use_split && split_mode == MXF_SPLIT_F16X2) ? (const unsigned*)(info2 + 2) : nullptr,
                                          (const unsigned*)(info2 + 3));
@@ -1050,7 +1156,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     if (want_grad && !het) MXF_T1(h, MXF_T_BWD, st);
     MXF_STAGE(h, "reverse pass", st);
-    if (!het) {
+    if (het_stream) {
+        // sum_n beta_n e_n^2 per sample and the per-row noise gradient: one more pass over the Kfu planes and T''
+        if (dnoise) MXF_HIP(h, hipMemsetAsync(dnoise, 0, sizeof(T) * (size_t)B, st));
+        hipLaunchKernelGGL(het_stats_kernel, dim3((unsigned)((SB / 16 + 3) / 4)), dim3(256), 0, st, SB, B, M, (const unsigned short*)plKfu, (int64_t)pl_big,
+                           (const float*)Text, (const float*)hys, sY, (const float*)noise, (const float*)hrs, (const float*)var, a1, want_grad,
+                           (float*)dnoise, hbe2);
+        hipLaunchKernelGGL((svgp_finalize_hets_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, (const D*)scal, (const D*)hbe2, (const D*)hhs, (const D*)noised,
+                           (const D*)vard, (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dvdir);
+        MXF_LAUNCH_CHECK(h);
+    } else if (!het) {
         if (whiten) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // Phi and the core's Su part (side stream): the value needs tr(C Phi)
         hipLaunchKernelGGL((svgp_finalize_kernel<T>), dim3(1), dim3(64), 0, st, S, B, M, P, (const D*)scal, (const D*)noised, (const D*)vard,
                            (const D*)(sc + 0), (const D*)(sc + 1), (const D*)(sc + 2), (const D*)(sc + 3), scaling, a1, logL, dnz, dvdir,
@@ -1101,7 +1216,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
         }
     }
-    if (dnoise && !het) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    if (dnoise && !het && !het_stream) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
     MXF_STAGE(h, "core reverse", st);
     hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream

@@ -619,7 +619,12 @@ template <int QT, int KIND, int PT, bool ACC = false>
 __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                               const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
                                                               int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
-                                                              int64_t ldU, const float* __restrict__ ls = nullptr, int ard = 0, int Q = 0) {
+                                                              int64_t ldU, const float* __restrict__ ls = nullptr, int ard = 0, int Q = 0,
+                                                              const float* __restrict__ majs = nullptr, const float* __restrict__ mins = nullptr,
+                                                              int64_t period = 1) {
+    // majs / mins (ACC form only; the streaming heteroscedastic SVGP bound, svgp_regression.py:61-67): every covariance is multiplied by
+    // majs[major index % period] (wave-uniform) and / or mins[minor index % period] (per lane) before it is split into planes -- and before
+    // it enters the fused row U -- i.e. the planes hold K diag(s) resp. diag(s) K for per-row weights s <= 1
     const int lane = threadIdx.x;
     float s2[QT];
     if constexpr (ACC) {
@@ -633,6 +638,8 @@ __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t
     float z[QT];
 #pragma unroll
     for (int q = 0; q < QT; q += 4) *reinterpret_cast<f32x4_t*>(&z[q]) = *reinterpret_cast<const f32x4_t*>(Xmin_s + r * QT + q);   // padded
+    float mscale = 1.f;
+    if constexpr (ACC) { if (mins) mscale = mins[(r < R ? r : R - 1) % period]; }
     float uacc[PT > 0 ? PT : 1];
 #pragma unroll
     for (int p = 0; p < (PT > 0 ? PT : 1); ++p) uacc[p] = 0.f;
@@ -664,7 +671,11 @@ __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t
                     else acc2 = __builtin_elementwise_fma(d, d, acc2);
                 }
                 const float red = acc2.x + acc2.y;
-                const float kv = (FULL || kb * 16 + nl < Kn) ? cov_from<float, KIND>(red, 16384.f) : 0.f;
+                float kv = (FULL || kb * 16 + nl < Kn) ? cov_from<float, KIND>(red, 16384.f) : 0.f;
+                if constexpr (ACC) {
+                    if (majs) { const int64_t km = FULL ? kb * 16 + nl : ((kb * 16 + nl < Kn) ? kb * 16 + nl : Kn - 1); kv *= majs[km % period]; }
+                    if (mins) kv *= mscale;
+                }
                 if (PT > 0) {
                     const int64_t kk = FULL ? kb * 16 + nl : ((kb * 16 + nl < Kn) ? kb * 16 + nl : Kn - 1);     // (kv == 0 beyond Kn)
 #pragma unroll
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t
 template <int KIND>
 int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls, int ard,
                      const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode,
-                     const float* wk, int Pw, float* U, int64_t ldU) {
+                     const float* wk, int Pw, float* U, int64_t ldU, const float* majs, const float* mins, int64_t period) {
     const int QT = Q <= 8 ? 8 : 16;
     const int64_t padr = (R + 127) / 128 * 128, padk = ((Kn + 15) / 16 + 15) / 16 * 256;
     float* buf = scratch;     // (padr + padk) * QT floats, caller-owned: two of these run concurrently on different streams
@@ -735,6 +746,7 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     // r03: the one-wave form for the f16x2 planes (probe builds: MXF_PLANES_LEAN=0 selects the staged kernel)
     const bool lean = mode == MXF_SPLIT_F16X2 && MXF_KNOB("MXF_PLANES_LEAN", 1) != 0;
     const int raw = (lean && MXF_KNOB("MXF_PLANES_ACC", 1) != 0) ? 1 : 0;       // difference-then-scale distances (gram_planes_lean_kernel ACC)
+    if ((majs || mins) && !raw) MXF_FAIL(h, -3, "gram planes: per-row weights need the f16x2 lean kernel");
     int kbpb = fuse_u ? (int)K16 : (int)MXF_KNOB("MXF_PLANES_KB", 8);
     while (!fuse_u && (K16 + kbpb - 1) / kbpb > 65535) kbpb *= 2;
     dim3 lgrid((unsigned)((R + 63) / 64), (unsigned)((K16 + kbpb - 1) / kbpb));
@@ -745,11 +757,11 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padk * QTV + 255) / 256), 1), dim3(256), 0, st, Xmaj, (int64_t)0, ls, \
                            (int64_t)0, ard, Kn, Q, padk, bmaj, (float*)nullptr, raw);                                                 \
         if (lean && raw && fuse_u && Pw == 1)                                                                                         \
-            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && raw && fuse_u)                                                                                               \
-            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && raw)                                                                                                         \
-            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q); \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && fuse_u && Pw == 1)                                                                                           \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU); \
         else if (lean && fuse_u)                                                                                                      \
@@ -836,15 +848,15 @@ size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q) {
 
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
                              int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st, int mode,
-                             const float* wk, int Pw, float* U, int64_t ldU) {
+                             const float* wk, int Pw, float* U, int64_t ldU, const float* majs, const float* mins, int64_t period) {
     if (R <= 0 || Kn <= 0) return 0;
     if (!scratch) MXF_FAIL(h, -2, "gram planes: scratch of mxf_gram_planes_scratch_bytes() bytes required");
     if (Q > 16) MXF_FAIL(h, -3, "gram planes: Q > 16 not supported");
     switch (kind) {
-        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
-        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
-        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
-        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU);
+        case MXF_K_RBF: return gram_planes_kind<MXF_K_RBF>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU, majs, mins, period);
+        case MXF_K_MATERN12: return gram_planes_kind<MXF_K_MATERN12>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU, majs, mins, period);
+        case MXF_K_MATERN32: return gram_planes_kind<MXF_K_MATERN32>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU, majs, mins, period);
+        case MXF_K_MATERN52: return gram_planes_kind<MXF_K_MATERN52>(h, R, Kn, Q, Xmin, Xmaj, ls, ard, var, planes, pstride, scratch, st, mode, wk, Pw, U, ldU, majs, mins, period);
     }
     MXF_FAIL(h, -2, "gram planes: stationary kernels only (kind %d)", kind);
 }

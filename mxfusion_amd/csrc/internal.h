@@ -56,7 +56,9 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
                              int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st,
-                             int mode = 0 /* MXF_SPLIT_BF16X3 */, const float* wk = nullptr, int Pw = 0, float* U = nullptr, int64_t ldU = 0);
+                             int mode = 0 /* MXF_SPLIT_BF16X3 */, const float* wk = nullptr, int Pw = 0, float* U = nullptr, int64_t ldU = 0,
+                             const float* majs = nullptr, const float* mins = nullptr, int64_t period = 1);
+// (majs / mins: optional per-row weights (period entries, index taken modulo period) on the major / minor index -- f16x2 lean kernel only)
 // (wk (Kn x Pw), U (Pw x ldU): optional fused product U[p][r] = sum_k wk[k][p] cov(xmin[r], xmaj[k]); see gram_planes_kernel)
 
 // whiten.hip: two f16 planes of an (R x K) operand -> the planes of its transpose (K x R); U != nullptr: U[k] = scale[0] * sc2 * sum_r a[r] x(r, k)
