@@ -55,6 +55,11 @@ __global__ void diag_embed_kernel(int64_t n, const T* __restrict__ d, T* __restr
         A[i] = (i / n == i % n) ? d[i / n] : (T)0;
 }
 
+template <typename TI, typename TO>
+__global__ void pcast_kernel(int64_t n, const TI* __restrict__ src, TO* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (TO)src[i];
+}
+
 bool stationary(int kind) { return kind == MXF_K_RBF || kind == MXF_K_MATERN12 || kind == MXF_K_MATERN32 || kind == MXF_K_MATERN52; }
 
 template <typename T>
@@ -90,11 +95,12 @@ int gp_predict_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int64_t 
 template <typename T>
 int svgp_predict_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t M, int64_t Nt, int Q, int P, const T* Z, const T* Xt, const T* ls, int ard,
                        const T* var, const T* mu, const T* W, const T* sdiag, const T* noise, double jitter, int noise_free, int full_cov, T* mean,
-                       T* vout, int* info, hipStream_t st) {
+                       T* vout, int* info, hipStream_t st, size_t ws_off = 0) {
     const int64_t C = (int64_t)S * Nt, MM = M * M;
     const size_t need = sizeof(T) * ((size_t)4 * MM + 2 * (size_t)M * P + 2 * (size_t)M * C + 2 * (size_t)C) + 64;
-    T* base = (T*)mxf_ws(h, need);
-    if (!base) MXF_FAIL(h, -4, "mxf_svgp_predict: cannot allocate %zu bytes of scratch", need);
+    char* ws0 = (char*)mxf_ws(h, ws_off + need);
+    if (!ws0) MXF_FAIL(h, -4, "mxf_svgp_predict: cannot allocate %zu bytes of scratch", ws_off + need);
+    T* base = (T*)(ws0 + ws_off);
     T* Lm = base; T* Su = Lm + MM; T* LinvLs = Su + MM; T* LSL = LinvLs + MM;
     T* Linvmu = LSL + MM; T* wv = Linvmu + M * P;
     T* V = wv + M * P; T* tmp = V + (size_t)M * C; T* cd1 = tmp + (size_t)M * C; T* cd2 = cd1 + C;
@@ -197,10 +203,36 @@ extern "C" int mxf_svgp_predict(mxf_handle h, int kind, int dtype, int S, int64_
         MXF_FAIL(h, -2, "mxf_svgp_predict: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (info) MXF_HIP(h, hipMemsetAsync(info, 0, 2 * sizeof(int), st));
-    if (dtype == MXF_F32)
-        return svgp_predict_typed<float>(h, kind, dtype, S, M, Nt, Q, P, (const float*)Z, (const float*)X_test, (const float*)lengthscale, ard, (const float*)variance,
-                                         (const float*)qU_mean, (const float*)qU_cov_W, (const float*)qU_cov_diag, (const float*)noise_var, jitter, noise_free,
-                                         full_cov, (float*)mean_out, (float*)var_out, (int*)info, st);
+    if (dtype == MXF_F32) {
+        // r04: float32 predictions are EVALUATED in float64 (inputs widened, results narrowed).  The reference factors Kuu in the model's
+        // dtype (svgp_regression.py:146-154); in float32 that loses cond(Kuu) 2^-24 of the posterior moments -- 1e-3 .. 1e-1 at the condition
+        // numbers a trained model has (2e4 .. 1e6), where north_star asks for 1e-5.  Prediction is not the hot path (one M^3 core + 2 M^2 Nt
+        // flops per call); the training call has kept its (M x M) core in float64 since r01 for the same reason.
+        const int64_t C = (int64_t)S * Nt, MM = M * M;
+        const int lsn = ard ? Q : 1;
+        const size_t nvo = full_cov ? (size_t)S * Nt * Nt : (size_t)C;
+        size_t off = 0;
+        auto take = [&](size_t n) { const size_t o = off; off += mxf_align(n * sizeof(double)); return o; };
+        const size_t oZ = take(M * Q), oX = take((size_t)C * Q), ols = take(lsn), ovr = take(1), omu = take(M * P), oW = take(MM), osd = take(M), onz = take(1),
+                     omean = take((size_t)C * P), ovout = take(nvo);
+        const size_t need_d = sizeof(double) * ((size_t)4 * MM + 2 * (size_t)M * P + 2 * (size_t)M * C + 2 * (size_t)C) + 64;
+        char* ws = (char*)mxf_ws(h, off + need_d);
+        if (!ws) MXF_FAIL(h, -4, "mxf_svgp_predict: cannot allocate %zu bytes of scratch", off + need_d);
+        auto up = [&](const void* src, size_t o, size_t n) {
+            if (src && n) hipLaunchKernelGGL((pcast_kernel<float, double>), dim3(gridn((int64_t)n)), dim3(256), 0, st, (int64_t)n, (const float*)src, (double*)(ws + o));
+        };
+        up(Z, oZ, M * Q); up(X_test, oX, (size_t)C * Q); up(lengthscale, ols, lsn); up(variance, ovr, 1); up(qU_mean, omu, M * P); up(qU_cov_W, oW, MM);
+        up(qU_cov_diag, osd, M); up(noise_var, onz, 1);
+        const int rc = svgp_predict_typed<double>(h, kind, MXF_F64, S, M, Nt, Q, P, (const double*)(ws + oZ), (const double*)(ws + oX), (const double*)(ws + ols), ard,
+                                                  (const double*)(ws + ovr), (const double*)(ws + omu), (const double*)(ws + oW), (const double*)(ws + osd),
+                                                  noise_var ? (const double*)(ws + onz) : nullptr, jitter, noise_free, full_cov, (double*)(ws + omean),
+                                                  (double*)(ws + ovout), (int*)info, st, off);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pcast_kernel<double, float>), dim3(gridn((int64_t)C * P)), dim3(256), 0, st, (int64_t)C * P, (const double*)(ws + omean), (float*)mean_out);
+        hipLaunchKernelGGL((pcast_kernel<double, float>), dim3(gridn((int64_t)nvo)), dim3(256), 0, st, (int64_t)nvo, (const double*)(ws + ovout), (float*)var_out);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (dtype == MXF_F64)
         return svgp_predict_typed<double>(h, kind, dtype, S, M, Nt, Q, P, (const double*)Z, (const double*)X_test, (const double*)lengthscale, ard,
                                           (const double*)variance, (const double*)qU_mean, (const double*)qU_cov_W, (const double*)qU_cov_diag,

@@ -142,6 +142,15 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         M = Z.shape[-2]
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
+        mean_fn = variables[self.model.mean] if self.model.F.factor.has_mean else None
+        # r04: a float32 prediction that records no autograd graph is EVALUATED in float64 (inputs widened, moments narrowed).  The reference
+        # factors Kuu in the model's dtype (svgp_regression.py:146-154): in float32 that costs cond(Kuu) 2^-24 of the posterior moments -- 1e-3 ..
+        # 1e-1 at a trained model's condition numbers, where north_star asks for 1e-5.  (Differentiable rollouts keep their dtype.)
+        wide = X.dtype == torch.float32 and X.is_cuda and not torch.is_grad_enabled()
+        if wide:
+            X, Z, noise_var, mu, S_W, S_diag = [t.double() for t in (X, Z, noise_var, mu, S_W, S_diag)]
+            kern_params = {k: v.double() for k, v in kern_params.items()}
+            mean_fn = None if mean_fn is None else mean_fn.double()
         fold = None                 # S samples of the test inputs against one posterior: fold them into columns (gp_regression.py here)
         if self.diagonal_variance and X.shape[0] > 1 and all(t.shape[0] == 1 for t in [Z, noise_var, mu, S_W, S_diag] + list(kern_params.values())):
             fold = tuple(X.shape[:2])
@@ -161,8 +170,8 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
         mu_t = lin.gemm(Kxt, wv, transA=True)
         if fold is not None:
             mu_t = mu_t.reshape(fold + (mu_t.shape[-1],))
-        if self.model.F.factor.has_mean:
-            mu_t = mu_t + variables[self.model.mean]
+        if mean_fn is not None:
+            mu_t = mu_t + mean_fn
         if torch.is_grad_enabled() and L.shape[0] == 1:
             LinvKxt = lin.gemm(ops.trtri(L), Kxt)        # rollout: one GEMM (and one in the reverse pass) instead of a chain of panel solves
         else:
@@ -188,6 +197,8 @@ class SVGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             var = var.unsqueeze(-1)
             if not self.noise_free:
                 var = var + torch.eye(N, dtype=X.dtype, device=X.device).reshape(1, N, N, 1) * noise_var.unsqueeze(-2)
+        if wide:
+            mu_t, var = mu_t.float(), var.float()
         return mu_t, var
 
     def compute(self, F, variables):
