@@ -121,6 +121,14 @@ class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
         LinvY = variables[self.graphs[1].LinvY]
         kern = self.model.kernel
         kern_params = kern.fetch_parameters(variables)
+        mean_fn = variables[self.model.mean] if self.model.F.factor.has_mean else None
+        # r04: a float32 prediction that records no autograd graph is EVALUATED in float64 (the stored posterior L, L^-1 Y widened, the results
+        # narrowed by compute()): the solve against L loses ~ sqrt(cond(K + noise I)) 2^-24 in float32.  Differentiable rollouts keep their dtype.
+        self._wide = X.dtype == torch.float32 and X.is_cuda and not torch.is_grad_enabled()
+        if self._wide:
+            X, noise_var, X_cond, L, LinvY = [t.double() for t in (X, noise_var, X_cond, L, LinvY)]
+            kern_params = {k: v.double() for k, v in kern_params.items()}
+            mean_fn = None if mean_fn is None else mean_fn.double()
         # S samples of the test inputs against ONE posterior (the rollout's trajectories; any sampled-input prediction): the sample axis is
         # folded into the column axis, so the cross Gram is one (N x S*Nt) matrix and every product below one full-width GEMM instead of
         # S skinny ones (at N=1000, S=64, Nt=1: 0.34 ms -> ~0.03 ms per product)
@@ -138,8 +146,8 @@ class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
         mu = lin.gemm(LinvKxt, LinvY, transA=True)                   # V^T LinvY (LinvY broadcast over S by stride 0)
         if fold is not None:
             mu = mu.reshape(fold + (mu.shape[-1],))
-        if self.model.F.factor.has_mean:
-            mu = mu + variables[self.model.mean]
+        if mean_fn is not None:
+            mu = mu + mean_fn
         return X, noise_var, kern, kern_params, LinvKxt, mu, fold
 
     def compute(self, F, variables):
@@ -162,6 +170,8 @@ class GPRegressionMeanVariancePrediction(SamplingAlgorithm):
                 var = ops.gemm(LinvKxt, LinvKxt, transA=True, alpha=-1.0, beta=1.0, out=Ktt.contiguous().clone())
                 if not self.noise_free:
                     var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+            if self._wide:
+                mu, var = mu.float(), var.float()
         outcomes = {self.model.Y.uuid: (mu, var)}
         if self.target_variables:
             return tuple(outcomes[v] for v in self.target_variables)
@@ -211,6 +221,8 @@ class GPRegressionSamplingPrediction(GPRegressionMeanVariancePrediction):
                     cov = cov + eye * self.jitter
                 Lc, _ = ops.potrf_(cov.contiguous())
                 samples = mu + ops.gemm(Lc, die)
+            if self._wide:
+                samples = samples.float()
         outcomes = {self.model.Y.uuid: samples}
         if self.target_variables:
             return tuple(outcomes[v] for v in self.target_variables)

@@ -112,6 +112,14 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             wv = variables[self.graphs[1].wv]
             kern = self.model.kernel
             kern_params = kern.fetch_parameters(variables)
+            mean_fn = variables[self.model.mean] if self.model.F.factor.has_mean else None
+            # r04: a float32 prediction that records no autograd graph is EVALUATED in float64 (the stored posterior widened, the moments
+            # narrowed): the triangular solves against L / LA lose ~ sqrt(cond(Kuu)) 2^-24 in float32 (see svgp_regression.py here)
+            wide = X.dtype == torch.float32 and X.is_cuda and not torch.is_grad_enabled()
+            if wide:
+                X, Z, noise_var, L, LA, wv = [t.double() for t in (X, Z, noise_var, L, LA, wv)]
+                kern_params = {k: v.double() for k, v in kern_params.items()}
+                mean_fn = None if mean_fn is None else mean_fn.double()
             fold = None             # S samples of the test inputs against one posterior: fold them into columns (gp_regression.py here)
             if self.diagonal_variance and X.shape[0] > 1 and all(t.shape[0] == 1 for t in [Z, noise_var, L, LA, wv] + list(kern_params.values())):
                 fold = tuple(X.shape[:2])
@@ -120,8 +128,8 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
             mu = lin.gemm(Kxt, wv, transA=True)
             if fold is not None:
                 mu = mu.reshape(fold + (mu.shape[-1],))
-            if self.model.F.factor.has_mean:
-                mu = mu + variables[self.model.mean]
+            if mean_fn is not None:
+                mu = mu + mean_fn
             LinvKxt = lin.trsm(L, Kxt)
             LAinvLinvKxt = lin.trsm(LA, LinvKxt)
             if self.diagonal_variance:
@@ -140,6 +148,8 @@ class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):
                 var = ops.gemm(LAinvLinvKxt, LAinvLinvKxt, transA=True, alpha=1.0, beta=1.0, out=var)
                 if not self.noise_free:
                     var = var + torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0) * noise_var.unsqueeze(-2)
+            if wide:
+                mu, var = mu.float(), var.float()
         return mu, var
 
     def compute(self, F, variables):
