@@ -84,6 +84,13 @@ class BatchInferenceLoop(GradLoop):
         st = getattr(self, '_gstate', None)
         if st is None or st.get('flat') is not param_dict.flat or st.get('key') != key:
             st = self._gstate = {'n': 0, 'flat': param_dict.flat, 'key': key}
+        from ..modules.gp_modules._fused import Float32Guard
+        if 'graph' in st and st.get('f32_epoch') != Float32Guard.poll_all(dev):
+            # an SVGP module's float32 guard changed its level (condition number of Kuu crossed a limit): the captured launches carry the OLD
+            # form -- drop the graph, warm up once eagerly (the modules now pick the new form), capture again
+            for k in ('graph', 'loss', 'grad', 'data', 'ws_gen', 'f32_epoch'):
+                st.pop(k, None)
+            st['n'] = 1
         if 'graph' in st and st['ws_gen'] != _lib.workspace_generation(dev):
             # the library re-allocated its scratch since the capture (a larger call in between: a prediction, another module): the
             # captured kernels carry the OLD scratch addresses -- drop the graph, warm up once more eagerly, capture again
@@ -110,7 +117,7 @@ class BatchInferenceLoop(GradLoop):
                 loss_for_gradient.backward()
             if _lib.workspace_generation(dev) != gen0:      # the library never allocates inside a capture; belt and braces
                 raise RuntimeError('mxfusion_amd: the scratch workspace was re-allocated during hipGraph capture')
-            st.update(graph=g, loss=loss.detach(), grad=param_dict.flat.grad, data=[d for d in data], ws_gen=gen0)
+            st.update(graph=g, loss=loss.detach(), grad=param_dict.flat.grad, data=[d for d in data], ws_gen=gen0, f32_epoch=Float32Guard.epoch)
         for d, d0 in zip(data, st['data']):
             if d is not d0:
                 d0.copy_(d)

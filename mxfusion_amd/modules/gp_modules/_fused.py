@@ -86,6 +86,7 @@ class Float32Guard(object):
     default = None
     _instances = None
     _counter = 0
+    epoch = 0               # bumped on every level change of any owner: a holder of a captured hipGraph re-captures when it moved (batch_loop.py)
 
     def __init__(self, name='svgp'):
         import weakref
@@ -113,6 +114,16 @@ class Float32Guard(object):
         for g in cls.instances():
             g.tier, g._checked_first, g.cond_max, g.cond_last, g.switches = cls.EXPLICIT, False, 0.0, 0.0, 0
             g._stale = True
+
+    @classmethod
+    def poll_all(cls, dev):
+        """Fold in what every owner's finished calls have published (no synchronisation); returns the level epoch.  A replayed hipGraph runs
+        no Python, so its holder calls this before each replay and re-captures when the epoch moved (the captured launches carry the
+        form that was current at capture time)."""
+        if cls.enabled and cls.force is None:
+            for g in cls.instances():
+                g.poll(dev)
+        return cls.epoch
 
     @classmethod
     def report(cls, dev=None):
@@ -150,6 +161,7 @@ class Float32Guard(object):
                               'streaming stage runs in %s from now on.' % (cond, self.name, self.NAMES[self.tier], self.NAMES[t]))
             self.tier = t
             self.switches += 1
+            Float32Guard.epoch += 1
             return True
         return False
 

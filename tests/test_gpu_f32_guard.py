@@ -201,3 +201,68 @@ def test_two_layer_model_keeps_the_first_layer_on_the_fast_form():
     # step 1 is already evaluated in the right forms (first calls are checked synchronously); so are the later ones
     for l in losses[:3]:
         assert abs(l - ref) <= 1e-5 * abs(ref), (losses, ref, by_name)
+
+
+def test_replayed_hipgraph_follows_the_guard():
+    """BatchInferenceLoop(use_graph=True) replays captured launches without running any Python, so a captured step keeps the float32 form
+    that was current at capture time.  The loop polls the guards before every replay (Float32Guard.poll_all: no synchronisation) and
+    re-captures when a level changed: after the length-scale moves from 1 to 3 (cond_1 14 -> 1e6) the replayed step is the WHITENED one
+    and its loss matches the oracle again."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop
+    DT = 'float32'
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    t = lambda a: torch.as_tensor(f32(a)).cuda()
+    rng = np.random.default_rng(3)
+    B, Q, M = 2048, 8, 256
+    X = f32(rng.uniform(-3., 3., (B, Q)))
+    Y = f32(np.sin(X @ rng.standard_normal(Q))[:, None] + 0.05 * rng.standard_normal((B, 1)))
+    Z = f32(rng.uniform(-3., 3., (M, Q)))
+    qm, qW, qd = f32(0.3 * rng.standard_normal((M, 1))), f32(0.4 * rng.standard_normal((M, M)) / np.sqrt(M)), f32(rng.uniform(0.05, 0.5, M))
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=t(Z))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=t([0.02]))
+    kern = RBF(input_dim=Q, ARD=True, variance=t([1.0]), lengthscale=t(np.ones(Q)), dtype=DT)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=DT)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    loop = BatchInferenceLoop(use_graph=True)
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=loop, dtype=DT)
+    infr.initialize(X=X.shape, Y=Y.shape)
+    post = gp._extra_graphs[0]
+    infr.params[post.qU_mean], infr.params[post.qU_cov_W], infr.params[post.qU_cov_diag] = t(qm), t(qW), t(qd)
+    ex = infr.create_executor()
+    data = [t(X), t(Y)]
+
+    def oracle(ell):
+        T = O.T
+        val = lambda v_: infr.params[v_].double().cpu().numpy()
+        return -float(O.svgp_log_pdf(O.RBF(Q, ARD=True), T(X)[None], T(Y)[None], T(Z)[None], T(val(m.noise_var))[None], T(qm)[None], T(qW)[None],
+                                     T(val(post.qU_cov_diag))[None], {'rbf_lengthscale': T(val(kern.lengthscale))[None], 'rbf_variance': T(val(kern.variance))[None]},
+                                     jitter=1e-6)[0])
+
+    def step():
+        infr.params.zero_grad()
+        loss = loop.step(ex, data, infr.params)
+        torch.cuda.synchronize()
+        return float(loss)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        for _ in range(4):
+            l1 = step()                                   # two eager warm-ups, capture, replay
+        assert 'graph' in loop._gstate
+        g = gp.svgp_log_pdf._f32_guard()
+        assert g.tier == G.EXPLICIT and abs(l1 - oracle(1.0)) <= 1e-5 * abs(l1)
+        infr.params[kern.lengthscale] = t(np.full(Q, 3.0))      # written in place: the captured graph reads the new values
+        ref3 = oracle(3.0)
+        step()                                            # the OLD (explicit) graph runs once more and publishes cond ~ 1e6
+        losses = [step() for _ in range(3)]               # poll -> level change -> eager whitened warm-up -> capture -> replay
+        assert g.tier == G.WHITENED and 'graph' in loop._gstate
+        for l in losses:
+            assert abs(l - ref3) <= 1e-5 * abs(ref3), (losses, ref3)
