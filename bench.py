@@ -475,6 +475,26 @@ def _pmc_traffic(stem):
     return None, None
 
 
+def box_spread():
+    """The same default command on other boxes of this pool (committed JSON lines, newest round's profiles/r<NN>_bench_full*.json): the step and the
+    Gram roofline vary by a few per cent with the box's power-limited clocks -- reported next to this run's own numbers."""
+    import glob
+    out = []
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench_full*.json')))
+    newest = max([os.path.basename(f)[:3] for f in files] or ['r00'])
+    for f in files:
+        if not os.path.basename(f).startswith(newest):
+            continue
+        try:
+            with open(f) as fh:
+                d = json.loads(fh.read().strip().splitlines()[-1])
+            out.append({"file": 'profiles/' + os.path.basename(f), "ms_per_step": d.get("ms_per_step"), "roofline_frac": (d.get("roofline") or {}).get("frac"),
+                        "roofline_mfma_frac": (d.get("roofline_mfma") or {}).get("frac")})
+        except (OSError, ValueError, IndexError):
+            continue
+    return out
+
+
 def gram_roofline(N, Q, dtype, reps=200):
     """RBF Gram at N x N, Q: algorithmic bytes = N*N*sizeof written + 2*N*Q*sizeof read, timed with HIP
     events on the stream the kernel is launched on (torch's current stream).  200 timed launches behind 20 untimed ones.  The launch time
@@ -837,6 +857,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q
         torch.cuda.empty_cache()
+        out["other_boxes"] = box_spread()
         out["roofline"] = gram_roofline(N, Q, args.dtype)
         out["roofline_mfma"] = mfma_roofline(M, N * S_local, args.dtype)
         if args.dtype == 'float32':
