@@ -85,7 +85,8 @@ def _nrm(a, b):
 
 
 @pytest.mark.parametrize('B,M,Q,P,S,kind', [(512, 128, 8, 1, 1, 'rbf'), (256, 256, 3, 1, 2, 'rbf'), (512, 128, 8, 2, 1, 'rbf'), (768, 128, 12, 1, 1, 'rbf'),
-                                            (512, 256, 8, 1, 1, 'matern52'), (256, 128, 5, 3, 2, 'matern32')])
+                                            (512, 256, 8, 1, 1, 'matern52'), (256, 128, 5, 3, 2, 'matern32'), (768, 384, 8, 1, 1, 'rbf'), (128, 128, 4, 1, 2, 'matern12'),
+                                            (1024, 640, 6, 1, 1, 'rbf')])
 def test_whitened_form_matches_the_oracle_small(B, M, Q, P, S, kind):
     """Values and all gradients of the whitened float32 call against the oracle's autograd, across the launch shapes (one / several output
     columns: fused / separate U; Q <= 8 / > 8: blocked / row-major T; 128- and 256-row tiles; sampled inputs), at a length-scale where Kuu
