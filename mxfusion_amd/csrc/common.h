@@ -75,7 +75,7 @@ struct mxf_ctx {
     hipStream_t side2 = nullptr;
     hipStream_t potrf_aux = nullptr;                        // look-ahead stream of the blocked Cholesky (chol.hip)
     hipEvent_t ev_pa = nullptr, ev_pb = nullptr, ev_ph = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr, ev_v = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
@@ -213,8 +213,7 @@ static inline bool mxf_side_init(mxf_ctx* h) {
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_v, hipEventDisableTiming) != hipSuccess) return false;
+        hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }
 

@@ -34,7 +34,6 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ev_aux) (void)hipEventDestroy(h->ev_aux);
     if (h->ev_aux2) (void)hipEventDestroy(h->ev_aux2);
     if (h->ev_su) (void)hipEventDestroy(h->ev_su);
-    if (h->ev_v) (void)hipEventDestroy(h->ev_v);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->potrf_aux) (void)hipStreamDestroy(h->potrf_aux);
