@@ -27,6 +27,10 @@ for dtype in ('float32', 'float64'):
             tr.append((it, float(loss.detach())))
     info = int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())
     ls = infr.params[m.Y.factor.kernel.lengthscale].double().cpu().numpy()
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    torch.cuda.synchronize()
+    g = m.Y.factor.svgp_log_pdf._f32_guard()
+    print(dtype, 'guard: level', Float32Guard.NAMES[g.tier], 'switches', g.switches, 'cond max %.3e last %.3e' % (g.cond_max, g.cond_last), flush=True)
     out[dtype] = (tr, info, ls, float(infr.params[m.noise_var]))
     del infr, m, q, ex
     torch.cuda.empty_cache()
