@@ -1317,9 +1317,15 @@ int sgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int64_t B, int64_t M, int 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
     CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); CONV(1, noise, noised);
     MXF_HIP(h, hipMemsetAsync(sc, 0, 16 * sizeof(D), st));
+    // (r04) cond_1(Kuu + jitter I) is published exactly as the SVGP call does (mxf_svgp_cond_slot / mxf_svgp_last_cond): the float32 form of
+    // this bound feeds a float32 Psi2 into C = Kuu + Psi2 / s2 and K^-1 Psi2 K^-1 -- ELBO 7e-6 at cond 3e4, a non-PD C at 1e6 -- and the
+    // module's guard widens the call to float64 above its limit
+    if (!mxf_cond_init(h)) MXF_FAIL(h, -4, "mxf_sgp_logpdf: cannot allocate the condition words");
+    MXF_HIP(h, hipMemsetAsync(h->cond_dev, 0, 2 * sizeof(double), st));
     int rc;
     rc = mxf_gram(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, nullptr, 0, jitter, MXF_WRITE, Lm, M, MM, st);   // Kuu :69-72
     if (rc) return rc;
+    hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     MXF_HIP(h, hipMemcpyAsync(Cm, Lm, MM * sizeof(D), hipMemcpyDeviceToDevice, st));
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st);                                  // L :77
     if (rc) return rc;
@@ -1327,6 +1333,8 @@ int sgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int64_t B, int64_t M, int 
     if (rc) return rc;
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);
     if (rc) return rc;
+    hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
+    hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, h->cond_host + 2 * h->cond_slot);
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // streaming statistics: Psi2 = Kuf Kuf^T (TN on the transposed Gram), psi1 = Kuf Y, ups = |Y|^2

@@ -328,13 +328,20 @@ class SVGPMatLogPdfFn(torch.autograd.Function):
 
 
 class SGPLogPdfFn(torch.autograd.Function):
-    """mxf_sgp_logpdf for ONE sample (arrays carry a unit sample axis); returns logL (1,), wv, L, LA."""
+    """mxf_sgp_logpdf for ONE sample (arrays carry a unit sample axis); returns logL (1,), wv, L, LA.  The float32 form of the Titsias
+    bound has the same conditioning limit as the explicit SVGP form (a float32 Psi2 inside C = Kuu + Psi2 / s2 and K^-1 Psi2 K^-1: ELBO
+    7e-6 at cond_1(Kuu) 3e4, a non-PD C at 1e6) and no whitened form: above Float32Guard.LIMIT the owner's guard widens the call."""
 
     @staticmethod
-    def forward(ctx, kind, ard, jitter, X, Y, Z, noise, ls, var):
-        want = any(ctx.needs_input_grad[3:])
-        r = ops.sgp_logpdf(kind, X[0], Y[0], Z[0], noise.reshape(-1), ls.reshape(-1), var.reshape(-1), ard, jitter=jitter, gscale=1.0,
-                           want_grad=want)
+    def forward(ctx, guard, kind, ard, jitter, X, Y, Z, noise, ls, var):
+        want = any(ctx.needs_input_grad[4:])
+
+        def run(tier):
+            cast = (lambda t: t.double()) if tier == Float32Guard.F64 else (lambda t: t)
+            r = ops.sgp_logpdf(kind, cast(X[0]), cast(Y[0]), cast(Z[0]), cast(noise.reshape(-1)), cast(ls.reshape(-1)), cast(var.reshape(-1)), ard, jitter=jitter,
+                               gscale=1.0, want_grad=want)
+            return _narrow(r) if tier == Float32Guard.F64 else r
+        r = _guarded(guard, X.device, X.dtype == torch.float32, False, run) if X.is_cuda else run(Float32Guard.EXPLICIT)
         if want:
             ctx.grads = (r['dX'], r['dY'], r['dZ'], r['dnoise'], r['dls'], r['dvar'])
             ctx.shapes = tuple(t.shape for t in (X, Y, Z, noise, ls, var))
@@ -344,8 +351,8 @@ class SGPLogPdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         c = g.sum()
-        out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[3:])]
-        return (None, None, None) + tuple(out)
+        out = [(grad.reshape(shp) * c) if need else None for grad, shp, need in zip(ctx.grads, ctx.shapes, ctx.needs_input_grad[4:])]
+        return (None, None, None, None) + tuple(out)
 
 
 Float32Guard.default = Float32Guard('svgp (shared default)')

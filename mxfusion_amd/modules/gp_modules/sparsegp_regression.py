@@ -29,6 +29,14 @@ class SparseGPRegressionLogPdf(VariationalInference):
         self.log_pdf_scaling = 1          # set but never used by the reference either
         self.jitter = jitter
 
+    def _f32_guard(self):
+        """This algorithm object's float32 validity guard (its own condition slot; levels explicit float32 / float64: _fused.Float32Guard)."""
+        g = getattr(self, '_guard', None)
+        if g is None:
+            from ._fused import Float32Guard
+            g = self._guard = Float32Guard('sgp')
+        return g
+
     def compute(self, F, variables):
         X = variables[self.model.X]
         Y = variables[self.model.Y]
@@ -47,7 +55,7 @@ class SparseGPRegressionLogPdf(VariationalInference):
         args = (X, Y, Z, noise_var, ls, var)
         S = max(t.shape[0] for t in args)
         pick = lambda t, s: t[s:s + 1] if t.shape[0] > 1 else t
-        outs = [SGPLogPdfFn.apply(kind, ard, float(self.jitter), *[pick(t, s) for t in args]) for s in range(S)]
+        outs = [SGPLogPdfFn.apply(self._f32_guard(), kind, ard, float(self.jitter), *[pick(t, s) for t in args]) for s in range(S)]
         logL = torch.cat([o[0] for o in outs])
         with torch.no_grad():      # :99-106 persist sample 0 only
             self.set_parameter(variables, self.graphs[1].wv, outs[0][1])
