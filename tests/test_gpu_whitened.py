@@ -126,3 +126,19 @@ def test_whitened_form_holds_the_bar_where_the_explicit_form_fails(ell):
     if ell >= 3.0:
         assert rel_e > 1e-5
     assert errs_w['dW'] < errs_e['dW']
+
+
+def test_whitened_form_at_the_bench_shape_vs_oracle():
+    """BASELINE configs[2]'s shape for one sample (N = 65 536, M = 1 024, Q = 8) at length-scale 3 (cond_1(Kuu) ~ 1e6): the whitened float32
+    call against the oracle's value and autograd gradients -- ELBO to 1e-5, every gradient to 1e-3 normwise."""
+    from mxfusion_amd import _lib
+    a = _inputs(65536, 1024, 8, 1, 3.0, seed=0)
+    a['var'] = np.array([1.0])
+    ref, gref = _oracle(a)
+    w = _run(a, _lib.FORM_WHITENED)
+    rel = abs(w['logL'][0] - ref[0]) / abs(ref[0])
+    errs = {k: _nrm(w[k], g) for k, g in gref.items()}
+    print('N 65536: whitened ELBO rel %.2e' % rel, {k: '%.1e' % v for k, v in errs.items()})
+    assert rel <= 1e-5, rel
+    for k, v in errs.items():
+        assert v <= 1e-3, (k, v)
