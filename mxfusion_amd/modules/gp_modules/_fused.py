@@ -137,7 +137,8 @@ class Float32Guard(object):
         return {'kuu_cond_max': max([g.cond_max for g in gs] or [0.0]),
                 'float32_fallback_active': any(g.tier == cls.F64 for g in gs),
                 'float32_whitened_active': any(g.tier == cls.WHITENED for g in gs),
-                'float32_tiers': {('%s#%d' % (g.name, g.slot)): cls.NAMES[g.tier if cls.force is None else cls.force] + ('' if cls.force is None else ' (forced)')
+                'float32_tiers': {('%s#%d' % (g.name, g.slot)): ('float64 inputs' if getattr(g, 'f64_inputs', False) else
+                                                                    cls.NAMES[g.tier if cls.force is None else cls.force] + ('' if cls.force is None else ' (forced)'))
                                   for g in gs},
                 'float32_guard': bool(cls.enabled)}
 
@@ -206,6 +207,7 @@ def _guarded(guard, dev, is_f32, whitened_ok, run):
     """Run `run(tier)` under `guard`: picks the level, configures the handle (form + condition slot), re-runs an owner's first call when its
     synchronous check asks for a higher level.  run(tier) evaluates the call in float32 (EXPLICIT / WHITENED) or widened to float64 (F64)."""
     g = guard if guard is not None else Float32Guard.default
+    g.f64_inputs = not is_f32
     if not is_f32:
         g.configure(dev, g.EXPLICIT)
         return run(g.EXPLICIT)
