@@ -82,6 +82,7 @@ class SVGPRegressionLogPdf(VariationalInference):
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
+        Z, mu, S_W, S_diag = self._pad_inducing(X, Y, Z, noise_var, mu, S_W, S_diag, var)
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
         scaling = float(self.log_pdf_scaling)
         if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
@@ -102,6 +103,32 @@ class SVGPRegressionLogPdf(VariationalInference):
         self._last_info = info
         return logL
 
+
+    PAD_MIN = 96        # inducing-point counts from here on are padded to the next multiple of 128 (float32 training calls)
+
+    def _pad_inducing(self, X, Y, Z, noise_var, mu, S_W, S_diag, var):
+        """The split-GEMM float32 training path needs M % 16 == 0 (its 256-row tiles and the whitened form M % 256 / 128 == 0); a natural choice
+        such as M = 1000 or 500 would fall to the generic float32 kernels (plain f32 MFMA rate, and float64 above cond 3e3).  Here M is padded
+        to the next multiple of 128 with DECOUPLED inducing points: inputs 1e6 (1 + i) away along the first coordinate -- every stationary
+        covariance with the data and with the other inducing points underflows to exactly 0, so Kuu gains a diagonal block (variance + jitter) I
+        -- and q(u) on them equal to that prior (mean 0, no W, diagonal variance + jitter): the padded block adds 0 to the bound and to
+        every gradient (its KL term is stationary at s = variance + jitter), autograd drops the padded slices.  Exact in the algebra; in
+        float32 the padded diagonal differs from the core's float64 (variance + jitter) by 1e-8 relative, a second-order 1e-16 in the bound."""
+        M = Z.shape[-2]
+        if not (X.is_cuda and X.dtype == torch.float32 and torch.is_grad_enabled() and M >= self.PAD_MIN and M % 128 != 0):
+            return Z, mu, S_W, S_diag
+        if noise_var.numel() != noise_var.shape[0] or Y.shape[-1] > self.PMAX or X.shape[-1] > 16:     # paths that never take the split kernels
+            return Z, mu, S_W, S_diag
+        npad = (M + 127) // 128 * 128 - M
+        Q, P = Z.shape[-1], mu.shape[-1]
+        far = torch.zeros(npad, Q, dtype=Z.dtype, device=Z.device)
+        far[:, 0] = 1e6 * (1.0 + torch.arange(npad, dtype=Z.dtype, device=Z.device))
+        Zp = torch.cat([Z, far.unsqueeze(0).expand(Z.shape[0], npad, Q)], -2)
+        mup = torch.cat([mu, torch.zeros(mu.shape[0], npad, P, dtype=mu.dtype, device=mu.device)], -2)
+        Wp = torch.nn.functional.pad(S_W, (0, npad, 0, npad))
+        Sd = max(S_diag.shape[0], var.shape[0])
+        sdp = torch.cat([S_diag.expand(Sd, M), (var.reshape(var.shape[0], 1) + float(self.jitter)).expand(Sd, npad)], -1)
+        return Zp, mup, Wp, sdp
 
     def _compute_materialised(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         """Combination kernels (add_kernel.py:44-68, multiply_kernel.py:44-67): Kuu / Kuf / Kdiag come from kern.K (each sub-kernel one

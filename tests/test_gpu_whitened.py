@@ -142,3 +142,70 @@ def test_whitened_form_at_the_bench_shape_vs_oracle():
     assert rel <= 1e-5, rel
     for k, v in errs.items():
         assert v <= 1e-3, (k, v)
+
+
+@pytest.mark.parametrize('M,ell', [(1000, 1.0), (1000, 2.2), (200, 1.5)])
+def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_split_path(M, ell):
+    """M = 1000 (or 200) inducing points through the module in float32: the bridge pads them to 1024 (256) with decoupled points (far away,
+    q(u) = prior on them), the call runs the split-GEMM path (explicit or whitened by the guard) -- and the bound and the gradients of the
+    REAL parameters equal the oracle's for the unpadded model (1e-5 / 2e-3)."""
+    import warnings
+    from mxfusion_amd import Model, Variable, _lib
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    t = lambda a: torch.as_tensor(f32(a)).cuda()
+    rng = np.random.default_rng(M)
+    B, Q = 4096, 8
+    X = f32(rng.uniform(-3., 3., (B, Q)))
+    Y = f32(np.sin(X @ rng.standard_normal(Q))[:, None] + 0.05 * rng.standard_normal((B, 1)))
+    Z = f32(rng.uniform(-3., 3., (M, Q)))
+    qm, qW, qd = f32(0.3 * rng.standard_normal((M, 1))), f32(0.4 * rng.standard_normal((M, M)) / np.sqrt(M)), f32(rng.uniform(0.05, 0.5, M))
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=t(Z))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=t([0.02]))
+    kern = RBF(input_dim=Q, ARD=True, variance=t([1.3]), lengthscale=t(np.full(Q, ell)), dtype='float32')
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype='float32')
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=BatchInferenceLoop(), dtype='float32')
+    infr.initialize(X=X.shape, Y=Y.shape)
+    post = gp._extra_graphs[0]
+    infr.params[post.qU_mean], infr.params[post.qU_cov_W], infr.params[post.qU_cov_diag] = t(qm), t(qW), t(qd)
+    ex = infr.create_executor()
+    dev = torch.cuda.current_device()
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        ex(t(X), t(Y))                                   # (first call: the guard's synchronous check may move the level)
+        infr.params.zero_grad()
+        _lib.svgp_timing(dev, True)
+        try:
+            loss, lfg = ex(t(X), t(Y))
+            lfg.backward()
+            stages = _lib.svgp_timing_read(dev)
+        finally:
+            _lib.svgp_timing(dev, False)
+    assert 'planes_a' in stages and 't_gemm' in stages, stages          # the split path, although M % 16 != 0
+    # the oracle on the UNPADDED model, at the values the module holds
+    val = lambda v_: infr.params[v_].double().cpu().numpy()
+    names = ('Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in zip(names, (Z, val(m.noise_var), qm, qW, val(post.qU_cov_diag), val(kern.lengthscale), val(kern.variance)))}
+    ref = -O.svgp_log_pdf(O.RBF(Q, ARD=True), O.T(X)[None], O.T(Y)[None], lv['Z'][None], lv['noise'][None], lv['qm'][None], lv['qW'][None], lv['qd'][None],
+                          {'rbf_lengthscale': lv['ls'][None], 'rbf_variance': lv['var'][None]}, jitter=1e-6)[0]
+    gref = dict(zip(names, torch.autograd.grad(ref, [lv[n] for n in names])))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    fg = infr.params.flat.grad
+
+    def grad_of(var):
+        o, n, shape = infr.params._slices[var.uuid]
+        return fg[o:o + n].view(shape).double().cpu().numpy()
+    for var, n in ((m.Z, 'Z'), (post.qU_mean, 'qm'), (post.qU_cov_W, 'qW')):
+        assert grad_of(var).shape == gref[n].shape
+        assert _nrm(grad_of(var), gref[n].numpy()) <= 2e-3, (n, _nrm(grad_of(var), gref[n].numpy()))
+    for var, n in ((kern.lengthscale, 'ls'), (kern.variance, 'var'), (m.noise_var, 'noise'), (post.qU_cov_diag, 'qd')):     # softplus-transformed: d/draw = d/dvalue * sigmoid(raw)
+        raw = infr.params.raw(var).double().cpu().numpy()
+        assert _nrm(grad_of(var), gref[n].numpy().reshape(raw.shape) / (1.0 + np.exp(-raw))) <= 2e-3, n
