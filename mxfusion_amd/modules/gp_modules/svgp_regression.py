@@ -82,7 +82,8 @@ class SVGPRegressionLogPdf(VariationalInference):
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
-        Z, mu, S_W, S_diag = self._pad_inducing(X, Y, Z, noise_var, mu, S_W, S_diag, var)
+        X, Y, row_corr = self._pad_rows(X, Y, Z, noise_var, ls, var)                       # (rows first: the padded inducing points must clear them too)
+        Z, mu, S_W, S_diag = self._pad_inducing(X, Y, Z, noise_var, mu, S_W, S_diag, ls, var)
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)
         scaling = float(self.log_pdf_scaling)
         if all(_S(t) == 1 for t in shared):      # (shared X with sampled Y runs natively too: the samples share the Kuf columns)
@@ -101,19 +102,34 @@ class SVGPRegressionLogPdf(VariationalInference):
             logL = torch.cat([o[0] for o in outs])
             info = ops.merge_info(*[o[1] for o in outs])
         self._last_info = info
+        if row_corr is not None:
+            logL = logL - scaling * row_corr
         return logL
 
 
     PAD_MIN = 96        # inducing-point counts from here on are padded to the next multiple of 128 (float32 training calls)
 
-    def _pad_inducing(self, X, Y, Z, noise_var, mu, S_W, S_diag, var):
+    @staticmethod
+    def _far_coordinates(X, Z, ls, n, sign):
+        """n points on the first coordinate axis, beyond the data and the inducing inputs and 128 length-scales apart: every stationary
+        covariance between them and anything real (and among themselves) is < exp(-128): exactly 0 in float32, 1e-56 in the float64 core.
+        Their SCALED coordinates stay below 3e4 + range / lengthscale, inside the f16 range the reverse pass splits coordinates into
+        (1e6-style offsets overflow it: inf * 0 there).  Built with device ops, no synchronisation; not differentiated."""
+        with torch.no_grad():
+            base = X[..., 0].abs().amax() + Z[..., 0].abs().amax()
+            step = 128.0 * ls.reshape(ls.shape[0], -1)[:, 0].amax()
+            far = torch.zeros(n, X.shape[-1], dtype=X.dtype, device=X.device)
+            far[:, 0] = sign * (base + step * (1.0 + torch.arange(n, dtype=X.dtype, device=X.device)))
+        return far
+
+    def _pad_inducing(self, X, Y, Z, noise_var, mu, S_W, S_diag, ls, var):
         """The split-GEMM float32 training path needs M % 16 == 0 (its 256-row tiles and the whitened form M % 256 / 128 == 0); a natural choice
-        such as M = 1000 or 500 would fall to the generic float32 kernels (plain f32 MFMA rate, and float64 above cond 3e3).  Here M is padded
-        to the next multiple of 128 with DECOUPLED inducing points: inputs 1e6 (1 + i) away along the first coordinate -- every stationary
-        covariance with the data and with the other inducing points underflows to exactly 0, so Kuu gains a diagonal block (variance + jitter) I
-        -- and q(u) on them equal to that prior (mean 0, no W, diagonal variance + jitter): the padded block adds 0 to the bound and to
-        every gradient (its KL term is stationary at s = variance + jitter), autograd drops the padded slices.  Exact in the algebra; in
-        float32 the padded diagonal differs from the core's float64 (variance + jitter) by 1e-8 relative, a second-order 1e-16 in the bound."""
+        such as M = 1000 or 500 would fall to the generic float32 kernels (75 instead of 21 ms per step at M = 1000, and float64 above cond
+        3e3).  Here M is padded to the next multiple of 128 with DECOUPLED inducing points (_far_coordinates: every covariance with the data
+        and with the other inducing points is 0, so Kuu gains a diagonal block (variance + jitter) I) and q(u) on them equal to that prior
+        (mean 0, no W, diagonal variance + jitter): the padded block adds 0 to the bound and to every gradient (its KL term is stationary
+        at s = variance + jitter), autograd drops the padded slices.  Exact in the algebra; in float32 the padded diagonal differs from the
+        core's float64 (variance + jitter) by 1e-8 relative, a second-order 1e-16 in the bound."""
         M = Z.shape[-2]
         if not (X.is_cuda and X.dtype == torch.float32 and torch.is_grad_enabled() and M >= self.PAD_MIN and M % 128 != 0):
             return Z, mu, S_W, S_diag
@@ -121,14 +137,33 @@ class SVGPRegressionLogPdf(VariationalInference):
             return Z, mu, S_W, S_diag
         npad = (M + 127) // 128 * 128 - M
         Q, P = Z.shape[-1], mu.shape[-1]
-        far = torch.zeros(npad, Q, dtype=Z.dtype, device=Z.device)
-        far[:, 0] = 1e6 * (1.0 + torch.arange(npad, dtype=Z.dtype, device=Z.device))
+        far = self._far_coordinates(X, Z, ls, npad, 1.0)
         Zp = torch.cat([Z, far.unsqueeze(0).expand(Z.shape[0], npad, Q)], -2)
         mup = torch.cat([mu, torch.zeros(mu.shape[0], npad, P, dtype=mu.dtype, device=mu.device)], -2)
         Wp = torch.nn.functional.pad(S_W, (0, npad, 0, npad))
         Sd = max(S_diag.shape[0], var.shape[0])
         sdp = torch.cat([S_diag.expand(Sd, M), (var.reshape(var.shape[0], 1) + float(self.jitter)).expand(Sd, npad)], -1)
         return Zp, mup, Wp, sdp
+
+    def _pad_rows(self, X, Y, Z, noise_var, ls, var):
+        """The same for the DATA rows: the split kernels need B % 16 == 0 (the whitened form S B % 256 == 0), and a data set of 65 000 or 20 011
+        rows would fall to the generic float32 kernels (3x slower).  B is padded to the next multiple of 256 with rows whose inputs lie on the
+        NEGATIVE side of the first coordinate (_far_coordinates: every covariance with the inducing points, padded ones included, is 0) and
+        whose targets are 0: such a row contributes exactly -P/2 (log 2 pi + log noise) - P/2 variance / noise to the data term
+        (svgp_regression.py:93-107 with k_n = 0, y_n = 0), which is subtracted again in closed form (autograd carries the subtraction into the
+        noise and variance gradients)."""
+        B, P, M = X.shape[-2], Y.shape[-1], Z.shape[-2]
+        if not (X.is_cuda and X.dtype == torch.float32 and torch.is_grad_enabled() and B >= 256 and B % 256 != 0 and M >= self.PAD_MIN):      # (M itself is padded next)
+            return X, Y, None
+        if noise_var.numel() != noise_var.shape[0] or P > self.PMAX or X.shape[-1] > 16:
+            return X, Y, None
+        npad = (B + 255) // 256 * 256 - B
+        far = self._far_coordinates(X, Z, ls, npad, -1.0)
+        Xp = torch.cat([X, far.unsqueeze(0).expand(X.shape[0], npad, X.shape[-1])], -2)
+        Yp = torch.cat([Y, torch.zeros(Y.shape[0], npad, P, dtype=Y.dtype, device=Y.device)], -2)
+        nz, vk = noise_var.reshape(noise_var.shape[0]), var.reshape(var.shape[0])
+        corr = npad * (-0.5 * P * (1.8378770664093453 + torch.log(nz)) - 0.5 * P * vk / nz)
+        return Xp, Yp, corr
 
     def _compute_materialised(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         """Combination kernels (add_kernel.py:44-68, multiply_kernel.py:44-67): Kuu / Kuf / Kdiag come from kern.K (each sub-kernel one

@@ -144,8 +144,8 @@ def test_whitened_form_at_the_bench_shape_vs_oracle():
         assert v <= 1e-3, (k, v)
 
 
-@pytest.mark.parametrize('M,ell', [(1000, 1.0), (1000, 2.2), (200, 1.5)])
-def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_split_path(M, ell):
+@pytest.mark.parametrize('M,ell,B', [(1000, 1.0, 4096), (1000, 2.2, 4096), (200, 1.5, 4096), (512, 1.0, 4001), (1000, 2.2, 3000)])
+def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_split_path(M, ell, B):
     """M = 1000 (or 200) inducing points through the module in float32: the bridge pads them to 1024 (256) with decoupled points (far away,
     q(u) = prior on them), the call runs the split-GEMM path (explicit or whitened by the guard) -- and the bound and the gradients of the
     REAL parameters equal the oracle's for the unpadded model (1e-5 / 2e-3)."""
@@ -158,7 +158,7 @@ def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_s
     f32 = lambda a: np.asarray(a, dtype=np.float32)
     t = lambda a: torch.as_tensor(f32(a)).cuda()
     rng = np.random.default_rng(M)
-    B, Q = 4096, 8
+    Q = 8            # (B = 4001 / 3000: the data rows are padded too -- to the next multiple of 256, with the padded rows' closed-form contribution subtracted)
     X = f32(rng.uniform(-3., 3., (B, Q)))
     Y = f32(np.sin(X @ rng.standard_normal(Q))[:, None] + 0.05 * rng.standard_normal((B, 1)))
     Z = f32(rng.uniform(-3., 3., (M, Q)))
@@ -189,7 +189,8 @@ def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_s
             stages = _lib.svgp_timing_read(dev)
         finally:
             _lib.svgp_timing(dev, False)
-    assert 'planes_a' in stages and 't_gemm' in stages, stages          # the split path, although M % 16 != 0
+    g = gp.svgp_log_pdf._f32_guard()
+    assert 'planes_a' in stages and 't_gemm' in stages, (stages, g.tier, g.cond_max, g.cond_last)          # the split path, although M % 16 != 0
     # the oracle on the UNPADDED model, at the values the module holds
     val = lambda v_: infr.params[v_].double().cpu().numpy()
     names = ('Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
@@ -209,3 +210,35 @@ def test_inducing_point_counts_that_are_not_tile_multiples_are_padded_onto_the_s
     for var, n in ((kern.lengthscale, 'ls'), (kern.variance, 'var'), (m.noise_var, 'noise'), (post.qU_cov_diag, 'qd')):     # softplus-transformed: d/draw = d/dvalue * sigmoid(raw)
         raw = infr.params.raw(var).double().cpu().numpy()
         assert _nrm(grad_of(var), gref[n].numpy().reshape(raw.shape) / (1.0 + np.exp(-raw))) <= 2e-3, n
+
+
+def test_padding_keeps_the_gradient_of_latent_inputs():
+    """Latent inputs (X requires grad) with both paddings in play (M = 200 -> 256, B = 1000 -> 1024): the padded points' coordinates stay inside
+    the f16 range of the reverse pass (a 1e6-style offset gives inf * 0 there), dX of the real rows equals the oracle's and has the unpadded shape."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    rng = np.random.default_rng(77)
+    B, M, Q = 1000, 200, 4
+    X = rng.uniform(-2., 2., (B, Q))
+    Y = np.sin(X.sum(1))[:, None] + 0.05 * rng.standard_normal((B, 1))
+    Z = rng.uniform(-2., 2., (M, Q))
+    qm, qW, qd = 0.3 * rng.standard_normal((M, 1)), 0.3 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
+    ls, var, noise = np.full(Q, 1.2), np.array([1.1]), np.array([0.05])
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()[None]
+    kern = RBF(input_dim=Q, ARD=True, dtype='float32')
+    fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, 1.0, Float32Guard('padding-test')
+    Xd, Zd = t(X).requires_grad_(True), t(Z).requires_grad_(True)
+    params = {kern.name + '_lengthscale': t(ls), kern.name + '_variance': t(var)}
+    got = fn._compute_columns(None, Xd, t(Y), Zd, t(noise), t(qm), t(qW), t(qd), kern, params)
+    gX, gZ = torch.autograd.grad(got.sum(), [Xd, Zd])
+    Xo, Zo = O.T(X).clone().requires_grad_(True), O.T(Z).clone().requires_grad_(True)
+    ref = O.svgp_log_pdf(O.RBF(Q, ARD=True), Xo[None], O.T(Y)[None], Zo[None], O.T(noise)[None], O.T(qm)[None], O.T(qW)[None], O.T(qd)[None],
+                         {'rbf_lengthscale': O.T(ls)[None], 'rbf_variance': O.T(var)[None]}, jitter=1e-6)[0]
+    rX, rZ = torch.autograd.grad(ref, [Xo, Zo])
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+    assert gX.shape == (1, B, Q) and gZ.shape == (1, M, Q)
+    assert torch.isfinite(gX).all() and torch.isfinite(gZ).all()
+    assert _nrm(gX[0].double().cpu().numpy(), rX.numpy()) <= 2e-3
+    assert _nrm(gZ[0].double().cpu().numpy(), rZ.numpy()) <= 2e-3
