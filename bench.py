@@ -429,12 +429,19 @@ def step_breakdown(infr, loop, Yd, lr, M, SB):
     ms = {k: v / n for k, v in acc.items()}
     out = {"step_breakdown_ms": {k: round(v, 4) for k, v in ms.items()}}
     pb = 4.0 * M * SB                                # two f16 planes per covariance
+    whitened = 'v_gemm' in ms                        # (whitened form: the second planes of the step are V^T, written by the V product's own epilogue)
     for key, name in (('planes_a', 'first'), ('planes_b', 'second')):
-        if key in ms:
+        if key in ms and not (whitened and key == 'planes_b'):
             out.setdefault("roofline_planes", {})[name] = {"bound": "hbm", "achieved": pb / ms[key] / 1e6, "peak": 8000.0, "unit": "GB/s",
                                                            "frac": pb / ms[key] / 1e6 / 8000.0, "ms_in_step": ms[key], "algorithmic_bytes": pb}
     if "roofline_planes" in out:
-        out["roofline_planes"]["kernel"] = "gram_planes_lean_kernel (Gram written as two f16 planes; whitened form: second = planes transposition, 8 bytes per element)"
+        out["roofline_planes"]["kernel"] = ("gram_planes_lean_kernel (Gram written as two f16 planes); whitened form: one Gram planes pass, the planes of V and V^T "
+                                            "come out of the V product (step_breakdown_ms.v_gemm; planes_b = the reduction of its partial sums of U)")
+    if whitened:
+        f = 2.0 * M * M * SB * sum(r + 1 for r in range(M // 256)) / (M // 256) ** 2 if M % 256 == 0 else 2.0 * M * M * SB
+        out["roofline_mfma_v_in_step"] = {"bound": "mfma", "kernel": "V = L^-1 Kuf inside the step (triangular A: flops counted per 256-row tile, k up to the tile's last row)",
+                                          "achieved": f / ms['v_gemm'] / 1e9, "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": f / ms['v_gemm'] / 1e9 / (2500.0 / 3),
+                                          "ms_in_step": ms['v_gemm'], "bytes_written": 2 * pb}
     if 't_gemm' in ms:
         f = 2.0 * M * M * SB
         out["roofline_mfma_in_step"] = {"bound": "mfma", "kernel": "T product inside the step", "achieved": f / ms['t_gemm'] / 1e9, "peak": 2500.0 / 3,

@@ -195,11 +195,15 @@ int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double 
  * largest magnitude sits near 2^13..2^14; as an operand of the next product its maxword is a word holding 8192.0f = scale 1) of the (M x N) operand whose contraction
  * index is its column -- element (m, n) at ((n / 16) * M + m) * 16 + n % 16 -- ready to be the operand of the next product; M % 128 == 0,
  * N % 256 == 0.  a_lower != 0: A is lower triangular (A[m][k] = 0 for k > m), the k loop of a row tile stops at its last row.
+ * Ct_planes != NULL: the same launch ALSO writes the planes of the transposed (N x M) operand -- element (n, m) at
+ * ((m / 16) * N + n) * 16 + m % 16 -- and, with a (M floats) and U (N floats) given, U[n] = sum_m a[m] (hi + lo)(m, n) in the planes' units
+ * (what the whitened tier needs of V = L^-1 Kuf: V for Phi = V V^T, V^T for T = Hh V, a^T V for the mean term -- one pass).
  * mxf_f16x2_planes_transpose turns the planes of an (R x K) operand into those of its transpose (K x R) (R, K multiples of 64; 4 bytes
  * read + 4 written per element, HBM bound); U != NULL: the same pass forms U[k] = scale[0] * sum_r a[r] x(r, k) (a: R floats, scale: one
  * float, both on the device).                                                                                                            */
 int mxf_gemm_f16x2_planes_out(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
-                              const void* B_planes, const void* B_maxword, void* C_planes, int a_lower, void* stream);
+                              const void* B_planes, const void* B_maxword, void* C_planes, void* Ct_planes, const void* a, void* U,
+                              int a_lower, void* stream);
 int mxf_f16x2_planes_transpose(mxf_handle h, int64_t R, int64_t K, const void* planes_in, void* planes_out, const void* a, const void* scale,
                                void* U, void* stream);
 

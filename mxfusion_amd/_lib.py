@@ -65,7 +65,7 @@ SIGNATURES = {
     'mxf_svgp_timing': [_i],
     'mxf_svgp_timing_read': [_c.POINTER(_d)],
     'mxf_svgp_cond_slot': [_i, _c.POINTER(_d), _c.POINTER(_d), _i],
-    'mxf_gemm_f16x2_planes_out': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    'mxf_gemm_f16x2_planes_out': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     'mxf_f16x2_planes_transpose': [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_comm_unique_id': [_vp],
     'mxf_comm_init': [_i, _i, _vp],

@@ -733,7 +733,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (whiten && !(use_split && split_mode == MXF_SPLIT_F16X2 && (M % 128) == 0 && (SB % 256) == 0))
         MXF_FAIL(h, -3, "mxf_svgp_logpdf: the whitened float32 form needs M %% 128 == 0, S B %% 256 == 0, Q <= 16, homoscedastic noise (see mxf_svgp_whitened_ok)");
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
-    if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); }
+    if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); acc((size_t)(M / 128) * SB, sizeof(float)); }
     if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
     else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
@@ -754,7 +754,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
                      gscr0 = (float*)cv.take<char>(gp_scr); gscr1 = (float*)cv.take<char>(gp_scr); }
     else { Kuf = cv.take<T>((size_t)M * SB); if (want_grad) Kfu = cv.take<T>((size_t)M * SB); }
     unsigned short* plLi = nullptr; D* ad = nullptr; T* aT = nullptr; float* sigf = nullptr;
-    if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); }
+    float* upart = nullptr;
+    if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); upart = cv.take<float>((size_t)(M / 128) * SB); }
+    // whitened tier: the planes of V^T (operand (n, k = m) of T = Hh V) go into the THIRD plane slots of the two big buffers (sized for the
+    // three-plane bf16 format; the whitened tier runs two-plane f16x2 only) -- the V product writes them next to V's own planes while other
+    // workgroups still read the Kfu planes, so they cannot share that buffer's first two slots
+    unsigned short* plVt = whiten ? plKfu + 2 * pl_big : nullptr;
+    const int64_t pVt = whiten ? (int64_t)((plKuf + 2 * pl_big) - plVt) : 0;
     float* hcs = nullptr; float* hrs = nullptr; float* hys = nullptr; D* hhs = nullptr; D* hbe2 = nullptr; float* hnz = nullptr;
     if (het_stream) { hcs = cv.take<float>(B); hrs = cv.take<float>(B); hys = cv.take<float>((size_t)(sY == 0 ? B : SB)); hhs = cv.take<D>(4); hbe2 = cv.take<D>(S); hnz = cv.take<float>(4); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
@@ -932,18 +938,41 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plLi, st, MXF_SPLIT_F16X2, limax);
         if (rc) return rc;
-        MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                                   // L^-1 planes ready
+        // a = L^-1 mu (float64, then the streaming dtype): the V product's epilogue forms U = a^T V from it
+        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                              // mu (second side stream)
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Linv, M, 0, mud, P, 0, 0.0, ad, P, 0, 1, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)ad, MP, aT, MP);
+        MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                                   // L^-1 planes and a ready
         // side stream: V = L^-1 Kuf, written as the planes of the (m, k = n) operand holding V / sigma * 2^14 (|v_n|^2 <= k_nn = sigma^2):
         // acc = (s_L L^-1) (Kfu / sigma^2 2^14)^T  ->  acc sigma / s_L.  L^-1 is lower triangular: a row tile's k loop stops at its last row.
+        // The SAME launch writes the planes of V^T (the (n, k = m) operand of T = Hh V) and, for one output column, the 128-row partial sums
+        // of U = a^T V (r04 late: a separate transposition + U pass over the planes took 3.3 ms of the 35 ms step -- 17 GB of traffic).
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
         MXF_T0(h, MXF_T_VGEMM, sd_);
         // (few samples per GPU: the Kuu chain on the caller's stream is the critical path -- both side-stream products leave it 40 CUs)
         const bool few = SB <= 2 * 192 * M;
         rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, few ? 40 : 0, split_mode, sigf, 1,
-                                     (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1);
+                                     (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1, plVt, pVt, P == 1 ? (const float*)aT : nullptr,
+                                     P == 1 ? upart : nullptr);
         if (rc) return rc;
         MXF_T1(h, MXF_T_VGEMM, sd_);
         MXF_STAGE(h, "V = Linv Kuf (sd)", sd_);
+        MXF_T0(h, MXF_T_PLANES_B, sd_);
+        if (P == 1) rc = mxf_upart_reduce_internal(h, SB, (int)(M / 128), upart, sigf, 1.f / 16384.f, (float*)(Text + M * SB), sd_);
+        else hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plVt,
+                                pVt, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
+        if (rc) return rc;
+        MXF_T1(h, MXF_T_PLANES_B, sd_);
+        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
+        // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T
+        MXF_T0(h, MXF_T_PSI2, sd_);
+        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                     few ? 202 : psi2_rb, split_mode, split_var, 1, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_T1(h, MXF_T_PSI2, sd_);
+        MXF_STAGE(h, "Phi (sd)", sd_);
     }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
@@ -953,40 +982,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
-    if (whiten) {
-        rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Linv, M, 0, mud, P, 0, 0.0, ad, P, 0, 1, 0, st);   // a = L^-1 mu
-        if (rc) return rc;
-        hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)ad, MP, aT, MP);
-    }
     MXF_STAGE(h, "Ki, w", st);
-    if (use_split) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                        // w (and a) ready: the Kfu planes + U pass / the transposition + U pass may start
-    if (whiten) {
-        // side stream: V planes -> planes of the (n, k = m) operand (into the Kfu planes' slot: V = L^-1 Kuf has consumed them) and, for one
-        // output column, U = a^T V in the same pass; P > 1: U from the transposed planes (one more read of them).  The T product waits for
-        // this pass, so it comes BEFORE Phi (r04: next to Phi on another stream it took 2.7x as long and the step did not move at 32
-        // samples, +0.1 ms at 4).
-        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_aux2, 0));
-        MXF_T0(h, MXF_T_PLANES_B, sd_);
-        rc = mxf_planes_transpose_internal(h, M, SB, plKuf, (int64_t)pl_big, plKfu, (int64_t)pl_big, (const float*)aT, sigf, 1.f / 16384.f,
-                                           P == 1 ? (float*)(Text + M * SB) : nullptr, sd_);
-        if (rc) return rc;
-        if (P > 1) {
-            hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plKfu,
-                               (int64_t)pl_big, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
-        }
-        MXF_T1(h, MXF_T_PLANES_B, sd_);
-        MXF_STAGE(h, "V^T planes + U (sd)", sd_);
-        MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
-        // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T: next to the T product
-        const bool few = SB <= 2 * 192 * M;
-        MXF_T0(h, MXF_T_PSI2, sd_);
-        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                     few ? 202 : psi2_rb, split_mode, split_var, 1, nullptr);
-        if (rc) return rc;
-        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
-        MXF_T1(h, MXF_T_PSI2, sd_);
-        MXF_STAGE(h, "Phi (sd)", sd_);
-    }
+    if (use_split && !whiten) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                             // w ready: the Kfu planes + U pass may start
     rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
     if (rc) return rc;
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
@@ -1056,7 +1053,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     MXF_T0(h, MXF_T_TGEMM, st);
     if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
-        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
+        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plVt, pVt, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
     else if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,

@@ -144,6 +144,12 @@ struct SplitArgs {
     unsigned short* Cp; int64_t pC;
     int64_t rot_div;
     int a_lower;                         // A is lower triangular (A[m][k] = 0 for k > m): a row tile's k loop ends at its last row
+    // CPL instantiations, optional: the same values ALSO as the planes of the transposed (N x K' = M) operand, element (n, m) at
+    // ((m / 16) * N + n) * 16 + m % 16 (through a wave-private LDS tile, 16-byte stores), and with avec the partial sums
+    // Upart[(m / 128) * N + n] = sum over the 128-row band of avec[m] * (hi + lo)(m, n)  (the whitened SVGP tier's V^T and a^T V)
+    unsigned short* Ct; int64_t pCt;
+    const float* avec; float* Upart;
+    int cp_nt;                           // bit 0: the planes, bit 1: the transposed planes are stored non-temporally
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
@@ -671,6 +677,11 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         // plane, and a store instruction covers 32 rows x 32 bytes = 1 KB contiguous of the 16-column block.
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        // a of this tile's rows, fetched BEFORE the plane stores are issued and parked in LDS behind the wave tiles: a vector load later in
+        // the epilogue waits for vmcnt(0), i.e. for this item's stores to retire (16 such stalls per item cost 1.8 ms of the whitened step)
+        float* alds = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(&smem[0][0][0]) + (NTH / 64) * (32 * 68));
+        float aval = 0.f;
+        if (g.Ct && g.avec && tid < WBMt) aval = g.avec[m0 + tid];
 #pragma unroll
         for (int x = 0; x < XT; ++x) {
             const int64_t row = m0 + 32 * XT * wh + 32 * x + li;
@@ -694,9 +705,83 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
                     const int64_t col = n0 + 64 * wq + 32 * y + 8 * (q + lk);
                     unsigned short* p = g.Cp + ((col >> 4) * g.M + row) * 16 + (col & 15);
                     const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
-                    *reinterpret_cast<u32x4*>(p) = vh;
-                    *reinterpret_cast<u32x4*>(p + g.pC) = vl;
+                    if (g.cp_nt & 1) { __builtin_nontemporal_store(vh, reinterpret_cast<u32x4*>(p)); __builtin_nontemporal_store(vl, reinterpret_cast<u32x4*>(p + g.pC)); }
+                    else { *reinterpret_cast<u32x4*>(p) = vh; *reinterpret_cast<u32x4*>(p + g.pC) = vl; }
                 }
+        }
+        if (g.Ct) {
+            // The transposed planes: rows live on lanes, so a lane never holds two consecutive m of one n -- every 32 (m) x 64 (n) slice of
+            // this wave goes through a wave-private LDS tile (the A ring is free between two work items): written row-wise (8 bytes = four n
+            // per lane and quad), read back column-wise as 16-bit elements (all lanes of a read on one or two tile rows: conflict-free with
+            // the 68-element row stride) into 16-byte units (n, eight consecutive m); a store instruction covers 32 n x 32 bytes = 1 KB.
+            constexpr int RS = 68;                             // tile row stride in 16-bit elements (136 bytes)
+            // (bare barriers: __syncthreads() would wait for vmcnt(0), i.e. for this item's plane stores to retire -- 14 us per item, measured)
+            asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // every wave has left the k loop: the A slabs are dead
+            unsigned short* wl = reinterpret_cast<unsigned short*>(&smem[0][0][0]) + wave * (32 * RS);
+            if (g.avec) {
+                if (tid < WBMt) alds[tid] = aval;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            }
+            const int nn = lane >> 1, hh = lane & 1;
+            float ua[2] = {0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < XT; ++x) {
+                const int64_t mrow = m0 + 32 * XT * wh + 32 * x;                    // first of this slice's 32 rows
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned w2[2];
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const f32x2 v = {alpha * c[x][y][4 * q + 2 * d], alpha * c[x][y][4 * q + 2 * d + 1]};
+                                const f16x2 fh = __builtin_convertvector(v, f16x2);
+                                const f16x2 fo = pl == 0 ? fh : __builtin_convertvector(v - __builtin_convertvector(fh, f32x2), f16x2);
+                                w2[d] = __builtin_bit_cast(unsigned, fo);
+                            }
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 wv = {w2[0], w2[1]};
+                            *reinterpret_cast<u32x2*>(wl + li * RS + 32 * y + 8 * q + 4 * lk) = wv;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) {
+                            unsigned short e[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) e[j] = wl[(16 * mb + 8 * hh + j) * RS + 32 * nh + nn];
+                            if (g.avec) {
+                                const f32x4 a0 = *reinterpret_cast<const f32x4*>(alds + 32 * XT * wh + 32 * x + 16 * mb + 8 * hh);
+                                const f32x4 a1 = *reinterpret_cast<const f32x4*>(alds + 32 * XT * wh + 32 * x + 16 * mb + 8 * hh + 4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    ua[nh] = fmaf(a0[j], (float)__builtin_bit_cast(_Float16, e[j]), ua[nh]);
+                                    ua[nh] = fmaf(a1[j], (float)__builtin_bit_cast(_Float16, e[4 + j]), ua[nh]);
+                                }
+                            }
+                            const u32x4 ov = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                              (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                            const int64_t n = n0 + 64 * wq + 32 * nh + nn;
+                            unsigned short* p = g.Ct + (int64_t)pl * g.pCt + (((mrow >> 4) + mb) * g.N + n) * 16 + 8 * hh;
+                            // (probe A/B at the bench shape: the LDS transposition costs 0.2 ms of the product, the 8.6 GB of stores 0.85 ms; non-temporal: no change)
+                            if (g.cp_nt & 2) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(p)); else *reinterpret_cast<u32x4*>(p) = ov;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (g.avec) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const float t2 = ua[nh] + __shfl_xor(ua[nh], 1, 64);            // the two 8-row halves of every 16-row block
+                    if (hh == 0) g.Upart[((m0 + 32 * XT * wh) >> 7) * g.N + n0 + 64 * wq + 32 * nh + nn] = t2;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // before the next work item's LDS-DMA lands in the ring
         }
     } else
 #pragma unroll
@@ -789,11 +874,16 @@ int mxf_split_planes_internal(mxf_ctx* h, int64_t R, int64_t K, const float* X, 
 int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA,
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked,
-                            unsigned* maxout, unsigned short* Cplanes, int64_t pC, int a_lower) {
+                            unsigned* maxout, unsigned short* Cplanes, int64_t pC, int a_lower, unsigned short* Ct, int64_t pCt,
+                            const float* avec, float* Upart) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
     g.c_blk = c_blocked; g.maxout = nullptr;
     g.Cp = Cplanes; g.pC = pC; g.a_lower = a_lower; g.rot_div = 0;
+    g.Ct = Ct; g.pCt = pCt; g.avec = avec; g.Upart = Upart;
+    static const int cp_nt = (int)MXF_KNOB("MXF_SPLIT_CPNT", 0);
+    g.cp_nt = cp_nt;
+    if ((Ct && !Cplanes) || (avec && (!Ct || !Upart))) MXF_FAIL(h, -2, "mxf_gemm_split: the transposed planes come with the planes output, the partial sums with both");
     if (Cplanes) {
         if (mode != MXF_SPLIT_F16X2 || (M % 128) != 0 || (N % WBN) != 0 || beta != 0.0 || lower_only || c_blocked)
             MXF_FAIL(h, -2, "mxf_gemm_split: the planes output needs the f16x2 format, M %% 128 == 0, N %% 256 == 0, beta == 0 and a full product");

@@ -49,7 +49,10 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus = 0, int mode = MXF_SPLIT_BF16X3, const float* ad0 = nullptr, int pow0 = 0,
                             const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr, int c_blocked = 0,
-                            unsigned* maxout = nullptr, unsigned short* Cplanes = nullptr, int64_t pC = 0, int a_lower = 0);
+                            unsigned* maxout = nullptr, unsigned short* Cplanes = nullptr, int64_t pC = 0, int a_lower = 0,
+                            unsigned short* Ct = nullptr, int64_t pCt = 0, const float* avec = nullptr, float* Upart = nullptr);
+// (Ct: the planes output ALSO in the transposed orientation, ((m / 16) * N + n) * 16 + m % 16, plane stride pCt; avec (M floats) / Upart
+//  ((M / 128) x N floats): per 128-row band the sums of avec[m] * (hi + lo)(m, n), in the planes' units -- deterministic, summed by the caller)
 // (Cplanes != nullptr: the product is written as two f16 planes (hi + lo of alpha * A B^T, plane stride pC) in the layout of an (M x K' = N)
 //  operand, ((n / 16) * M + m) * 16 + n % 16 -- C / ldc are ignored; a_lower: A is lower triangular, the k loop of a row tile stops at its last row)
 // (maxout: the wide kernel's plain products raise this word (atomicMax) to the bit pattern of max |C|; every other path leaves it untouched)
@@ -62,6 +65,7 @@ int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q,
 // (wk (Kn x Pw), U (Pw x ldU): optional fused product U[p][r] = sum_k wk[k][p] cov(xmin[r], xmaj[k]); see gram_planes_kernel)
 
 // whiten.hip: two f16 planes of an (R x K) operand -> the planes of its transpose (K x R); U != nullptr: U[k] = scale[0] * sc2 * sum_r a[r] x(r, k)
+int mxf_upart_reduce_internal(mxf_ctx* h, int64_t N, int nparts, const float* Upart, const float* scale, float sc2, float* U, hipStream_t st);
 int mxf_planes_transpose_internal(mxf_ctx* h, int64_t R, int64_t K, const unsigned short* in, int64_t pin, unsigned short* out, int64_t pout,
                                   const float* a, const float* scale, float sc2, float* U, hipStream_t st);
 int mxf_tril_copy_internal(mxf_ctx* h, int64_t n, const double* src, double* dst, hipStream_t st);      // dst = tril(src), float64

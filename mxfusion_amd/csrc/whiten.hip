@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void planes_transpose_kernel(int64_t R, int64_
     }
 }
 
+// U[n] = scale * sc2 * sum_p Upart[p][n]: the 128-row partial sums the planes-output product's epilogue leaves (gemm_split.hip, avec / Upart),
+// added in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void upart_reduce_kernel(int64_t N, int nparts, const float* __restrict__ Upart, const float* __restrict__ scale,
+                                                           float sc2, float* __restrict__ U) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += Upart[(int64_t)p * N + n];
+    U[n] = s * (scale ? scale[0] : 1.f) * sc2;
+}
+
 // dst = tril(src) (float64, n x n): potrf leaves the strict upper triangle of its buffer as it was
 __global__ void tril_copy_kernel(int64_t n, const double* __restrict__ src, double* __restrict__ dst) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * n; i += (int64_t)gridDim.x * blockDim.x)
@@ -99,6 +110,13 @@ int mxf_planes_transpose_internal(mxf_ctx* h, int64_t R, int64_t K, const unsign
     return 0;
 }
 
+int mxf_upart_reduce_internal(mxf_ctx* h, int64_t N, int nparts, const float* Upart, const float* scale, float sc2, float* U, hipStream_t st) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(upart_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, nparts, Upart, scale, sc2, U);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
 int mxf_tril_copy_internal(mxf_ctx* h, int64_t n, const double* src, double* dst, hipStream_t st) {
     int64_t b = (n * n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -109,13 +127,23 @@ int mxf_tril_copy_internal(mxf_ctx* h, int64_t n, const double* src, double* dst
 
 // ---- C ABI: the two operations for callers that chain split products (include/mxf_gp.h) ---------------------------------------------
 extern "C" int mxf_gemm_f16x2_planes_out(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
-                                         const void* B_planes, const void* B_maxword, void* C_planes, int a_lower, void* stream) {
+                                         const void* B_planes, const void* B_maxword, void* C_planes, void* Ct_planes, const void* a, void* U,
+                                         int a_lower, void* stream) {
     if (!h) return -1;
     if (M <= 0 || N <= 0 || K <= 0 || !A_planes || !B_planes || !A_maxword || !B_maxword || !C_planes) MXF_FAIL(h, -2, "mxf_gemm_f16x2_planes_out: bad argument");
-    return mxf_gemm_split_internal(h, M, N, K, alpha, (const unsigned short*)A_planes, (int64_t)mxf_split_plane_elems(M, K), (const unsigned short*)B_planes,
-                                   (int64_t)mxf_split_plane_elems(N, K), 0.0, nullptr, N, 0, (hipStream_t)stream, 0, MXF_SPLIT_F16X2, nullptr, 0,
-                                   (const unsigned*)A_maxword, (const unsigned*)B_maxword, 0, nullptr, (unsigned short*)C_planes,
-                                   (int64_t)mxf_split_plane_elems(M, N), a_lower);
+    if ((a || U) && !(a && U && Ct_planes)) MXF_FAIL(h, -2, "mxf_gemm_f16x2_planes_out: U needs a, U and Ct_planes");
+    float* upart = nullptr;
+    if (U) {
+        upart = (float*)mxf_ws(h, sizeof(float) * (size_t)(M / 128) * (size_t)N);
+        if (!upart) MXF_FAIL(h, -4, "mxf_gemm_f16x2_planes_out: cannot allocate the partial sums");
+    }
+    int rc = mxf_gemm_split_internal(h, M, N, K, alpha, (const unsigned short*)A_planes, (int64_t)mxf_split_plane_elems(M, K), (const unsigned short*)B_planes,
+                                     (int64_t)mxf_split_plane_elems(N, K), 0.0, nullptr, N, 0, (hipStream_t)stream, 0, MXF_SPLIT_F16X2, nullptr, 0,
+                                     (const unsigned*)A_maxword, (const unsigned*)B_maxword, 0, nullptr, (unsigned short*)C_planes,
+                                     (int64_t)mxf_split_plane_elems(M, N), a_lower, (unsigned short*)Ct_planes, (int64_t)mxf_split_plane_elems(N, M),
+                                     (const float*)a, upart);
+    if (rc || !U) return rc;
+    return mxf_upart_reduce_internal(h, N, (int)(M / 128), upart, nullptr, 1.f, (float*)U, (hipStream_t)stream);
 }
 
 extern "C" int mxf_f16x2_planes_transpose(mxf_handle h, int64_t R, int64_t K, const void* planes_in, void* planes_out, const void* a,

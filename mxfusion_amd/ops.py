@@ -154,14 +154,21 @@ def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, 
     return out
 
 
-def gemm_f16x2_planes_out(A_split, B_split, M, N, K, alpha=1.0, a_lower=False):
+def gemm_f16x2_planes_out(A_split, B_split, M, N, K, alpha=1.0, a_lower=False, transposed=False, a=None):
     """alpha A B^T written directly as the two f16 planes (unscaled hi + lo) of the (M x N) operand whose contraction index is its column
-    (mxf_gemm_f16x2_planes_out: chained split products; M % 128 == 0, N % 256 == 0).  Returns the int16 planes tensor."""
+    (mxf_gemm_f16x2_planes_out: chained split products; M % 128 == 0, N % 256 == 0).  Returns the int16 planes tensor; transposed=True: also
+    the planes of the (N x M) transpose from the same launch; with a (M,) float32 also U[n] = sum_m a[m] (hi + lo)(m, n)."""
     (pa, wa), (pb, wb) = A_split, B_split
     n = _lib.load().mxf_f32x3_plane_elems(M, N)
     out = torch.empty(2 * n, dtype=torch.int16, device=pa.device)
-    _lib.call('mxf_gemm_f16x2_planes_out', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), _p(out), int(bool(a_lower)), _stream())
-    return out
+    transposed = transposed or a is not None
+    outT = torch.empty(2 * _lib.load().mxf_f32x3_plane_elems(N, M), dtype=torch.int16, device=pa.device) if transposed else None
+    U = torch.empty(N, dtype=torch.float32, device=pa.device) if a is not None else None
+    _lib.call('mxf_gemm_f16x2_planes_out', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), _p(out), _p(outT),
+              _p(_c(a)) if a is not None else None, _p(U), int(bool(a_lower)), _stream())
+    if not transposed:
+        return out
+    return (out, outT) if U is None else (out, outT, U)
 
 
 def f16x2_planes_transpose(planes, R, K, a=None, scale=None):

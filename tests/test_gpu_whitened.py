@@ -38,6 +38,10 @@ def test_planes_output_product_and_transposition(M, N, K, lower):
     assert np.array_equal(gotT, ops.planes_to_dense(pl, M, N).cpu().numpy().T)
     Uref = 0.5 * a.astype(np.float64) @ (got * alpha)
     assert np.abs(U.cpu().numpy() - Uref).max() <= 1e-5 * np.abs(Uref).max()
+    # the same launch can write the transposed planes and U itself (what the SVGP step uses)
+    pl2, plT2, U2 = ops.gemm_f16x2_planes_out(ops.f16x2_split(_dev(A)), ops.f16x2_split(_dev(Bm)), M, N, K, alpha=alpha, a_lower=lower, a=_dev(a))
+    assert torch.equal(pl2, pl) and torch.equal(plT2, plT)
+    assert np.abs(U2.cpu().numpy() - 2.0 * Uref).max() <= 1e-5 * np.abs(2.0 * Uref).max()
     # the planes feed a following split product: Phi = X X^T
     w = torch.full((1,), 8192.0, dtype=torch.float32).cuda().view(torch.int32)      # a max word in [2^13, 2^14) = scale 1: the planes are unscaled
     Phi = ops.gemm_f16x2_planes((pl, w), (pl, w), M, M, N).cpu().numpy()
