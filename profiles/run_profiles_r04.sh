@@ -23,14 +23,15 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_gram_fet
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_gram_sq -o gram -- python $R/tests/probes/gram_f32.py > $O/pmc_gram_sq.log 2>&1
 python $R/profiles/pmc_summary.py gram_lean_kernel $O/gram_pmc.json $O/pmc_gram_write $O/pmc_gram_fetch $O/pmc_gram_sq > $O/gram_pmc.txt 2>&1
 # 5. PMC passes of the split GEMMs: t / psi2 as in r03; tzero = the T shape on an all-zero B operand (clock + matrix-pipe busy of the bare
-#    schedule); v = the whitened tier's triangular planes-output product
-for w in t tzero psi2 v; do
+#    schedule); v = the whitened tier's triangular planes-output product as the step runs it (V, V^T planes and U partial sums
+#    from one launch), vp = the same product writing the V planes only
+for w in t tzero psi2 v vp; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${w}_fetch -o g -- python $R/tests/probes/split_pmc.py $w > $O/pmc_${w}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${w}_write -o g -- python $R/tests/probes/split_pmc.py $w > $O/pmc_${w}_write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o g -- python $R/tests/probes/split_pmc.py $w > $O/pmc_${w}_sq.log 2>&1
   python $R/profiles/pmc_summary.py gemm_f16x2 $O/gemm_${w}_pmc.json $O/pmc_${w}_fetch $O/pmc_${w}_write $O/pmc_${w}_sq > $O/gemm_${w}_pmc.txt 2>&1
 done
-# 6. the planes transposition (+ U) pass of the whitened tier: HBM traffic
+# 6. the stand-alone planes transposition (+ U) pass (mxf_f16x2_planes_transpose; no longer in the step): HBM traffic
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_tr_fetch -o g -- python $R/tests/probes/split_pmc.py tr > $O/pmc_tr_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_tr_write -o g -- python $R/tests/probes/split_pmc.py tr > $O/pmc_tr_write.log 2>&1
 python $R/profiles/pmc_summary.py planes_transpose $O/transpose_pmc.json $O/pmc_tr_fetch $O/pmc_tr_write > $O/transpose_pmc.txt 2>&1

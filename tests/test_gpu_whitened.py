@@ -246,3 +246,41 @@ def test_padding_keeps_the_gradient_of_latent_inputs():
     assert torch.isfinite(gX).all() and torch.isfinite(gZ).all()
     assert _nrm(gX[0].double().cpu().numpy(), rX.numpy()) <= 2e-3
     assert _nrm(gZ[0].double().cpu().numpy(), rZ.numpy()) <= 2e-3
+
+
+@pytest.mark.parametrize('kind,S,P,B,M', [('matern32', 1, 1, 1000, 200), ('matern12', 1, 2, 700, 130), ('rbf', 2, 1, 900, 300), ('matern52', 2, 3, 520, 100)])
+def test_padding_with_other_kernels_output_columns_and_sampled_parameters(kind, S, P, B, M):
+    """Both paddings for every stationary kind (the padded points must be far enough for the slowest-decaying kernel, exp(-r): 128
+    length-scales), several output columns, and sampled inputs / length-scales / variance / inducing inputs (S = 2: the sampled-operand call;
+    the padded coordinates are shared by the samples, placed beyond the largest range and length-scale): bound and gradients vs the oracle."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern12, Matern32, Matern52
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    rng = np.random.default_rng(B + M)
+    Q = 3
+    X = rng.uniform(-2., 2., (S, B, Q))
+    Y = np.sin(X[0] @ rng.standard_normal((Q, P))) + 0.05 * rng.standard_normal((B, P))
+    Z = rng.uniform(-2., 2., (S, M, Q)) if S > 1 else rng.uniform(-2., 2., (1, M, Q))
+    qm, qW, qd = 0.3 * rng.standard_normal((M, P)), 0.3 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
+    ls = rng.uniform(0.8, 1.4, (S, Q))
+    var, noise = rng.uniform(0.9, 1.3, (S, 1)), np.array([[0.05]])
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()
+    kern = {'rbf': RBF, 'matern12': Matern12, 'matern32': Matern32, 'matern52': Matern52}[kind](input_dim=Q, ARD=True, dtype='float32')
+    fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
+    fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, 1.0, Float32Guard('padding-test-' + kind)
+    leaves = {n: t(v).requires_grad_(True) for n, v in (('X', X), ('Z', Z), ('noise', noise), ('qm', qm[None]), ('qW', qW[None]), ('qd', qd[None]), ('ls', ls), ('var', var))}
+    got = fn._compute_columns(None, leaves['X'], t(Y)[None], leaves['Z'], leaves['noise'], leaves['qm'], leaves['qW'], leaves['qd'], kern,
+                              {kern.name + '_lengthscale': leaves['ls'], kern.name + '_variance': leaves['var']})
+    names = ('X', 'Z', 'noise', 'qm', 'qW', 'qd', 'ls', 'var')
+    ggot = torch.autograd.grad(got.mean(), [leaves[n] for n in names])
+    ok = {'rbf': O.RBF, 'matern52': O.Matern52, 'matern32': O.Matern32, 'matern12': O.Matern12}[kind](Q, ARD=True)
+    lo = {n: O.T(v).clone().requires_grad_(True) for n, v in (('X', X), ('Z', Z), ('noise', noise), ('qm', qm[None]), ('qW', qW[None]), ('qd', qd[None]), ('ls', ls), ('var', var))}
+    ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
+                         {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6)
+    gref = torch.autograd.grad(ref.mean(), [lo[n] for n in names])
+    assert got.shape == ref.shape
+    assert np.abs(got.detach().double().cpu().numpy() - ref.detach().numpy()).max() <= 1e-5 * np.abs(ref.detach().numpy()).max()
+    for n, a, b in zip(names, ggot, gref):
+        assert a.shape == b.shape, (n, a.shape, b.shape)
+        assert torch.isfinite(a).all(), n
+        assert _nrm(a.double().cpu().numpy(), b.numpy()) <= 2e-3, (n, _nrm(a.double().cpu().numpy(), b.numpy()))
