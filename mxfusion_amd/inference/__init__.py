@@ -7,6 +7,7 @@ from .meanfield import create_Gaussian_meanfield  # noqa: F401
 from .batch_loop import BatchInferenceLoop, DistributedBatchInferenceLoop  # noqa: F401
 from .minibatch_loop import MinibatchInferenceLoop, DistributedMinibatchInferenceLoop  # noqa: F401
 from .prediction import ModulePredictionAlgorithm  # noqa: F401
-from .forward_sampling import ForwardSamplingAlgorithm, ForwardSampling  # noqa: F401
+from .forward_sampling import ForwardSamplingAlgorithm, ForwardSampling, VariationalPosteriorForwardSampling  # noqa: F401
+from .inference_parameters import InferenceParameters  # noqa: F401
 from .expectation import ExpectationAlgorithm  # noqa: F401
 from .pilco_alg import PILCOAlgorithm  # noqa: F401
