@@ -150,6 +150,14 @@ __global__ void diag_of_kernel(int64_t total, int64_t n, const T* __restrict__ g
     }
 }
 
+// kernels that end in ONE same-address atomic per workgroup (the scalar sums of normal_logpdf_kernel): 2048 of them serialise at the L2
+// (~15 ns apiece: 33 us for the 2 M-element log-pdf of a 4-sample step, of which the data take 6) -- two workgroups per CU
+inline unsigned grid_for_reduce(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (unsigned)b;
+}
 inline unsigned grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -214,8 +222,8 @@ extern "C" int mxf_normal_logpdf(mxf_handle h, int dtype, int S, int64_t n, cons
     if ((n_mean != 1 && n_mean != n) || (n_var != 1 && n_var != n)) MXF_FAIL(h, -2, "mxf_normal_logpdf: mean/var must have 1 or n elements");
     hipStream_t st = (hipStream_t)stream;
     DISPATCH(h, dtype, "mxf_normal_logpdf",
-             hipLaunchKernelGGL((normal_logpdf_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const float*)x, (const float*)mean, n_mean, (const float*)var, n_var, (float)scale, (float*)out_acc, (float*)dx_acc, (float*)dmean_acc, (float*)dvar_acc),
-             hipLaunchKernelGGL((normal_logpdf_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, S, n, (const double*)x, (const double*)mean, n_mean, (const double*)var, n_var, scale, (double*)out_acc, (double*)dx_acc, (double*)dmean_acc, (double*)dvar_acc));
+             hipLaunchKernelGGL((normal_logpdf_kernel<float>), dim3(grid_for_reduce(n)), dim3(256), 0, st, S, n, (const float*)x, (const float*)mean, n_mean, (const float*)var, n_var, (float)scale, (float*)out_acc, (float*)dx_acc, (float*)dmean_acc, (float*)dvar_acc),
+             hipLaunchKernelGGL((normal_logpdf_kernel<double>), dim3(grid_for_reduce(n)), dim3(256), 0, st, S, n, (const double*)x, (const double*)mean, n_mean, (const double*)var, n_var, scale, (double*)out_acc, (double*)dx_acc, (double*)dmean_acc, (double*)dvar_acc));
 }
 
 extern "C" int mxf_adam_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* m, void* v, double lr, double beta1,
