@@ -47,6 +47,21 @@ __global__ void axpby_kernel(int64_t n, T a, const T* __restrict__ x, T b, const
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = a * x[i] + (y ? b * y[i] : (T)0);
 }
+// the gradient outputs of the SVGP training call's tail in ONE launch: dst_k (+)= (T)(src_k + src2_k), k < cnt  (six dependent 5-us launches
+// at the end of the caller's stream otherwise)
+struct FinishArgs { const double* src[6]; const double* src2[6]; void* dst[6]; int64_t n[6]; int acc[6]; int cnt; };
+template <typename T>
+__global__ void svgp_finish_kernel(FinishArgs a) {
+    const int k = blockIdx.y;
+    if (k >= a.cnt) return;
+    T* __restrict__ d = (T*)a.dst[k];
+    const double* __restrict__ s1 = a.src[k];
+    const double* __restrict__ s2 = a.src2[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = s1[i] + (s2 ? s2[i] : 0.0);
+        d[i] = (a.acc[k] ? d[i] : (T)0) + (T)v;
+    }
+}
 // dst(TO) (+)= a * (TO)src(TI)
 template <typename TI, typename TO>
 __global__ void add_convert_kernel(int64_t n, TO a, const TI* __restrict__ src, TO* __restrict__ dst, int accumulate) {
@@ -646,6 +661,22 @@ __global__ void svgp_init_kernel(int* __restrict__ info, int* __restrict__ info2
     // last launch -- a call that returned early (an error between its norm kernels and cond_publish_kernel) must not leak its norms
     if (threadIdx.x < 2) cond_dev[threadIdx.x] = 0.0;
 }
+// the same launch with the float64 copies of Z, the length-scales and the variance the core works on (and sigma for the whitened tier): three
+// more dependent launches in front of the Kuu Gram otherwise
+template <typename T>
+__global__ __launch_bounds__(256) void svgp_prologue_kernel(int* __restrict__ info, int* __restrict__ info2, double* __restrict__ cond_dev, int64_t nZ,
+                                                            const T* __restrict__ Z, double* __restrict__ Zd, int64_t nls, const T* __restrict__ ls,
+                                                            double* __restrict__ lsd, const T* __restrict__ var, double* __restrict__ vard,
+                                                            float* __restrict__ sig) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && info) info[0] = 0;
+        if (threadIdx.x < 8) info2[threadIdx.x] = 0;
+        if (threadIdx.x < 2) cond_dev[threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) { vard[0] = (double)var[0]; if (sig) sig[0] = sqrtf((float)var[0]); }
+        for (int64_t i = threadIdx.x; i < nls; i += blockDim.x) lsd[i] = (double)ls[i];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nZ; i += (int64_t)gridDim.x * blockDim.x) Zd[i] = (double)Z[i];
+}
 // sigma = sqrt(variance) as a float word (the whitened tier's planes hold V / sigma * 2^14: |v_n|^2 <= k_nn = variance)
 __global__ void svgp_sigma_kernel(const float* __restrict__ var, float* __restrict__ sig) { if (threadIdx.x == 0) sig[0] = sqrtf(var[0]); }
 
@@ -781,8 +812,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     double* cond_slot = h->cond_host + 2 * h->cond_slot;
     for (int i = 0; i < MXF_NT; ++i) h->tm.used[i] = false;
     MXF_T0(h, MXF_T_CALL, st); MXF_T0(h, MXF_T_CHAIN, st);
-    hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2, h->cond_dev);
-    if (whiten) hipLaunchKernelGGL(svgp_sigma_kernel, dim3(1), dim3(64), 0, st, (const float*)var, sigf);
+    if (!use_mat)
+        hipLaunchKernelGGL((svgp_prologue_kernel<T>), dim3(gridn(M * Q) > 64 ? 64 : gridn(M * Q)), dim3(256), 0, st, info, info2, h->cond_dev, (int64_t)(M * Q), Z, Zd,
+                           (int64_t)lsn, ls, lsd, var, vard, whiten ? sigf : (float*)nullptr);
+    else {
+        hipLaunchKernelGGL(svgp_init_kernel, dim3(1), dim3(64), 0, st, info, info2, h->cond_dev);
+        if (whiten) hipLaunchKernelGGL(svgp_sigma_kernel, dim3(1), dim3(64), 0, st, (const float*)var, sigf);
+    }
     if (het_stream) {       // nmin, the row weights, sum log noise / sum beta, y' = r y -- before the fork: both side streams read them
         MXF_HIP(h, hipMemsetAsync(info2 + 5, 0x7f, sizeof(int), st));                 // 0x7f7f7f7f: a huge finite float, above any noise variance
         MXF_HIP(h, hipMemsetAsync(hhs, 0, 4 * sizeof(D), st));
@@ -793,7 +829,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         const int64_t ny = sY == 0 ? B : SB;
         hipLaunchKernelGGL(het_scale_y_kernel, dim3(gridn(ny)), dim3(256), 0, st, ny, B, (const float*)Y, (const float*)hrs, hys);
     }
-    if (!use_mat) { CONV(M * Q, Z, Zd); CONV(lsn, ls, lsd); CONV(1, var, vard); }
 #undef CONV
     int rc;
     static const int64_t psi2_ka = MXF_KNOB("MXF_SVGP_PSI2_KA", -1);
@@ -1208,10 +1243,15 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);
     if (rc) return rc;
-    if (dmu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (T)1, (const D*)dmud, dmu, 0);
     // Kuu-side reverse mode in float64, then added to the streaming-side gradients
+    FinishArgs fa;
+    fa.cnt = 0;
+    auto fin = [&](const D* src, const D* src2, void* dst, int64_t n, int acc) {
+        fa.src[fa.cnt] = src; fa.src2[fa.cnt] = src2; fa.dst[fa.cnt] = dst; fa.n[fa.cnt] = n; fa.acc[fa.cnt] = acc; ++fa.cnt;
+    };
+    if (dmu) fin(dmud, nullptr, dmu, MP, 0);
     if (use_mat) {
-        if (mat.dKuu) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, MM, (T)1, (const D*)dKuu, mat.dKuu, 0);
+        if (mat.dKuu) fin(dKuu, nullptr, mat.dKuu, MM, 0);
     } else {
         if (!early_clear) {
             MXF_HIP(h, hipMemsetAsync(dZc, 0, sizeof(D) * M * Q, st));
@@ -1220,14 +1260,16 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         }
         rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
         if (rc) return rc;
-        if (dZ) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(M * Q)), dim3(256), 0, st, M * Q, (T)1, (const D*)dZc, dZ, 1);
-        if (dls) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(lsn)), dim3(64), 0, st, (int64_t)lsn, (T)1, (const D*)dlsc, dls, 1);
-        if (dvar) {
-            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)dvc, dvar, 1);
-            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 5), dvar, 1);
-        }
+        if (dZ) fin(dZc, nullptr, dZ, M * Q, 1);
+        if (dls) fin(dlsc, nullptr, dls, lsn, 1);
+        if (dvar) fin(dvc, sc + 5, dvar, 1, 1);
     }
-    if (dnoise && !het && !het_stream) hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(1), dim3(64), 0, st, (int64_t)1, (T)1, (const D*)(sc + 4), dnoise, 0);
+    if (dnoise && !het && !het_stream) fin(sc + 4, nullptr, dnoise, 1, 0);
+    if (fa.cnt) {
+        int64_t nmax = 1;
+        for (int i = 0; i < fa.cnt; ++i) nmax = fa.n[i] > nmax ? fa.n[i] : nmax;
+        hipLaunchKernelGGL((svgp_finish_kernel<T>), dim3(gridn(nmax), (unsigned)fa.cnt), dim3(256), 0, st, fa);
+    }
     MXF_STAGE(h, "core reverse", st);
     hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));     // join the Su chain: every output is ordered on the caller's stream
