@@ -5,6 +5,8 @@ import torch
 
 from mxfusion_amd import ops
 from mxfusion_amd.components.variables.variable import Variable
+from mxfusion_amd.components.factor import Factor
+from mxfusion_amd.components.functions.function_evaluation import FunctionEvaluation
 
 
 class _GramFn(torch.autograd.Function):
@@ -65,7 +67,78 @@ class _Gram2Fn(torch.autograd.Function):
         return (None, out[0], out[1]) + tuple(grads)
 
 
+def rename_duplicate_names(names):
+    """util/util.py:65-100: [(index, new name)] for every repeated name -- the repeat gets the first free `<prefix><count>` (a trailing
+    integer of the name counts as its counter): ['a', 'b', 'a', 'a'] -> [(2, 'a0'), (3, 'a1')]."""
+    import re
+    all_names = set(names)
+    if len(all_names) == len(names):
+        return []
+    cur, prog, renames = set(), re.compile(r'^(.*)(\d+)$'), []
+    for i, n in enumerate(names):
+        if n in cur:
+            res = prog.match(n)
+            prefix, count = (n, 0) if res is None else (res.groups()[0], int(res.groups()[1]) + 1)
+            while prefix + str(count) in all_names:
+                count += 1
+            renames.append((i, prefix + str(count)))
+            all_names.add(prefix + str(count))
+        else:
+            cur.add(n)
+    return renames
+
+
+class KernelFunctionEvaluation(FunctionEvaluation):
+    """A kernel used as a function inside a model (kernel.py:29 `Kernel(MXFusionFunction)`, mxfusion_function.py:55-79
+    FunctionEvaluationWithParameters): inputs X (, X2) and the kernel's parameters under their prefixed names, one output `covariance`;
+    the inputs are attributes of the factor (`fe.X`, `fe.rbf_lengthscale`) as in the reference's factor."""
+
+    def __init__(self, kernel, inputs):
+        out = Variable(shape=None)
+        Factor.__init__(self, inputs, [('covariance', out)], [n for n, _ in inputs], ['covariance'])       # (a FunctionEvaluation to the factor graph's walk)
+        self._func = self._kernel = kernel
+        for n, v in inputs:
+            object.__setattr__(self, n, v)
+
+    def eval(self, F, variables, always_return_tuple=False):
+        kw = {n: variables[v.uuid] for n, v in self.inputs}
+        X, X2 = kw.pop('X'), kw.pop('X2', None)
+        K = self._kernel.K(F, X, X2, **kw)
+        return (K,) if always_return_tuple else K
+
+
 class Kernel(object):
+    def __call__(self, X, X2=None, **kernel_params):
+        """rbf(X_var, X2_var, rbf_lengthscale=l_var, ...) -> the covariance Variable (its .factor evaluates K); parameters that are not
+        given are the kernel's own Variables (mxfusion_function.py:55-79, _parse_arguments)."""
+        own = self.parameters
+        unknown = [k for k in kernel_params if k not in own]
+        if unknown:
+            raise TypeError('%s(): unknown kernel parameter(s) %s (the kernel has %s)' % (self.name, unknown, sorted(own)))
+        inputs = [('X', X)] + ([('X2', X2)] if X2 is not None else [])
+        inputs += [(n, kernel_params.get(n, own[n])) for n in self.parameter_names]
+        fe = KernelFunctionEvaluation(self, inputs)
+        return fe.outputs[0][1]
+
+    def eval(self, F, X, X2=None, **kernel_params):
+        """kernel.py:247-259."""
+        return self.K(F, X, X2, **kernel_params)
+
+    def replicate_self(self, attribute_map=None):
+        """kernel.py:261-273 / :365-373: a copy of the kernel whose parameter Variables are replicas (same UUIDs) -- what a module's internal
+        graphs hold of the kernel the user passed in."""
+        import copy
+        rep = copy.copy(self)
+        object.__setattr__(rep, '_parameter_names', [])
+        rep.active_dims = copy.copy(self.active_dims)
+        for n in self._parameter_names:
+            setattr(rep, n, getattr(self, n).replicate_self())
+        if hasattr(self, 'sub_kernels'):
+            rep.sub_kernels = [k.replicate_self(attribute_map) for k in self.sub_kernels]
+            for k in rep.sub_kernels:
+                object.__setattr__(rep, k.name, k)
+        return rep
+
     def __init__(self, input_dim, name, active_dims=None, dtype=None, ctx=None):
         self.input_dim = input_dim
         self.name = name
@@ -140,16 +213,13 @@ class CombinationKernel(Kernel):
     """kernel.py:317-373: sub-kernel parameters are exposed as `<comb>_<sub>_<param>`."""
 
     def __init__(self, sub_kernels, name, dtype=None, ctx=None):
-        super(CombinationKernel, self).__init__(input_dim=sub_kernels[0].input_dim, name=name, dtype=dtype, ctx=ctx)
-        names = [k.name for k in sub_kernels]
-        if len(set(names)) != len(names):   # reference renames duplicates <name>0, <name>1 ...
-            seen = {}
-            for k in sub_kernels:
-                c = seen.get(k.name, 0)
-                seen[k.name] = c + 1
-                if names.count(k.name) > 1:
-                    k.name = k.name + str(c)
+        sub_kernels = list(sub_kernels)
+        for i, n in rename_duplicate_names([k.name for k in sub_kernels]):       # kernel.py:333-335: rbf, rbf -> rbf, rbf0
+            sub_kernels[i].name = n
+        super(CombinationKernel, self).__init__(input_dim=max(k.input_dim for k in sub_kernels), name=name, dtype=dtype, ctx=ctx)
         self.sub_kernels = sub_kernels
+        for k in sub_kernels:
+            object.__setattr__(self, k.name, k)                                  # kernel.py:339-340: kern.rbf, kern.linear
 
     @property
     def parameters(self):
@@ -177,7 +247,10 @@ class CombinationKernel(Kernel):
 
 class AddKernel(CombinationKernel):
     def __init__(self, sub_kernels, name='add', dtype=None, ctx=None):
-        super(AddKernel, self).__init__(sub_kernels, name, dtype, ctx)
+        flat = []
+        for k in sub_kernels:          # add_kernel.py:36-43: a sum of sums is ONE sum (rbf + (rbf + linear) -> add(rbf, rbf0, linear))
+            flat.extend(k.sub_kernels if isinstance(k, AddKernel) else [k])
+        super(AddKernel, self).__init__(flat, name, dtype, ctx)
 
     def _compute_K(self, F, X, X2=None, **params):
         """add_kernel.py:44-68."""

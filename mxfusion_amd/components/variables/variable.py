@@ -79,6 +79,17 @@ class Variable(object):
         """q[v].assign_factor(PointMass / Normal ...) (map.py:56-59, meanfield.py:40-43)."""
         factor.set_single_output(self)
 
+    def __deepcopy__(self, memo):
+        """(FactorGraph.clone) the copy is hashable -- it has its UUID -- before anything that may use it as a dictionary key is copied."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        object.__setattr__(new, 'uuid', self.uuid)
+        for k, v in self.__dict__.items():
+            if k != 'uuid':
+                object.__setattr__(new, k, copy.deepcopy(v, memo))
+        return new
+
     def __hash__(self):
         return hash(self.uuid)
 

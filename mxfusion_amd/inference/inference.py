@@ -93,9 +93,22 @@ class Inference(object):
             return executor(*data)
 
     def print_params(self):
+        """inference.py:62-83: the inference parameters as a string, one block per parameter --
+        `<variable> in <Model | Posterior | FactorGraph>(<graph id>) : <value>` -- naming the first graph that holds the variable."""
+        from ..models.model import Model
+        from ..models.posterior import Posterior
+
+        def kind(graph):
+            return 'Model' if isinstance(graph, Model) else ('Posterior' if isinstance(graph, Posterior) else 'FactorGraph')
+        out = ''
         for u, v in self.params._vars.items():
-            if u in self.params:
-                print(v.name, u, self.params[v])
+            if u not in self.params:
+                continue
+            owner = next((g for g in self._graphs if u in g), None)
+            var = owner[u] if owner is not None else v
+            tag = '%s(%s)' % (kind(owner), ('%x' % id(owner))[-5:]) if owner is not None else 'FactorGraph(?)'
+            out += '{} in {} : {} \n\n'.format(var, tag, self.params[v])
+        return out
 
     # ---- checkpoint (inference.py:179-310): the reference's zip layout, parameters keyed by UUID -------------------
     def _graph_listing(self):

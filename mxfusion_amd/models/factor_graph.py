@@ -1,6 +1,6 @@
 """FactorGraph runtime (mxfusion/models/factor_graph.py:28-297): registration of named variables and the
-topological walks log_pdf (:192-238) / draw_samples (:240-297).  Graph cloning / reconciliation / JSON
-(:325-643) is bookkeeping outside the hot path and is not re-created."""
+topological walks log_pdf (:192-238) / draw_samples (:240-297); clone (:415-477) as a structural copy.  Graph reconciliation / JSON
+(:479-643) lives in util/graph_json.py."""
 from ..common.exceptions import ModelSpecificationError
 from ..components.factor import Factor
 from ..components.variables.variable import Variable, VariableType
@@ -51,6 +51,23 @@ class FactorGraph(object):
             self._register_variable(v)
         for v in getattr(f, 'extra_parameters', lambda: [])():
             self._register_variable(v)
+
+    def clone(self, leaves=None):
+        """factor_graph.py:415-477: an independent copy of the graph -- same topology, same UUIDs and names, new component objects (modules
+        with their internal graphs and attached algorithms, kernels with their parameter Variables included); array values (constants,
+        initial values) are SHARED with the original, nothing is copied on the device.  `leaves`: accepted for signature compatibility --
+        the whole graph is cloned."""
+        import copy
+        import torch
+        memo = {}
+
+        def share(o):          # arrays keep their identity in the copy
+            memo[id(o)] = o
+        for v in self._variables.values():
+            for a in (getattr(v, '_value', None), getattr(v, '_initial_value', None)):
+                if isinstance(a, torch.Tensor):
+                    share(a)
+        return copy.deepcopy(self, memo)
 
     def __getitem__(self, key):
         uuid = key.uuid if isinstance(key, Variable) else key

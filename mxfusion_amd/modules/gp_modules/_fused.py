@@ -88,6 +88,10 @@ class Float32Guard(object):
     _counter = 0
     epoch = 0               # bumped on every level change of any owner: a holder of a captured hipGraph re-captures when it moved (batch_loop.py)
 
+    def __deepcopy__(self, memo):
+        """A cloned module (FactorGraph.clone) gets a guard -- and a condition slot -- of its own."""
+        return Float32Guard(self.name)
+
     def __init__(self, name='svgp'):
         import weakref
         cls = Float32Guard

@@ -308,11 +308,35 @@ class White(Kernel):
         return variance.reshape(-1, 1).expand(max(X.shape[0], variance.shape[0]), X.shape[-2]).clone()
 
 
+def rename_duplicate_names(names):
+    """util/util.py:65-100: [(index, new name)] -- a repeated name gets the first free ``<prefix><count>`` (rbf, rbf -> rbf, rbf0)."""
+    import re
+    all_names = set(names)
+    if len(all_names) == len(names):
+        return []
+    cur, prog, renames = set(), re.compile(r'^(.*)(\d+)$'), []
+    for i, n in enumerate(names):
+        if n in cur:
+            res = prog.match(n)
+            prefix, count = (n, 0) if res is None else (res.groups()[0], int(res.groups()[1]) + 1)
+            while prefix + str(count) in all_names:
+                count += 1
+            renames.append((i, prefix + str(count)))
+            all_names.add(prefix + str(count))
+        else:
+            cur.add(n)
+    return renames
+
+
 class _Combination(Kernel):
-    """kernels/kernel.py:317-373 -- sub-kernel parameters are prefixed ``<comb>_<sub>_``."""
+    """kernels/kernel.py:317-373 -- sub-kernel parameters are prefixed ``<comb>_<sub>_``; duplicate sub-kernel names are renamed
+    (:333-335); input_dim is the largest of the sub-kernels' (:332)."""
 
     def __init__(self, sub_kernels, name):
-        super().__init__(sub_kernels[0].input_dim, name, None)
+        sub_kernels = list(sub_kernels)
+        for i, n in rename_duplicate_names([k.name for k in sub_kernels]):
+            sub_kernels[i].name = n
+        super().__init__(max(k.input_dim for k in sub_kernels), name, None)
         self.sub_kernels = sub_kernels
 
     def param_names(self):
@@ -321,7 +345,11 @@ class _Combination(Kernel):
 
 class AddKernel(_Combination):
     def __init__(self, sub_kernels, name='add'):
-        super().__init__(sub_kernels, name)
+        """kernels/add_kernel.py:36-46: a sum of sums is flattened into one sum."""
+        flat = []
+        for k in sub_kernels:
+            flat.extend(k.sub_kernels if isinstance(k, AddKernel) else [k])
+        super().__init__(flat, name)
 
     def _compute_K(self, X, X2=None, **params):
         """kernels/add_kernel.py:44-68."""

@@ -215,3 +215,18 @@ def test_variational_posterior_forward_sampling_draws_latents_from_q(golden_dir)
     assert torch.allclose(Xs.double(), want, rtol=1e-12, atol=1e-12)
     with pytest.raises(InferenceError):
         VariationalPosteriorForwardSampling(num_samples=2, observed=[], inherited_inference=Inference(ForwardSamplingAlgorithm(model=m, observed=[], num_samples=2), dtype=DT))
+
+
+def test_a_cloned_model_computes_the_same_bound_and_prints_its_parameters(golden_dir):
+    """gpregression_test.py:352-377 (test_prediction_print, test_module_clone): the clone of the KAT-GP model evaluates to the reference's
+    log-pdf (-18.8144...) through its own Inference, and print_params lists the inference's parameters."""
+    from mxfusion_amd.inference import Inference, MAP
+    g = np.load(os.path.join(golden_dir, 'kat_gp.npz'))
+    m = _gp_model(g['noise'], g['ls'], g['var'], 2)
+    c = m.clone()
+    assert c.Y.factor is not m.Y.factor and c.Y.uuid == m.Y.uuid
+    infr = Inference(MAP(model=c, observed=[c.X, c.Y]), dtype=DT)
+    loss, _ = infr.run(X=_t(g['X']), Y=_t(g['Y']))
+    assert abs(float(-loss) - (-18.814420362103)) < 1e-9
+    txt = infr.print_params()
+    assert isinstance(txt, str) and len(txt) > 1 and 'Model' in txt

@@ -374,11 +374,11 @@ def test_linear_bias_white_kernels_reverse_mode(square, S, ard):
     rl, rv = rng.rand(1, 1) + 0.5, rng.rand(1, 1) + 0.5
     G = rng.randn(S, N, N if square else N2)
     kern = (Linear(Q, ARD=ard, dtype=DT) + Bias(Q, dtype=DT) + White(Q, dtype=DT)) * RBF(Q, dtype=DT)
-    okern = O.MultiplyKernel([O.AddKernel([O.AddKernel([O.Linear(Q, ARD=ard), O.Bias(Q)]), O.White(Q)]), O.RBF(Q)])   # '+' nests, kernel.py:149-164
+    okern = O.MultiplyKernel([O.AddKernel([O.AddKernel([O.Linear(Q, ARD=ard), O.Bias(Q)]), O.White(Q)]), O.RBF(Q)])   # a sum of sums is ONE AddKernel, add_kernel.py:36-46
     vals = dict(X=X, X2=X2, lv=lv, bv=bv, wv=wv, rl=rl, rv=rv)
     dev = {n: _t(v).requires_grad_(True) for n, v in vals.items()}
     ora = {n: O.T(v).clone().requires_grad_(True) for n, v in vals.items()}
-    names = {'mul_add_add_linear_variances': 'lv', 'mul_add_add_bias_variance': 'bv', 'mul_add_white_variance': 'wv', 'mul_rbf_lengthscale': 'rl',
+    names = {'mul_add_linear_variances': 'lv', 'mul_add_bias_variance': 'bv', 'mul_add_white_variance': 'wv', 'mul_rbf_lengthscale': 'rl',
              'mul_rbf_variance': 'rv'}
     assert sorted(kern.parameters) == sorted(names)
     K = kern.K(None, dev['X'], None if square else dev['X2'], **{k: dev[v] for k, v in names.items()})
@@ -562,3 +562,64 @@ def test_forward_sampling_wrapper_and_expectation_algorithm(golden_dir):
     ex = TransferInference(ExpectationAlgorithm(model=m, observed=[m.X], num_samples=4, target_variables=[m.Y]), infr_params=infr.params, dtype=DT)
     mean = ex.run(X=_t(g['X']))[0]
     assert np.allclose(mean.cpu().numpy(), ref.numpy().mean(0), atol=1e-10)
+
+
+@pytest.mark.parametrize('ls_samples,var_samples,x_samples,ard', [(False, False, False, True), (True, False, False, True), (False, True, False, True),
+                                                                  (False, False, True, True), (False, False, True, False)])
+def test_kernel_as_a_function_in_a_model(ls_samples, var_samples, x_samples, ard):
+    """kernel_test.py:101-139 (test_kernel_as_MXFusionFunction): rbf(X_var [, X2_var], rbf_lengthscale=l_var, rbf_variance=v_var) gives a
+    Variable whose factor evaluates the covariance -- the same numbers as K(...) with fetch_parameters' dictionary, for every combination
+    of sampled operands the reference test runs; the factor is a FunctionEvaluation to the factor graph, its inputs are attributes."""
+    from mxfusion_amd import Variable
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.components.functions.function_evaluation import FunctionEvaluation
+    rng = np.random.RandomState(0)
+    S, Q = 3, 2
+    X = rng.rand(S if x_samples else 1, 5, Q)
+    X2 = rng.rand(S if x_samples else 1, 4, Q)
+    ls = rng.rand(S if ls_samples else 1, Q if ard else 1) + 1e-4
+    var = rng.rand(S if var_samples else 1, 1) + 1e-4
+    okern = O.RBF(Q, ARD=ard)
+    for with_x2 in (False, True):
+        X_mf, X2_mf, l_mf, v_mf = Variable(shape=X.shape[1:]), Variable(shape=X2.shape[1:]), Variable(shape=ls.shape[1:]), Variable(shape=var.shape[1:])
+        rbf = RBF(Q, ard, 1., 1., 'rbf', None, DT)
+        ev = (rbf(X_mf, X2_mf, rbf_lengthscale=l_mf, rbf_variance=v_mf) if with_x2 else rbf(X_mf, rbf_lengthscale=l_mf, rbf_variance=v_mf)).factor
+        assert isinstance(ev, FunctionEvaluation) and ev.X is X_mf and ev.rbf_lengthscale is l_mf and ev.rbf_variance is v_mf
+        variables = {ev.X.uuid: _t(X), ev.rbf_lengthscale.uuid: _t(ls), ev.rbf_variance.uuid: _t(var)}
+        if with_x2:
+            variables[ev.X2.uuid] = _t(X2)
+        res_eval = ev.eval(F=None, variables=variables)
+        params = rbf.fetch_parameters({rbf.lengthscale.uuid: _t(ls), rbf.variance.uuid: _t(var)})
+        res_direct = rbf.K(None, _t(X), _t(X2) if with_x2 else None, **params)
+        assert torch.equal(res_eval, res_direct)
+        ref = okern.K(O.T(X), O.T(X2) if with_x2 else None, rbf_lengthscale=O.T(ls), rbf_variance=O.T(var))
+        assert np.allclose(res_eval.cpu().numpy(), ref.numpy(), rtol=1e-12, atol=1e-14)
+    with pytest.raises(TypeError):
+        rbf(X_mf, rbf_lengthscal=l_mf)
+
+
+@pytest.mark.parametrize('samples', [False, True])
+def test_adding_an_add_kernel_flattens_and_renames(samples):
+    """kernel_test.py:246-260 (test_adding_add_kernel): rbf + (rbf + linear) is ONE AddKernel of three sub-kernels named rbf, rbf0, linear
+    (add_kernel.py:36-46, kernel.py:333-340), parameters add_rbf_*, add_rbf0_*, add_linear_variances, sub-kernels reachable as attributes;
+    K, K(X, X2), Kdiag of the replicated kernel equal the sum of the parts (the oracle's kernels), with and without sampled operands."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Linear, AddKernel
+    rng = np.random.RandomState(1)
+    S, Q = (3 if samples else 1), 6
+    X, X2 = rng.rand(S, 5, Q), rng.rand(S, 4, Q)
+    ls, var, ls0, var0, lv = rng.rand(S, Q) + 1e-4, rng.rand(S, 1) + 1e-4, rng.rand(S, Q) + 1e-4, rng.rand(S, 1) + 1e-4, rng.rand(S, Q) + 1e-4
+    kern = (RBF(Q, True, 1., 1., 'rbf', None, DT) + (RBF(Q, True, 1., 1., 'rbf', None, DT) + Linear(Q, True, 1, 'linear', None, DT))).replicate_self()
+    assert isinstance(kern, AddKernel) and [k.name for k in kern.sub_kernels] == ['rbf', 'rbf0', 'linear']
+    assert kern.rbf0 is kern.sub_kernels[1] and kern.linear is kern.sub_kernels[2]
+    assert sorted(kern.parameter_names) == sorted(['add_rbf_lengthscale', 'add_rbf_variance', 'add_rbf0_lengthscale', 'add_rbf0_variance', 'add_linear_variances'])
+    p = {'add_rbf_lengthscale': ls, 'add_rbf_variance': var, 'add_rbf0_lengthscale': ls0, 'add_rbf0_variance': var0, 'add_linear_variances': lv}
+    okern = O.RBF(Q, ARD=True) + (O.RBF(Q, ARD=True) + O.Linear(Q, ARD=True))
+    assert [k.name for k in okern.sub_kernels] == ['rbf', 'rbf0', 'linear']
+    parts = (O.RBF(Q, ARD=True).K(O.T(X), rbf_lengthscale=O.T(ls), rbf_variance=O.T(var)) + O.RBF(Q, ARD=True).K(O.T(X), rbf_lengthscale=O.T(ls0), rbf_variance=O.T(var0))
+             + O.Linear(Q, ARD=True).K(O.T(X), linear_variances=O.T(lv)))
+    dp = {k: _t(v) for k, v in p.items()}
+    op = {k: O.T(v) for k, v in p.items()}
+    assert np.allclose(okern.K(O.T(X), **op).numpy(), parts.numpy(), rtol=1e-13)
+    assert np.allclose(kern.K(None, _t(X), **dp).cpu().numpy(), parts.numpy(), rtol=1e-11, atol=1e-13)
+    assert np.allclose(kern.K(None, _t(X), _t(X2), **dp).cpu().numpy(), okern.K(O.T(X), O.T(X2), **op).numpy(), rtol=1e-11, atol=1e-13)
+    assert np.allclose(kern.Kdiag(None, _t(X), **dp).cpu().numpy(), okern.Kdiag(O.T(X), **op).numpy(), rtol=1e-11, atol=1e-13)
