@@ -30,6 +30,11 @@ class Factor(object):
     def output_names(self):
         return self._output_names
 
+    def __repr__(self):
+        """factor.py:113-119: ClassName(input=variable, ...)."""
+        ins = self.__dict__.get('_inputs') or []
+        return type(self).__name__ + ('(' + ', '.join('%s=%s' % (n, v) for n, v in ins) + ')' if ins else '')
+
     def set_single_output(self, var):
         self._outputs = [(self._output_names[0], var)]
         var.factor = self

@@ -35,11 +35,18 @@ class Variable(object):
         self.shape = tuple(shape) if shape is not None else (1,)
 
     def set_prior(self, value):
-        if isinstance(value, (int, float, np.ndarray, torch.Tensor)):
+        """variable.py:191-198: set the distribution this variable is drawn from (m.x.set_prior(Normal(...))); the factor and its input
+        variables join the variable's graph.  (A plain number / array makes the variable a constant -- the constructor's `value=` path.)"""
+        from ..factor import Factor
+        if isinstance(value, Factor):
+            self.assign_factor(value)
+            if self.graph is not None:
+                self.graph._register_factor(value)
+        elif isinstance(value, (int, float, np.ndarray, torch.Tensor)):
             self.isConstant = True
             self._value = value
         else:
-            raise TypeError('Variable value must be a constant')
+            raise TypeError('set_prior: a distribution (or a constant value) is expected, not %s' % type(value).__name__)
 
     @property
     def constant(self):

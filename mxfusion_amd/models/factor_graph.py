@@ -52,6 +52,15 @@ class FactorGraph(object):
         for v in getattr(f, 'extra_parameters', lambda: [])():
             self._register_variable(v)
 
+    def __repr__(self):
+        """factor_graph.py:49-59: one line per factor in evaluation order -- `outputs = Function(...)` / `outputs ~ Distribution(...)`."""
+        from ..components.functions.function_evaluation import FunctionEvaluation
+        lines = ['%s (%s)' % (type(self).__name__, ('%x' % id(self))[-5:])]
+        for f in self.ordered_factors:
+            outs = ', '.join(str(v) for _, v in f.outputs)
+            lines.append(outs + (' = ' if isinstance(f, FunctionEvaluation) else ' ~ ') + str(f))
+        return '\n'.join(lines)
+
     def clone(self, leaves=None):
         """factor_graph.py:415-477: an independent copy of the graph -- same topology, same UUIDs and names, new component objects (modules
         with their internal graphs and attached algorithms, kernels with their parameter Variables included); array values (constants,

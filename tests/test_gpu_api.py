@@ -230,3 +230,72 @@ def test_a_cloned_model_computes_the_same_bound_and_prints_its_parameters(golden
     assert abs(float(-loss) - (-18.814420362103)) < 1e-9
     txt = infr.print_params()
     assert isinstance(txt, str) and len(txt) > 1 and 'Model' in txt
+
+
+def _normal_normal_model():
+    """testing/inference/map_test.py:49-55: x ~ N(mean, var) with free mean / positive var, y ~ N(x, 1), both of length N."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    m = Model()
+    m.mean = Variable()
+    m.var = Variable(transformation=PositiveTransformation())
+    m.N = Variable()
+    m.x = Normal.define_variable(mean=m.mean, variance=m.var, shape=(m.N,), dtype=DT)
+    m.y = Normal.define_variable(mean=m.x, variance=_t([1.]), shape=(m.N,), dtype=DT)
+    return m
+
+
+def test_map_examples_of_the_reference(golden_dir):
+    """map_test.py:74-109: MAP with x latent (test_one_map_example), with x observed (test_function_map_example), and the outcome of a
+    MAP inference handed to VariationalPosteriorForwardSampling(10, [m.x], infr, [m.y]) (test_inference_outcome_passing_success):
+    the losses fall, and the forward samples of y are N(x, 1) around the observed x."""
+    from mxfusion_amd.inference import GradBasedInference, MAP, BatchInferenceLoop, VariationalPosteriorForwardSampling
+    rng = np.random.RandomState(0)
+    D = 10
+    y, x = rng.rand(D), rng.rand(D)
+
+    def run(observed_names):
+        m = _normal_normal_model()
+        losses = []
+
+        class Rec(BatchInferenceLoop):
+            def run(self, infr_executor, data, **kw):
+                def wrapped(*a):
+                    out = infr_executor(*a)
+                    losses.append(float(out[0].detach()))
+                    return out
+                return super(Rec, self).run(wrapped, data, **kw)
+        infr = GradBasedInference(MAP(model=m, observed=[getattr(m, n) for n in observed_names]), grad_loop=Rec(), dtype=DT)
+        infr.run(max_iter=10, learning_rate=0.05, **{n: _t({'y': y, 'x': x}[n]) for n in observed_names})
+        assert len(losses) >= 10 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+        return m, infr
+    run(['y'])
+    m, infr = run(['y', 'x'])
+    infr2 = VariationalPosteriorForwardSampling(10, [m.x], infr, [m.y], dtype=DT)
+    ys, = infr2.run(x=_t(x))
+    assert ys.shape == (10, D) and torch.isfinite(ys).all()
+    assert float((ys.mean(0) - _t(x)).abs().max()) < 2.0          # 10 draws of N(x, 1)
+
+
+def test_change_default_dtype():
+    """inference_alg_test.py:65-83: with config.DEFAULT_DTYPE = 'float64' a model built without dtype arguments runs in float64."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.common import config
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.inference import GradBasedInference, MAP
+    old = config.DEFAULT_DTYPE
+    config.DEFAULT_DTYPE = 'float64'
+    try:
+        rng = np.random.RandomState(0)
+        data = rng.randn(100) * np.sqrt(5.) + 3.
+        m = Model()
+        m.mu = Variable()
+        m.s = Variable(transformation=PositiveTransformation())
+        m.Y = Normal.define_variable(mean=m.mu, variance=m.s, shape=(100,))
+        infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.Y]))
+        infr.run(Y=_t(data), learning_rate=0.1, max_iter=2)
+        assert infr.params[m.mu].dtype == torch.float64 and infr.params[m.s].dtype == torch.float64
+    finally:
+        config.DEFAULT_DTYPE = old

@@ -262,3 +262,30 @@ def test_module_clone():
     g0 = m.Y.factor.svgp_log_pdf._f32_guard()
     g1 = m.clone().Y.factor.svgp_log_pdf._f32_guard()
     assert g0 is not g1 and g0.slot != g1.slot
+
+
+def test_set_prior_module_variable_access_and_graph_printing():
+    """variable_test.py:28-39 (set_prior puts the distribution and its inputs into the variable's graph), factor_graph_test.py:431-438
+    (a module's kernel parameter is reachable from the model by UUID; printing a graph lists its factors)."""
+    import torch
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions import Normal
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    m = Model(verbose=False)
+    m.x = Variable()
+    d = Normal(mean=torch.tensor([0.]), variance=torch.tensor([1e6]))
+    m.x.set_prior(d)
+    assert m.x.factor is d and any(f is d for f in m._factors) and all(v.uuid in m for _, v in d.inputs)
+    m1 = Model()
+    m1.N = Variable()
+    m1.X = Variable(shape=(m1.N, 3))
+    m1.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m1.kernel = RBF(input_dim=3, variance=1, lengthscale=1)
+    m1.Y = GPRegression.define_variable(X=m1.X, kernel=m1.kernel, noise_var=m1.noise_var, shape=(m1.N, 1))
+    l = m1.Y.factor.kernel.lengthscale
+    assert m1[l.uuid] == l
+    txt = str(m1)
+    assert txt.startswith('Model (') and '~ GPRegression(' in txt and 'noise_var=' in txt
+    assert '~ Normal(mean=' in str(m)
