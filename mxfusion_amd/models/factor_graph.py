@@ -61,6 +61,35 @@ class FactorGraph(object):
             lines.append(outs + (' = ' if isinstance(f, FunctionEvaluation) else ' ~ ') + str(f))
         return '\n'.join(lines)
 
+    # ---- the reference's serialisation / reconciliation entry points (factor_graph.py:479-643), implemented in util/graph_json.py ------
+    def as_json(self):
+        """factor_graph.py:619-628: the networkx node-link dictionary of this graph, laid out as the reference writes it."""
+        from ..util import graph_json
+        return graph_json.graph_as_json(self)
+
+    @staticmethod
+    def save(graph_file, json_graphs):
+        """factor_graph.py:630-643."""
+        import json
+        with open(graph_file, 'w') as f:
+            json.dump(json_graphs, f, ensure_ascii=False)
+
+    @staticmethod
+    def load_graphs(graphs_list, existing_graphs=None):
+        """factor_graph.py:604-617: the saved graphs as read-only SavedGraph objects (uuid / name / type / edges -- what reconciliation
+        needs; rebuilding live components from JSON is not supported: a model is re-created from its script and reconciled)."""
+        from ..util import graph_json
+        return graph_json.load_graphs(graphs_list if isinstance(graphs_list, list) else [graphs_list])
+
+    @staticmethod
+    def reconcile_graphs(current_graphs, primary_previous_graph, secondary_previous_graphs=None, primary_current_graph=None):
+        """factor_graph.py:479-524: {uuid in the previous graphs: uuid in the current graphs}; the previous graphs may be live FactorGraphs
+        or SavedGraph objects from load_graphs."""
+        from ..util import graph_json
+        as_saved = lambda g: graph_json.load_graphs([graph_json.graph_as_json(g)])[0] if isinstance(g, FactorGraph) else g
+        cur = ([primary_current_graph] if primary_current_graph is not None else []) + list(current_graphs)
+        return graph_json.reconcile_graphs(cur, as_saved(primary_previous_graph), [as_saved(g) for g in (secondary_previous_graphs or [])])
+
     def clone(self, leaves=None):
         """factor_graph.py:415-477: an independent copy of the graph -- same topology, same UUIDs and names, new component objects (modules
         with their internal graphs and attached algorithms, kernels with their parameter Variables included); array values (constants,

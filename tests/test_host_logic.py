@@ -289,3 +289,46 @@ def test_set_prior_module_variable_access_and_graph_printing():
     txt = str(m1)
     assert txt.startswith('Model (') and '~ GPRegression(' in txt and 'noise_var=' in txt
     assert '~ Normal(mean=' in str(m)
+
+
+def test_replicate_and_reconcile_gp_model(tmp_path):
+    """factor_graph_test.py:158-165 (test_replicate_gp_model), :288-292 (test_reconcile_gp_model), :368-395
+    (test_save_reload_then_reconcile_gp_module), through the reference's own entry points on FactorGraph: the clone holds the same
+    components (model and the module's internal graphs, same shapes); two independently built copies of the script reconcile 1:1 over
+    every component of the model and of the module's graphs; so does a copy saved to JSON and loaded back."""
+    import json
+    import torch
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.models import FactorGraph
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+
+    def make():
+        m = Model()
+        m.N = Variable()
+        m.X = Variable(shape=(m.N, 3))
+        m.noise_var = Variable(transformation=PositiveTransformation(), initial_value=torch.tensor([1.]))
+        kernel = RBF(input_dim=3, variance=torch.tensor([1.]), lengthscale=torch.tensor([1.]))
+        m.Y = GPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, shape=(m.N, 2))
+        return m
+
+    def uuids(m):
+        gp = m.Y.factor
+        s = set(m.variables)                                # (the model's variables + those of the module's internal graphs)
+        for g in [gp._module_graph] + list(gp._extra_graphs):
+            s |= set(g.variables)
+        return s
+    m = make()
+    m2 = m.clone()
+    assert uuids(m) == uuids(m2)
+    assert all(tuple(getattr(s, 'uuid', s) for s in m[u].shape) == tuple(getattr(s, 'uuid', s) for s in m2[u].shape) for u in m.variables)
+    m1, m3 = make(), make()
+    cmap = FactorGraph.reconcile_graphs([m1], m3)
+    assert len(set(cmap.values())) == len(cmap)                       # 1:1
+    assert uuids(m3) <= set(cmap) and set(cmap[u] for u in uuids(m3)) == uuids(m1)
+    f = str(tmp_path / 'graph.json')
+    FactorGraph.save(f, m3.as_json())
+    loaded = FactorGraph.load_graphs([json.load(open(f))])[0]
+    cmap2 = FactorGraph.reconcile_graphs([m1], loaded)
+    assert {k: v for k, v in cmap2.items() if k in uuids(m3)} == {k: v for k, v in cmap.items() if k in uuids(m3)}
