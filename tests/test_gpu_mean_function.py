@@ -161,3 +161,57 @@ def test_gp_log_pdf_baseline_config_1_literal_shape():
         for kk, gg in gref.items():
             a, b = r[kk].double().cpu().numpy().ravel(), gg.numpy().ravel()
             assert np.linalg.norm(a - b) <= gtol * np.linalg.norm(b), (dt, kk, np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize('which', ['gp', 'svgp', 'sgp'])
+@pytest.mark.parametrize('diagonal', [True, False])
+def test_sampling_prediction_with_a_mean_function(golden_dir, which, diagonal):
+    """The reference's test_sampling_prediction_w_mean (gpregression_test.py:309-350, svgpregression_test.py, sparsegpregression_test.py):
+    the sampling-prediction algorithm of each module behind a trainable mean function, with injected noise -- the draws equal the oracle's
+    (predictive moments of the zero-mean model on Y - m(X), plus m(X*))."""
+    from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
+    from mxfusion_amd.inference import Inference, MAP, TransferInference, ModulePredictionAlgorithm
+    from mxfusion_amd.modules.gp_modules.gp_regression import GPRegressionSamplingPrediction
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionSamplingPrediction
+    from mxfusion_amd.modules.gp_modules.sparsegp_regression import SparseGPRegressionSamplingPrediction
+    g = dict(np.load(os.path.join(golden_dir, {'gp': 'kat_gp.npz', 'svgp': 'kat_svgp.npz', 'sgp': 'kat_sgp.npz'}[which])))
+    D = g['Y'].shape[1]
+    rng = np.random.RandomState(11)
+    W0, b0 = rng.randn(3, D) * 0.8, rng.randn(D) * 0.3
+    m = _model(which, g, D, W0, b0)
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.initialize(X=g['X'].shape, Y=g['Y'].shape)
+    gp = m.Y.factor
+    if which == 'svgp':
+        post = gp._extra_graphs[0]
+        infr.params[post.qU_mean], infr.params[post.qU_cov_W], infr.params[post.qU_cov_diag] = _t(g['qm']), _t(g['qW']), _t(g['qd'])
+    infr.run(X=_t(g['X']), Y=_t(g['Y']))
+    S, Nt = 3, g['Xt'].shape[0]
+    eps = rng.randn(S, Nt, D)
+    jit = 0. if diagonal else 1e-8
+    cls, name = {'gp': (GPRegressionSamplingPrediction, 'gp_predict'), 'svgp': (SVGPRegressionSamplingPrediction, 'svgp_predict'),
+                 'sgp': (SparseGPRegressionSamplingPrediction, 'sgp_predict')}[which]
+    alg = cls(gp._module_graph, gp._extra_graphs[0], [gp._module_graph.X], rand_gen=MockRandomGenerator(_t(eps)), diagonal_variance=diagonal, jitter=jit)
+    gp.attach_prediction_algorithms(targets=gp.output_names, conditionals=gp.input_names, algorithm=alg, alg_name=name)
+    infr2 = TransferInference(ModulePredictionAlgorithm(model=m, observed=[m.X], target_variables=[m.Y], num_samples=S), infr_params=infr.params, dtype=DT)
+    ys = infr2.run(X=_t(g['Xt']))[0]
+    T = O.T
+    k = O.RBF(3, ARD=True)
+    kp = {'rbf_lengthscale': T(g['ls'])[None], 'rbf_variance': T(g['var'])[None]}
+    Xt = T(g['Xt'])[None]
+    mean_t, mean_x = _mean_fn(Xt, T(W0)[None], T(b0)[None]), _mean_fn(T(g['X'])[None], T(W0)[None], T(b0)[None])
+    if which == 'gp':
+        _, (Xc, L, LinvY) = O.gp_log_pdf(k, T(g['X'])[None], T(g['Y'])[None], T(g['noise'])[None], kp, jitter=1e-6, mean=mean_x, return_posterior=True)
+        ref = O.gp_predict_sample(k, Xt, T(g['noise'])[None], Xc[None], L[None], LinvY[None], kp, T(eps), mean=mean_t, diagonal_variance=diagonal, jitter=jit)
+    elif which == 'svgp':
+        ref = O.svgp_predict_sample(k, Xt, T(g['Z'])[None], T(g['noise'])[None], T(g['qm'])[None], T(g['qW'])[None], T(g['qd'])[None], kp, T(eps),
+                                    jitter=jit, mean=mean_t, diagonal_variance=diagonal)
+    else:
+        _, (wv, L, LA) = O.sgp_log_pdf(k, T(g['X'])[None], T(g['Y'])[None], T(g['Z'])[None], T(g['noise'])[None], kp, jitter=1e-8, mean=mean_x,
+                                       return_posterior=True)
+        ref = O.sgp_predict_sample(k, Xt, T(g['Z'])[None], T(g['noise'])[None], L[None], LA[None], wv[None], kp, T(eps), mean=mean_t,
+                                   diagonal_variance=diagonal, jitter=jit)
+    assert ys.shape == (S, Nt, D)
+    assert np.allclose(ys.cpu().numpy(), ref.numpy(), atol=1e-7, rtol=1e-7), (which, diagonal)
+    # the mean matters: the same draws without it differ
+    assert float((ys.cpu() - (ref - mean_t)).abs().max()) > 1e-2
