@@ -732,7 +732,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     static const int het_stream_env = MXF_KNOB("MXF_SVGP_HET_STREAM", 1);
     const int64_t SBh = ((sX == 0) ? (int64_t)1 : (int64_t)S) * B;
     const bool het_stream = het_stream_env && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
-                            (B % 16 == 0) && (M % 16 == 0) && M >= 128 && h->svgp_form == MXF_SVGP_EXPLICIT && mxf_svgp_bwd_is_mfma(dtype, SBh, B, Q, P, X);
+                            (B % 16 == 0) && (M % 16 == 0) && M >= 128 && h->svgp_form == MXF_SVGP_EXPLICIT && mxf_svgp_bwd_is_mfma(kind, dtype, SBh, B, Q, P, X);
     const bool het = (nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16) && !het_stream;
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
     if (S > 1 && sX == 0 && sY == 0) MXF_FAIL(h, -3, "mxf_svgp_logpdf: S > 1 with neither X nor Y sampled");
@@ -1075,7 +1075,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // [T; U] = [H0; w^T] Kuf_all
     // (training step on the split path whose reverse pass runs on the matrix pipe: T is written in 16-column blocks, so that each 16 x 16
     //  tile that pass reads is one contiguous KB instead of 16 pieces of 64 bytes, 4 SB bytes apart)
-    const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_is_mfma(dtype, SB, B, Q, P, Text)) ? 1 : 0;
+    const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_is_mfma(kind, dtype, SB, B, Q, P, Text)) ? 1 : 0;
     if (use_split) {
         unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
         if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st, false); if (rc) return rc; }      // (word cleared by svgp_init_kernel)

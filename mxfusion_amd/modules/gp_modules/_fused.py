@@ -63,7 +63,7 @@ class Float32Guard(object):
       EXPLICIT  cond_1(Kuu + jitter I) <= LIMIT            T = H0 Kuf with the explicit inverse H0 = Kuu^-1 - Kuu^-1 Su Kuu^-1: two full-width
                                                            split GEMMs, the fastest form; rounding error ~ cond 2^-24 (ELBO 5e-8 .. 5e-6 up to
                                                            cond ~ 1.4e3, 2e-3 at 5e4: tests/probes/f32_accuracy.py)
-      WHITENED  LIMIT < cond <= LIMIT_WHITENED (5e6)       the factorised form the reference evaluates (svgp_regression.py:83-92) on the split
+      WHITENED  LIMIT < cond <= LIMIT_WHITENED (1e6)       the factorised form the reference evaluates (svgp_regression.py:83-92) on the split
                                                            GEMMs: V = L^-1 Kuf, Phi = V V^T, T = L^-T (I - A_s A_s^T) V (mxf_svgp_configure,
                                                            csrc/whiten.hip): three full-width products, error ~ sqrt(cond) 2^-24
       F64       above, or where the whitened form does     the streaming stage in float64 (inputs widened, outputs narrowed; same C-ABI call with
@@ -79,7 +79,7 @@ class Float32Guard(object):
     EXPLICIT, WHITENED, F64 = 0, 1, 2
     NAMES = ('explicit-inverse float32', 'whitened float32', 'float64')
     LIMIT = 3e3
-    LIMIT_WHITENED = 5e6
+    LIMIT_WHITENED = 1e6
     HYSTERESIS = 0.25
     enabled = True          # class-wide switch (bench.py --no-f32-guard, tests): False = always the explicit float32 form
     force = None            # measurements (bench.py --f32-form): every float32 call at this level, whatever its condition number

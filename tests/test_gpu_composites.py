@@ -454,7 +454,10 @@ def test_svgp_logpdf_heteroscedastic_streams_on_the_fused_path(B, M, Q, S, kind,
     finally:
         _lib.svgp_timing(dev, False)
     assert int(r['info'].abs().sum()) == 0
-    assert 'planes_a' in stages and 't_gemm' in stages and 'reverse_pass' in stages, stages      # the streaming split path ran
+    if kind == 'rbf':
+        assert 'planes_a' in stages and 't_gemm' in stages and 'reverse_pass' in stages, stages      # the streaming split path ran
+    else:       # (r04: the Matern kinds keep the difference-form reverse pass -- gram_bwd.hip, mxf_svgp_bwd_is_mfma -- and with it the generic per-row-noise path)
+        assert 'planes_a' not in stages, stages
     ref = logL.detach().numpy()
     assert np.abs(r['logL'].double().cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), (r['logL'], ref)
     for n, key in zip(names, ('dX', 'dY', 'dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')):

@@ -1,6 +1,6 @@
 """The float32 guard of the SVGP module (modules/gp_modules/_fused.py: Float32Guard): three levels PER MODULE --
 explicit-inverse float32 up to cond_1(Kuu + jitter I) = 3e3, WHITENED float32 (the reference's factorised form, svgp_regression.py:83-92, on
-the split GEMMs) up to 5e6, float64 above or where the whitened form does not apply (no-grad evaluations, combination kernels).  The first
+the split GEMMs) up to 1e6, float64 above or where the whitened form does not apply (no-grad evaluations, combination kernels).  The first
 call of an owner is checked synchronously; later calls through the condition number every finished call publishes into the owner's slot
 of pinned host memory (mxf_svgp_cond_slot, no synchronisation).  Checked against the ORACLE at B = 8192, M = 1024."""
 import warnings
@@ -51,9 +51,9 @@ def _module_call(a, guard=None, grad=True):
 def test_ill_conditioned_start_is_never_evaluated_in_a_form_that_cannot_hold_it():
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard
     G = Float32Guard
-    # cond_1 ~ 1e6: the explicit form fails, the whitened float32 form holds north_star's bar -- through the float32 API, first call
-    a = _inputs(3.0)
-    ref = _oracle(a, 3.0)
+    # length-scale 2.6, cond_1 ~ 2e5 (3.0 gives 1.1e6, beyond the whitened limit of 1e6 since r04 late): the explicit form fails, the whitened float32 form holds north_star's bar -- through the float32 API, first call
+    a = _inputs(2.6)
+    ref = _oracle(a, 2.6)
     g = G('t1')
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
@@ -83,8 +83,8 @@ def test_ill_conditioned_start_is_never_evaluated_in_a_form_that_cannot_hold_it(
 
 def test_guard_moves_without_synchronising_and_comes_back():
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
-    good, bad = _inputs(1.0), _inputs(3.0)
-    ref_good, ref_bad = _oracle(good, 1.0), _oracle(bad, 3.0)
+    good, bad = _inputs(1.0), _inputs(2.6)
+    ref_good, ref_bad = _oracle(good, 1.0), _oracle(bad, 2.6)
     g = G('drift')
     with warnings.catch_warnings(record=True):
         warnings.simplefilter('always')
@@ -104,8 +104,8 @@ def test_guard_is_per_module_and_covers_evaluations():
     """Two owners on one handle (the two layers of a deep GP): the ill-conditioned one moves to the whitened form, the other stays on the
     fast form (the r03 guard was process-wide and sticky).  A no-grad evaluation above the limit runs in float64."""
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
-    good, bad = _inputs(1.0, seed=1), _inputs(3.0)
-    ref_bad = _oracle(bad, 3.0)
+    good, bad = _inputs(1.0, seed=1), _inputs(2.6)
+    ref_bad = _oracle(bad, 2.6)
     g1, g2 = G('layer1'), G('layer2')
     assert g1.slot != g2.slot
     with warnings.catch_warnings(record=True):
@@ -206,7 +206,7 @@ def test_two_layer_model_keeps_the_first_layer_on_the_fast_form():
 def test_replayed_hipgraph_follows_the_guard():
     """BatchInferenceLoop(use_graph=True) replays captured launches without running any Python, so a captured step keeps the float32 form
     that was current at capture time.  The loop polls the guards before every replay (Float32Guard.poll_all: no synchronisation) and
-    re-captures when a level changed: after the length-scale moves from 1 to 3 (cond_1 14 -> 1e6) the replayed step is the WHITENED one
+    re-captures when a level changed: after the length-scale moves from 1 to 2.6 (cond_1 14 -> 2e5) the replayed step is the WHITENED one
     and its loss matches the oracle again."""
     from mxfusion_amd import Model, Variable
     from mxfusion_amd.components.variables import PositiveTransformation
@@ -259,8 +259,8 @@ def test_replayed_hipgraph_follows_the_guard():
         assert 'graph' in loop._gstate
         g = gp.svgp_log_pdf._f32_guard()
         assert g.tier == G.EXPLICIT and abs(l1 - oracle(1.0)) <= 1e-5 * abs(l1)
-        infr.params[kern.lengthscale] = t(np.full(Q, 3.0))      # written in place: the captured graph reads the new values
-        ref3 = oracle(3.0)
+        infr.params[kern.lengthscale] = t(np.full(Q, 2.6))      # written in place: the captured graph reads the new values
+        ref3 = oracle(2.6)
         step()                                            # the OLD (explicit) graph runs once more and publishes cond ~ 1e6
         losses = [step() for _ in range(3)]               # poll -> level change -> eager whitened warm-up -> capture -> replay
         assert g.tier == G.WHITENED and 'graph' in loop._gstate
