@@ -670,7 +670,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
     ap.add_argument('--f32-form', default='auto', choices=['auto', 'explicit', 'whitened', 'float64'],
-                    help="float32 SVGP calls: 'auto' = the per-module guard picks (explicit-inverse up to cond 3e3, whitened up to 5e6, float64 above); "
+                    help="float32 SVGP calls: 'auto' = the per-module guard picks (explicit-inverse up to cond 1e3, whitened up to 1e6, float64 above); "
                          "the others force one form for a measurement")
     ap.add_argument('--trained-like', action='store_true', help='svgp workload: time the step at the trained-like parameters (length-scale 2.2, '
                     'noise 0.02, non-trivial q(u)) instead of the initial point')
@@ -713,7 +713,7 @@ def main():
 
     def guard_report():
         """float32 validity of what was timed: the largest cond_1(Kuu + jitter I) the training calls published and the level every SVGP
-        module ended on (explicit-inverse float32 up to 3e3, whitened float32 up to 5e6, float64 above: DESIGN.md section 5)."""
+        module ended on (explicit-inverse float32 up to 1e3, whitened float32 up to 1e6, float64 above: DESIGN.md section 5)."""
         from mxfusion_amd.modules.gp_modules._fused import Float32Guard
         torch.cuda.synchronize()
         return Float32Guard.report(torch.device('cuda', torch.cuda.current_device()))
@@ -847,7 +847,7 @@ def main():
         out.update(step_breakdown(infr, loop, Yd, args.lr, M, N * S_local))
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == 'float32' and not args.trained_like and args.f32_form == 'auto':
         # the regime the step is used in: the same step at trained-like parameters (explicit form: cond ~ 1.4e3 < 3e3), and in the
-        # whitened float32 form the guard selects above cond 3e3
+        # whitened float32 form the guard selects above cond 1e3
         from mxfusion_amd.modules.gp_modules._fused import Float32Guard
         nst = max(3, args.steps // 2)
         set_trained_like(m, infr, Q, M, td)

@@ -39,7 +39,7 @@ class GradBasedInference(Inference):
         self._check_float32_validity()
         return out
 
-    F32_COND_LIMIT = 3e3
+    F32_COND_LIMIT = 1e3
 
     def _check_float32_validity(self):
         """The float32 forms of the SVGP bound are valid up to a condition number of Kuu + jitter I each (explicit inverse: 3e3, whitened:

@@ -60,5 +60,5 @@ for it in range(n):
         ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
                              {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6).numpy()
         eo = float(np.abs(v64 - ref).max() / np.abs(ref).max())
-    bad = (not np.isfinite(ev)) or ev > 2e-5 or eg > 5e-3 or (eo is not None and eo > 1e-9) or not all(np.isfinite(x).all() for x in g32)
+    bad = (not np.isfinite(ev)) or ev > 2e-5 or eg > 5e-3 or (eo is not None and eo > max(1e-9, 1e-14 * cond)) or not all(np.isfinite(x).all() for x in g32)
     print('%s  f32-f64 value %.1e grad %.1e  f64-oracle %s %s' % (tag, ev, eg, ('%.1e' % eo) if eo is not None else '-', 'BAD' if bad else ''), flush=True)

@@ -1,5 +1,5 @@
 """The float32 guard of the SVGP module (modules/gp_modules/_fused.py: Float32Guard): three levels PER MODULE --
-explicit-inverse float32 up to cond_1(Kuu + jitter I) = 3e3, WHITENED float32 (the reference's factorised form, svgp_regression.py:83-92, on
+explicit-inverse float32 up to cond_1(Kuu + jitter I) = 1e3, WHITENED float32 (the reference's factorised form, svgp_regression.py:83-92, on
 the split GEMMs) up to 1e6, float64 above or where the whitened form does not apply (no-grad evaluations, combination kernels).  The first
 call of an owner is checked synchronously; later calls through the condition number every finished call publishes into the owner's slot
 of pinned host memory (mxf_svgp_cond_slot, no synchronisation).  Checked against the ORACLE at B = 8192, M = 1024."""
