@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
 
 // dZ, dls, R from the row-side sums of svgp_bwd_mfma_kernel (one row per thread; float64: z^2 S - 2 z B + x^2 C cancels a digit or two)
 // cs: the extra scale of the pass's coordinates (sqrt(log2(e) / 2) for RBF, whose pass also leaves dvar = -(sum_m S_m) / variance to this kernel)
-__global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z, const float* __restrict__ ls,
+__global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, int ard, const float* __restrict__ Z /* prescaled: Zs */, const float* __restrict__ ls,
                                                               const double* __restrict__ zacc, const double* __restrict__ dls3,
                                                               float* __restrict__ dZ, float* __restrict__ dls, float* __restrict__ R, double cs,
                                                               const float* __restrict__ var, float* __restrict__ dvar_from_S) {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void svgp_bwd_finish_kernel(int64_t M, int Q, 
         for (int q = 0; q < 8; ++q) {
             if (q < Q) {
                 const double ilq = 1.0 / (double)ls[ard ? q : 0];
-                const double z = (double)(Z[m * Q + q] / ls[ard ? q : 0] * (float)cs), Bq = zacc[m * 16 + q];      // the pass's own scaled coordinate (float32)
+                const double z = (double)Z[m * 8 + q], Bq = zacc[m * 16 + q];      // the pass's own scaled, centred coordinate (bwd_prescale_kernel's output: 8 per row)
                 if (dZ) dZ[m * Q + q] += (float)((z * S - Bq) * ilq / cs);
                 g12[q] = z * (z * S - 2.0 * Bq);
             }
@@ -961,8 +961,24 @@ int bwd_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q, const v
 // mx (optional; zeroed by the caller): bit pattern of max_i |aux[i]| (yv == nullptr: the row w) or of max_i |yv[s * sY + i % B] - aux[i]| (the
 // residual y_n - U_n) -- the bound behind the f16 accumulation of the matrix-pipe pass.  One atomic per workgroup, and only if it can raise
 // the word (non-negative floats order as their bit patterns).
+// centre[q] = mean of Z[m][q] over the FIRST 64 inducing inputs (rows the caller appended to pad M -- far-away decoupled points, svgp_regression.py
+// _pad_inducing -- come last and must not drag the centre away): the matrix-pipe pass forms r2 = |x|^2 + |z|^2 - 2 x.z in float32, whose absolute error grows with the NORMS of
+// the scaled coordinates -- distances are translation invariant, so both operands are centred on the inducing inputs first (r04: inputs at an
+// offset of 100 / 1000 units -- years, raw sensor readings -- gave 1e-2 / 98 % gradient errors and 1e-5 / 2e-2 on the bound un-centred)
+__global__ __launch_bounds__(256) void bwd_centre_kernel(int64_t M, int Q, const float* __restrict__ Z, float* __restrict__ centre) {
+    __shared__ double red[4];
+    const int q = blockIdx.x;
+    double s = 0.0;
+    for (int64_t m = threadIdx.x; m < M; m += 256) s += (double)Z[m * Q + q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) centre[q] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)M);
+}
+
 __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restrict__ src, int64_t B, int Q, const float* __restrict__ ls, int ard,
-                                                           float* __restrict__ dst, float* __restrict__ norms, float cs,
+                                                           const float* __restrict__ centre, float* __restrict__ dst, float* __restrict__ norms, float cs,
                                                            const float* __restrict__ aux, const float* __restrict__ yv, int64_t sY,
                                                            unsigned* __restrict__ mx) {
     __shared__ float smax[4];
@@ -982,7 +998,7 @@ __global__ __launch_bounds__(256) void bwd_prescale_kernel(const float* __restri
     if (i >= B) return;
     float v[8], n2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? src[r * Q + q] / ls[ard ? q : 0] * cs : 0.f; n2 = fmaf(v[q], v[q], n2); }
+    for (int q = 0; q < 8; ++q) { v[q] = (q < Q) ? (src[r * Q + q] - centre[q]) / ls[ard ? q : 0] * cs : 0.f; n2 = fmaf(v[q], v[q], n2); }
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     *reinterpret_cast<f32x4*>(dst + r * 8) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(dst + r * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1017,9 +1033,11 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     if (SB > 2147483647LL - 4096) MXF_FAIL(h, -3, "svgp reverse pass: more than 2^31 columns (%lld)", (long long)SB);       // (32-bit column indices in the pass)
     const int64_t nsamp = SB / B;         // (the matrix-pipe pass requires B % 16 == 0 and whole samples: SB = S B)
     if (nsamp > 65535 || nsamp * B != SB) MXF_FAIL(h, -3, "svgp reverse pass: bad sample layout (SB %lld, B %lld)", (long long)SB, (long long)B);
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, st, Z, M, Q, ls, ard, Zs, (float*)nullptr, cs,
+    float* centre = reinterpret_cast<float*>(zacc + (size_t)M * 16 + 9);            // (eight floats behind the two bound words; written after the memset above)
+    hipLaunchKernelGGL(bwd_centre_kernel, dim3((unsigned)Q), dim3(256), 0, st, M < 64 ? M : (int64_t)64, Q, Z, centre);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, st, Z, M, Q, ls, ard, (const float*)centre, Zs, (float*)nullptr, cs,
                        w, (const float*)nullptr, (int64_t)0, f16 ? mx : (unsigned*)nullptr);
-    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)nsamp), dim3(256), 0, st, X, B, Q, ls, ard, Xs, Xn, cs,
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)nsamp), dim3(256), 0, st, X, B, Q, ls, ard, (const float*)centre, Xs, Xn, cs,
                        Urow, Y, sY, f16 ? mx + 1 : (unsigned*)nullptr);
     BwdMfmaArgs a;
     a.Zs = Zs; a.Xs = Xs; a.Xn = Xn; a.ls = ls; a.var = var; a.T = Text; a.U = Text + M * SB; a.Y = Y; a.w = w; a.noise = noise;
@@ -1055,7 +1073,7 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
         default: MXF_FAIL(h, -2, "svgp reverse pass: kind %d has no stationary reverse mode", kind);
     }
 #undef MF_GO
-    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, Z, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R,
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, (const float*)Zs, ls, (const double*)a.zacc, (const double*)a.dls3, dZ, dls, R,
                        (double)cs, var, kind == MXF_K_RBF ? dvar : (float*)nullptr);
     MXF_LAUNCH_CHECK(h);
     return 0;

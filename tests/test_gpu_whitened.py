@@ -306,3 +306,24 @@ def test_float32_gradients_with_inducing_inputs_next_to_data_points(kind, Q):
     assert abs(got['logL'][0] - ref[0]) <= 1e-5 * abs(ref[0])
     for k, g in gref.items():
         assert _nrm(got[k], g) <= 5e-4, (k, _nrm(got[k], g))
+
+
+@pytest.mark.parametrize('offset', [100.0, 1000.0])
+def test_float32_training_call_does_not_depend_on_where_the_inputs_sit(offset):
+    """Inputs at an offset (years, raw sensor readings: X, Z = offset + U(-2, 2)).  The matrix-pipe reverse pass forms r2 = |x|^2 + |z|^2 - 2 x.z
+    in float32; un-centred that gave 1e-2 gradient errors at an offset of 100 and 98 % (2e-2 on the bound) at 1000.  Both operands are centred on
+    the inducing inputs now (translation invariance): bound and gradients against the oracle as for centred data."""
+    from mxfusion_amd import _lib
+    rng = np.random.default_rng(9)
+    B, M, Q = 2048, 128, 5
+    X = offset + rng.uniform(-2., 2., (1, B, Q))
+    Y = (np.sin((X[0] - offset) @ rng.standard_normal((Q, 1))) + 0.05 * rng.standard_normal((B, 1)))[None]
+    Z = offset + rng.uniform(-2., 2., (M, Q))
+    a = dict(X=X, Y=Y, Z=Z, noise=np.array([0.05]), qm=0.3 * rng.standard_normal((M, 1)), qW=0.3 * rng.standard_normal((M, M)) / np.sqrt(M),
+             qd=rng.uniform(0.05, 0.5, M), ls=np.full(Q, 0.3 * np.sqrt(Q)), var=np.array([1.1]))
+    a = {k: np.asarray(v, dtype=np.float32).astype(np.float64) for k, v in a.items()}
+    ref, gref = _oracle(a)
+    got = _run(a, _lib.FORM_EXPLICIT)
+    assert abs(got['logL'][0] - ref[0]) <= 1e-5 * abs(ref[0])
+    for k, g in gref.items():
+        assert _nrm(got[k], g) <= 2e-4, (k, _nrm(got[k], g))
