@@ -180,6 +180,40 @@ class Float32Guard(object):
         if mx > 0:
             self._move(mx)
 
+    # ---- input range (RBF): the matrix-pipe reverse pass forms r2 = |x|^2 + |z|^2 - 2 x.z from coordinates centred on the inducing inputs and
+    # scaled by the length-scales; its absolute error ~1e-7 (|x|^2 + |z|^2) costs the gradients 1e-4 at a radius of ~80 length-scales -- a long one-dimensional series
+    # with a short length-scale.  Checked on an owner's first call (synchronously) and every RANGE_EVERY calls after that (device reduction,
+    # copied to pinned host memory without synchronising, read by a later call); too wide -> the owner's float32 calls run in float64.
+    RANGE_LIMIT = 100.0         # (tests/probes/range_accuracy.py: gradients 3.5e-5 at a radius of 40 length-scales, 1.4e-4 at 80, 6e-4 at 160; the bound itself stays at 1e-7)
+    RANGE_EVERY = 32
+
+    def range_too_wide(self, X, Z, ls):
+        if not (Float32Guard.enabled and Float32Guard.force is None and X.is_cuda):
+            return False
+        n = getattr(self, '_range_calls', 0)
+        self._range_calls = n + 1
+        if getattr(self, '_range_host', None) is None:
+            self._range_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._range_wide = False
+        if n % self.RANGE_EVERY == 0:
+            with torch.no_grad():
+                c = Z[..., :64, :].mean(-2, keepdim=True)
+                r = (((X - c) / ls.reshape(ls.shape[0], 1, -1)) ** 2).sum(-1).amax().sqrt().float().reshape(1)      # Euclidean radius in length-scales
+            if n == 0:
+                self._range_host[0] = float(r)           # (an owner's first call synchronises anyway: first_call_needs_rerun)
+            else:
+                self._range_host.copy_(r, non_blocking=True)
+        val = float(self._range_host[0])
+        wide = val > (0.8 * self.RANGE_LIMIT if self._range_wide else self.RANGE_LIMIT)
+        if wide and not self._range_wide:
+            import warnings
+            warnings.warn('mxfusion_amd: the inputs of %s span %.0f length-scales around the inducing inputs: the float32 reverse pass of the RBF '
+                          'kernel loses accuracy there (DESIGN.md section 5); its calls run in float64 from now on.' % (self.name, val))
+            Float32Guard.epoch += 1
+        self._range_wide = wide
+        self.range_radius = val
+        return wide
+
     def form(self, dev, whitened_ok):
         """The level this call runs at (enabled guards only; the caller holds float32 CUDA inputs)."""
         if not Float32Guard.enabled:
@@ -207,7 +241,7 @@ class Float32Guard(object):
         return need > ran_at
 
 
-def _guarded(guard, dev, is_f32, whitened_ok, run):
+def _guarded(guard, dev, is_f32, whitened_ok, run, wide=False):
     """Run `run(tier)` under `guard`: picks the level, configures the handle (form + condition slot), re-runs an owner's first call when its
     synchronous check asks for a higher level.  run(tier) evaluates the call in float32 (EXPLICIT / WHITENED) or widened to float64 (F64)."""
     g = guard if guard is not None else Float32Guard.default
@@ -216,10 +250,12 @@ def _guarded(guard, dev, is_f32, whitened_ok, run):
         g.configure(dev, g.EXPLICIT)
         return run(g.EXPLICIT)
     tier = g.form(dev, whitened_ok)
+    if wide:                    # (range_too_wide: float64 whatever the condition number says)
+        tier = g.F64
     g.configure(dev, tier)
     r = run(tier)
     if g.first_call_needs_rerun(dev, tier, whitened_ok):
-        tier = g.F64 if (g.tier == g.WHITENED and not whitened_ok) else g.tier
+        tier = g.F64 if (wide or (g.tier == g.WHITENED and not whitened_ok)) else g.tier
         g.configure(dev, tier)
         r = run(tier)
     return r
@@ -250,7 +286,9 @@ class SVGPLogPdfFn(torch.autograd.Function):
             # the whitened form covers float32 TRAINING calls of the streaming (homoscedastic) path on split-capable shapes
             wok = is_f32 and want and homo and _lib.svgp_whitened_ok(_lib.F32, S, X.shape[-2], Z.shape[-2], X.shape[-1], Y.shape[-1],
                                                                       0 if X.shape[0] == 1 else X.shape[-2] * X.shape[-1])
-            r = _guarded(guard, X.device, is_f32, wok, run)
+            g_ = guard if guard is not None else Float32Guard.default
+            wide = bool(is_f32 and want and kind == 'rbf' and g_ is not None and (g_._range_wide if getattr(g_, '_range_by_module', False) else g_.range_too_wide(X, Z, ls)))
+            r = _guarded(guard, X.device, is_f32, wok, run, wide=wide)
         else:
             r = run(Float32Guard.EXPLICIT)
         if want:
@@ -285,7 +323,9 @@ class SVGPSampledLogPdfFn(torch.autograd.Function):
         if X.is_cuda:
             is_f32 = X.dtype == torch.float32
             wok = is_f32 and want and _lib.svgp_whitened_ok(_lib.F32, 1, X.shape[-2], Z.shape[-2], X.shape[-1], Y.shape[-1], 0)   # (one sample per inner call)
-            r = _guarded(guard, X.device, is_f32, wok, run)
+            g_ = guard if guard is not None else Float32Guard.default
+            wide = bool(is_f32 and want and kind == 'rbf' and g_ is not None and (g_._range_wide if getattr(g_, '_range_by_module', False) else g_.range_too_wide(X, Z, ls)))
+            r = _guarded(guard, X.device, is_f32, wok, run, wide=wide)
         else:
             r = run(Float32Guard.EXPLICIT)
         if want:

@@ -82,6 +82,10 @@ class SVGPRegressionLogPdf(VariationalInference):
         kind, ard = spec
         ls = kern_params[kern.name + '_lengthscale']
         var = kern_params[kern.name + '_variance']
+        if kind == 'rbf' and X.is_cuda and X.dtype == torch.float32 and torch.is_grad_enabled():
+            g_ = self._f32_guard()                      # the input-range check on the REAL rows and inducing inputs (the padding below is far away by design)
+            g_.range_too_wide(X, Z, ls)
+            g_._range_by_module = True
         X, Y, row_corr = self._pad_rows(X, Y, Z, noise_var, ls, var)                       # (rows first: the padded inducing points must clear them too)
         Z, mu, S_W, S_diag = self._pad_inducing(X, Y, Z, noise_var, mu, S_W, S_diag, ls, var)
         shared = (Z, noise_var, mu, S_W, S_diag, ls, var)

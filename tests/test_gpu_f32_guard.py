@@ -266,3 +266,38 @@ def test_replayed_hipgraph_follows_the_guard():
         assert g.tier == G.WHITENED and 'graph' in loop._gstate
         for l in losses:
             assert abs(l - ref3) <= 1e-5 * abs(ref3), (losses, ref3)
+
+
+def test_inputs_spanning_many_length_scales_run_in_float64():
+    """A long one-dimensional series with a short length-scale (inputs spanning +-200 length-scales around the inducing inputs): the float32
+    reverse pass of the RBF kernel forms r2 from norms and loses accuracy there, so the owner's calls run in float64 (checked synchronously on
+    its first call); the bound and the gradients hold the float64 bar against the oracle.  The same series with a length-scale that covers
+    it stays in float32."""
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G, SVGPLogPdfFn
+    rng = np.random.default_rng(2)
+    B, M, Q = 1024, 128, 1
+    X = np.sort(rng.uniform(0., 400., (1, B, Q)), axis=1)
+    Y = (np.sin(X[0] / 7.0) + 0.05 * rng.standard_normal((B, 1)))[None]
+    Z = np.linspace(0., 400., M)[:, None]
+    qm, qW, qd = 0.3 * rng.standard_normal((M, 1)), 0.1 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    for ell, expect_wide in ((1.0, True), (40.0, False)):          # (radius 200 / 5 length-scales; the limit is 100)
+        vals = {k: r32(v) for k, v in dict(X=X, Y=Y, Z=Z[None], noise=[[0.05]], qm=qm[None], qW=qW[None], qd=qd[None], ls=[[ell]], var=[[1.1]]).items()}
+        g = G('range-%g' % ell)
+        t = {k: torch.as_tensor(v, dtype=torch.float32).cuda().requires_grad_(k != 'Y') for k, v in vals.items()}
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            logL, info = SVGPLogPdfFn.apply(g, 'rbf', True, 1e-6, 1.0, t['X'], t['Y'], t['Z'], t['noise'], t['qm'], t['qW'], t['qd'], t['ls'], t['var'])
+            logL.sum().backward()
+        torch.cuda.synchronize()
+        assert g._range_wide == expect_wide, (ell, g.range_radius)
+        assert any('length-scales' in str(x.message) for x in w) == expect_wide
+        if expect_wide:
+            assert g.range_radius > 150
+            k = O.RBF(Q, ARD=True)
+            lv = {n: O.T(v).clone().requires_grad_(True) for n, v in vals.items()}
+            ref = O.svgp_log_pdf(k, lv['X'], lv['Y'], lv['Z'], lv['noise'], lv['qm'], lv['qW'], lv['qd'], {'rbf_lengthscale': lv['ls'], 'rbf_variance': lv['var']}, jitter=1e-6)
+            gX, gZ = torch.autograd.grad(ref.sum(), [lv['X'], lv['Z']])
+            assert abs(float(logL[0]) - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
+            nrm = lambda a, b: float(np.linalg.norm(a.ravel() - b.ravel()) / np.linalg.norm(b.ravel()))
+            assert nrm(t['X'].grad.double().cpu().numpy(), gX.numpy()) <= 1e-4 and nrm(t['Z'].grad.double().cpu().numpy(), gZ.numpy()) <= 1e-4
