@@ -346,7 +346,8 @@ __global__ __launch_bounds__(64) void gram_lean_kernel(const T* __restrict__ Xs_
 // norms (optional): norms[s][row] = sum_q out[s][row][q]^2 (the QT threads of a row are neighbouring lanes)
 template <typename T, int QT, int KIND>
 __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __restrict__ ls, int64_t sls, int ard, int64_t N, int Q,
-                                int64_t pad, T* __restrict__ out, T* __restrict__ norms = nullptr, int raw = 0) {
+                                int64_t pad, T* __restrict__ out, T* __restrict__ norms = nullptr, int raw = 0,
+                                const T* __restrict__ centre = nullptr, int64_t sC = 0) {
     const int s = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pad * QT) return;
@@ -356,7 +357,9 @@ __global__ void prescale_kernel(const T* __restrict__ X, int64_t sX, const T* __
     if (row < N && q < Q) {
         const T l = ls[(int64_t)s * sls + (ard ? q : 0)];
         const T m = raw ? (T)1 : ((KIND == MXF_K_LINEAR) ? t_sqrt<T>(l) : coord_scale<T, KIND>() / l);      // raw: the padded copy only
-        v = X[(int64_t)s * sX + row * Q + q] * m;
+        // centre (stationary kinds): one point subtracted from BOTH operands before scaling -- x / l rounds proportionally to |x| / l, so inputs
+        // at an offset of 1000 units cost 4e-5 on K in float32 where centred inputs cost 1e-7 (tests/probes/offset_gram.py)
+        v = (X[(int64_t)s * sX + row * Q + q] - (centre ? centre[(int64_t)s * sC + q] : (T)0)) * m;
     }
     out[(int64_t)s * pad * QT + i] = v;
     if (norms) {
@@ -437,6 +440,11 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
         if (KIND != MXF_K_BIAS && KIND != MXF_K_WHITE) {                                                              \
             const int64_t padr = (a.N + TR - 1) / TR * TR, padc = (a.N2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC) * (4 * 64 * VEC); \
             const int Sx = (a.sX == 0 && a.sls == 0) ? 1 : S, Sz = (a.sX2 == 0 && a.sls == 0) ? 1 : S;                \
+            /* the common centre of both operands: the first row of X, or of X2 when X is sampled and X2 shared (its pre-scaled copy is then \
+               shared by the samples and must not depend on one of them) */                                           \
+            const bool cen_x2_ = !a.square && a.sX != 0 && a.sX2 == 0 && a.X2 != nullptr;                             \
+            const T* cen_ = (KIND == MXF_K_LINEAR) ? (const T*)nullptr : (cen_x2_ ? a.X2 : a.X);                      \
+            const int64_t scen_ = cen_x2_ ? 0 : a.sX;                                                                 \
             const int64_t padx = a.square ? (padr > padc ? padr : padc) : padr;                                       \
             const size_t ncoord = ((size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc)) * QT;                     \
             const size_t need = (ncoord + (xf ? (size_t)Sx * padx + (a.square ? 0 : (size_t)Sz * padc) : 0)) * sizeof(T); \
@@ -444,14 +452,14 @@ int launch_kind(mxf_ctx* h, GramArgs<T> a, int S, int mode, hipStream_t st) {
             if (!buf) MXF_FAIL(h, -4, "mxf_gram: cannot allocate %zu bytes for the pre-scaled coordinates", need);    \
             xnorm = xf ? buf + ncoord : nullptr; sxn = (Sx == 1) ? 0 : padx;                                          \
             hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padx * QT + 255) / 256), Sx), dim3(256), 0, st, a.X, a.sX, \
-                               a.ls, a.sls, a.ard, a.N, a.Q, padx, buf, xnorm);                                       \
+                               a.ls, a.sls, a.ard, a.N, a.Q, padx, buf, xnorm, 0, cen_, scen_);                       \
             a.Xs = buf; a.sXs = (Sx == 1) ? 0 : padx * QT;                                                            \
             if (a.square) { a.Zs = buf; a.sZs = a.sXs; znorm = xnorm; szn = sxn; }                                    \
             else {                                                                                                    \
                 T* bz = buf + (size_t)Sx * padx * QT;                                                                 \
                 znorm = xf ? xnorm + (size_t)Sx * padx : nullptr; szn = (Sz == 1) ? 0 : padc;                         \
                 hipLaunchKernelGGL((prescale_kernel<T, QT, KIND>), dim3((unsigned)((padc * QT + 255) / 256), Sz), dim3(256), 0, st, a.X2, \
-                                   a.sX2, a.ls, a.sls, a.ard, a.N2, a.Q, padc, bz, znorm);                            \
+                                   a.sX2, a.ls, a.sls, a.ard, a.N2, a.Q, padc, bz, znorm, 0, cen_, scen_);            \
                 a.Zs = bz; a.sZs = (Sz == 1) ? 0 : padc * QT;                                                         \
             }                                                                                                         \
         }                                                                                                             \

@@ -85,9 +85,11 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
     const T variance = a.var[(int64_t)s * a.svar];
     const T* __restrict__ dK = a.dK + (int64_t)s * a.sdK;
 
-    T il[QT];
+    T il[QT], cen[QT];
+    // stationary kinds: both operands are centred on the first row of X before they are scaled -- distances do not change, but x / l carries
+    // a rounding error proportional to |x| / l (inputs at an offset of 1000 units: 4e-5 on K and its gradients in float32 instead of 1e-7)
 #pragma unroll
-    for (int q = 0; q < QT; ++q) il[q] = (q < Q) ? (T)1 / ls[a.ard ? q : 0] : (T)0;
+    for (int q = 0; q < QT; ++q) { il[q] = (q < Q) ? (T)1 / ls[a.ard ? q : 0] : (T)0; cen[q] = (KIND != MXF_K_LINEAR && q < Q) ? X[q] : (T)0; }
     for (int64_t i = tid; i < (rend - r0) * QA; i += 256) racc[i] = (T)0;
 
     T gl[QT];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
         const bool cvalid = col < a.N2;
         T z[QT], gz[QT];
 #pragma unroll
-        for (int q = 0; q < QT; ++q) { z[q] = (cvalid && q < Q) ? X2[col * Q + q] * il[q] : (T)0; gz[q] = 0; }
+        for (int q = 0; q < QT; ++q) { z[q] = (cvalid && q < Q) ? (X2[col * Q + q] - cen[q]) * il[q] : (T)0; gz[q] = 0; }
         T e[PMAX];
         double e2 = 0;
         T qn = 0;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
             for (int i = tid; i < TRB * QT; i += 256) {
                 const int r = i / QT, q = i % QT;
                 const int64_t row = rt + r;
-                xs[i] = (row < rend && q < Q) ? X[row * Q + q] / ls[a.ard ? q : 0] : (T)0;
+                xs[i] = (row < rend && q < Q) ? (X[row * Q + q] - (KIND != MXF_K_LINEAR ? X[q] : (T)0)) / ls[a.ard ? q : 0] : (T)0;
             }
             if (FUSED) {
                 for (int i = tid; i < TRB * PMAX; i += 256) {

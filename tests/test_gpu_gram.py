@@ -163,3 +163,38 @@ def test_combination_kernel_classes_take_the_fused_pair_path_and_differentiate(c
     (Kr * O.T(w)).sum().backward()
     for n in names:
         assert np.allclose(dv[n].grad.cpu().numpy(), ov[n].grad.numpy(), rtol=1e-8, atol=1e-10), n
+
+
+@pytest.mark.parametrize('kind', ['rbf', 'matern12', 'matern52'])
+@pytest.mark.parametrize('sampled', ['none', 'X', 'X2'])
+def test_float32_gram_does_not_depend_on_where_the_inputs_sit(kind, sampled):
+    """Inputs at an offset of 10 000 units (raw time stamps, sensor readings): x / l rounds proportionally to |x| / l, which cost 3e-4 on K
+    and on its reverse mode in float32 (1e-7 for centred inputs).  Both operands are centred on a common point before they are scaled
+    (first row of X; of X2 when X is sampled and X2 shared): float32 K, K(X, X2) and the reverse mode against the oracle at 1e-6."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(3)
+    S, N, N2, Q, off = 3, 70, 45, 5, 1.0e4
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = r32(off + rng.uniform(-2, 2, (S if sampled == 'X' else 1, N, Q)))
+    X2 = r32(off + rng.uniform(-2, 2, (S if sampled == 'X2' else 1, N2, Q)))
+    ls, var = r32(rng.rand(1, Q) + 0.8), r32([[1.2]])
+    G = rng.randn(max(X.shape[0], X2.shape[0]), N, N2)
+    ok = {'rbf': O.RBF, 'matern12': O.Matern12, 'matern52': O.Matern52}[kind](Q, ARD=True)
+    # the oracle on the CENTRED inputs (the same distances, exactly: X - off is exact in float64): the reference's own expansion-form distances
+    # lose 6e-8 of r2 at this offset even in float64 (Matern12's diagonal comes out 1.1997 instead of 1.2)
+    lv = {n: O.T(v).clone().requires_grad_(True) for n, v in (('X', X - off), ('X2', X2 - off), ('ls', ls), ('var', var))}
+    kp = {ok.name + '_lengthscale': lv['ls'], ok.name + '_variance': lv['var']}
+    K = ok.K(lv['X'], lv['X2'], **kp)
+    gref = torch.autograd.grad((K * O.T(G)).sum(), [lv['X'], lv['X2'], lv['ls']])
+    d = lambda a: torch.as_tensor(a, dtype=torch.float32).cuda()
+    nrm = lambda a, b: float(np.linalg.norm(a.ravel() - b.ravel()) / np.linalg.norm(b.ravel()))
+    Kd = ops.gram(kind, d(X), d(X2), d(ls), d(var), True)
+    assert nrm(Kd.double().cpu().numpy(), K.detach().numpy()) <= 1e-6
+    Ks = ops.gram(kind, d(X), None, d(ls), d(var), True)
+    assert nrm(Ks.double().cpu().numpy(), ok.K(O.T(X - off), None, **{k: v.detach() for k, v in kp.items()}).numpy()) <= 1e-6
+    g = ops.gram_bwd(kind, d(X), d(X2), d(ls), d(var), True, d(G))
+    for got, ref, name in zip((g[0], g[1], g[2]), gref, ('dX', 'dX2', 'dls')):
+        got = got.double().cpu().numpy()
+        if got.shape != tuple(ref.shape):
+            got = got.sum(0, keepdims=True)
+        assert nrm(got, ref.numpy()) <= 2e-5, (name, nrm(got, ref.numpy()))
