@@ -26,9 +26,10 @@ for it in range(n):
     ard = bool(rng.randint(2))
     sampled = S > 1 and bool(rng.randint(2))
     ell = float(rng.choice([0.5, 1.0, 2.0])) * np.sqrt(Q)
-    X = rng.uniform(-2., 2., (S, B, Q))
-    Y = np.sin(X[0] @ rng.standard_normal((Q, P))) + 0.05 * rng.standard_normal((B, P))
-    Z = rng.uniform(-2., 2., (S if sampled else 1, M, Q))
+    off = float(rng.choice([0., 0., 50., 3000.]))            # inputs at an offset (raw time stamps ...): nothing may depend on it
+    X = off + rng.uniform(-2., 2., (S, B, Q))
+    Y = np.sin((X[0] - off) @ rng.standard_normal((Q, P))) + 0.05 * rng.standard_normal((B, P))
+    Z = off + rng.uniform(-2., 2., (S if sampled else 1, M, Q))
     qm, qW, qd = 0.3 * rng.standard_normal((M, P)), 0.3 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
     ls = rng.uniform(0.8, 1.2, (S if sampled else 1, Q if ard else 1)) * ell
     var, noise = rng.uniform(0.9, 1.3, (S if sampled else 1, 1)), np.array([[0.05]])
@@ -52,11 +53,11 @@ for it in range(n):
     ev = float(np.abs(v32 - v64).max() / np.abs(v64).max())
     eg = max(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)) for a, b in zip(g32, g64))
     cond = res[torch.float32][3]
-    tag = '%s S%d B%d M%d Q%d P%d ard%d smp%d tier%s cond %.1e' % (kind, S, B, M, Q, P, ard, sampled, tier, cond)
+    tag = '%s S%d B%d M%d Q%d P%d ard%d smp%d tier%s cond %.1e off %g' % (kind, S, B, M, Q, P, ard, sampled, tier, cond, off)
     eo = None
     if B * M <= 300000:
         ok = KINDS[kind][1](Q, ARD=ard)
-        lo = {k: O.T(v) for k, v in vals}
+        lo = {k: O.T(v - off if k in ('X', 'Z') else v) for k, v in vals}
         ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
                              {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6).numpy()
         eo = float(np.abs(v64 - ref).max() / np.abs(ref).max())
