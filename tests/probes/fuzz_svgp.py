@@ -33,6 +33,9 @@ for it in range(n):
     qm, qW, qd = 0.3 * rng.standard_normal((M, P)), 0.3 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
     ls = rng.uniform(0.8, 1.2, (S if sampled else 1, Q if ard else 1)) * ell
     var, noise = rng.uniform(0.9, 1.3, (S if sampled else 1, 1)), np.array([[0.05]])
+    het = (not sampled) and rng.randint(4) == 0          # per-row (P = 1) or per-element noise
+    if het:
+        noise = rng.uniform(0.02, 0.2, (1, B, 1 if (P == 1 or rng.randint(2)) else P))
     r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)      # every run sees the SAME (float32-representable) inputs: arithmetic, not input rounding
     Y = r32(Y)
     vals = tuple((k, r32(v)) for k, v in (('X', X), ('Z', Z), ('noise', noise), ('qm', qm[None]), ('qW', qW[None]), ('qd', qd[None]), ('ls', ls), ('var', var)))
@@ -53,7 +56,7 @@ for it in range(n):
     ev = float(np.abs(v32 - v64).max() / np.abs(v64).max())
     eg = max(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)) for a, b in zip(g32, g64))
     cond = res[torch.float32][3]
-    tag = '%s S%d B%d M%d Q%d P%d ard%d smp%d tier%s cond %.1e off %g' % (kind, S, B, M, Q, P, ard, sampled, tier, cond, off)
+    tag = '%s S%d B%d M%d Q%d P%d ard%d smp%d tier%s cond %.1e off %g het%d' % (kind, S, B, M, Q, P, ard, sampled, tier, cond, off, het)
     eo = None
     if B * M <= 300000:
         ok = KINDS[kind][1](Q, ARD=ard)
