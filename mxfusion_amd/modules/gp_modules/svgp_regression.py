@@ -115,15 +115,17 @@ class SVGPRegressionLogPdf(VariationalInference):
 
     @staticmethod
     def _far_coordinates(X, Z, ls, n, sign):
-        """n points on the first coordinate axis, beyond the data and the inducing inputs and 128 length-scales apart: every stationary
+        """n points along the first coordinate axis, beyond the data and the inducing inputs and 128 length-scales apart: every stationary
         covariance between them and anything real (and among themselves) is < exp(-128): exactly 0 in float32, 1e-56 in the float64 core.
         Their SCALED coordinates stay below 3e4 + range / lengthscale, inside the f16 range the reverse pass splits coordinates into
         (1e6-style offsets overflow it: inf * 0 there).  Built with device ops, no synchronisation; not differentiated."""
         with torch.no_grad():
-            base = X[..., 0].abs().amax() + Z[..., 0].abs().amax()
+            # (measured from the EDGE of the data on that side, not from the origin: inputs at an offset -- raw time stamps -- must not push the
+            #  padded points out of the f16 range once the reverse pass has centred its operands)
+            edge = torch.maximum(X[..., 0].amax(), Z[..., 0].amax()) if sign > 0 else torch.minimum(X[..., 0].amin(), Z[..., 0].amin())
             step = 128.0 * ls.reshape(ls.shape[0], -1)[:, 0].amax()
-            far = torch.zeros(n, X.shape[-1], dtype=X.dtype, device=X.device)
-            far[:, 0] = sign * (base + step * (1.0 + torch.arange(n, dtype=X.dtype, device=X.device)))
+            far = X[..., :1, :].reshape(-1, X.shape[-1])[:1].expand(n, X.shape[-1]).clone()          # the other coordinates: those of a real point
+            far[:, 0] = edge + sign * step * (1.0 + torch.arange(n, dtype=X.dtype, device=X.device))
         return far
 
     def _pad_inducing(self, X, Y, Z, noise_var, mu, S_W, S_diag, ls, var):
@@ -171,7 +173,24 @@ class SVGPRegressionLogPdf(VariationalInference):
 
     def _compute_materialised(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         """Combination kernels (add_kernel.py:44-68, multiply_kernel.py:44-67): Kuu / Kuf / Kdiag come from kern.K (each sub-kernel one
-        mxf_gram pass with its own reverse mode) and the bound from mxf_svgp_logpdf_mat, one call per sample."""
+        mxf_gram pass with its own reverse mode) and the bound from mxf_svgp_logpdf_mat, one call per sample.
+        float32 above the explicit form's condition limit (this path has no whitened form): the WHOLE evaluation runs in float64, Gram
+        matrices included -- a float32 Kuu / Kuf widened afterwards still carries its 1e-7 rounding, which cond(Kuu) amplifies (r04 sweep:
+        3e-5 ... 3e-4 on the bound at cond 1e3 ... 1e6 with the widened-afterwards form)."""
+        from ._fused import Float32Guard
+        if X.is_cuda and X.dtype == torch.float32 and Float32Guard.enabled and Float32Guard.force is None:
+            g = self._f32_guard()
+            wide = lambda: self._compute_materialised(F, *[t.double() for t in (X, Y, Z, noise_var, mu, S_W, S_diag)], kern,
+                                                      {k: v.double() for k, v in kern_params.items()}).float()
+            g.poll(X.device)
+            if g.tier != Float32Guard.EXPLICIT:
+                return wide()
+            first = not g._checked_first
+            out = self._materialised_core(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
+            return wide() if (first and g.tier != Float32Guard.EXPLICIT) else out        # (an owner's first call checks synchronously)
+        return self._materialised_core(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
+
+    def _materialised_core(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
         Kuu = kern.K(F, Z, **kern_params)
         Kuf = kern.K(F, Z, X, **kern_params)
         Kdiag = kern.Kdiag(F, X, **kern_params)

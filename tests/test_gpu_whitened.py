@@ -327,3 +327,34 @@ def test_float32_training_call_does_not_depend_on_where_the_inputs_sit(offset):
     assert abs(got['logL'][0] - ref[0]) <= 1e-5 * abs(ref[0])
     for k, g in gref.items():
         assert _nrm(got[k], g) <= 2e-4, (k, _nrm(got[k], g))
+
+
+def test_padding_with_inputs_at_a_large_offset():
+    """Both paddings with inputs at an offset of 1e5 units (M = 200 -> 256, B = 1000 -> 1024): the padded points are placed from the edge of
+    the data, not from the origin, so that they stay inside the f16 range of the (centred) reverse pass -- bound and gradients against the
+    oracle on the centred inputs."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    rng = np.random.default_rng(78)
+    B, M, Q, off = 1000, 200, 4, 1.0e5
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = r32(off + rng.uniform(-2., 2., (B, Q)))
+    Y = r32(np.sin((X - off).sum(1))[:, None] + 0.05 * rng.standard_normal((B, 1)))
+    Z = r32(off + rng.uniform(-2., 2., (M, Q)))
+    qm, qW, qd = r32(0.3 * rng.standard_normal((M, 1))), r32(0.3 * rng.standard_normal((M, M)) / np.sqrt(M)), r32(rng.uniform(0.05, 0.5, M))
+    ls, var, noise = r32(np.full(Q, 1.2)), r32([1.1]), r32([0.05])
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()[None]
+    kern = RBF(input_dim=Q, ARD=True, dtype='float32')
+    fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
+    fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, 1.0, Float32Guard('padding-offset')
+    Xd, Zd = t(X).requires_grad_(True), t(Z).requires_grad_(True)
+    got = fn._compute_columns(None, Xd, t(Y), Zd, t(noise), t(qm), t(qW), t(qd), kern, {kern.name + '_lengthscale': t(ls), kern.name + '_variance': t(var)})
+    gX, gZ = torch.autograd.grad(got.sum(), [Xd, Zd])
+    Xo, Zo = O.T(X - off).clone().requires_grad_(True), O.T(Z - off).clone().requires_grad_(True)
+    ref = O.svgp_log_pdf(O.RBF(Q, ARD=True), Xo[None], O.T(Y)[None], Zo[None], O.T(noise)[None], O.T(qm)[None], O.T(qW)[None], O.T(qd)[None],
+                         {'rbf_lengthscale': O.T(ls)[None], 'rbf_variance': O.T(var)[None]}, jitter=1e-6)[0]
+    rX, rZ = torch.autograd.grad(ref, [Xo, Zo])
+    assert torch.isfinite(gX).all() and torch.isfinite(gZ).all()
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+    assert _nrm(gX[0].double().cpu().numpy(), rX.numpy()) <= 2e-3 and _nrm(gZ[0].double().cpu().numpy(), rZ.numpy()) <= 2e-3
