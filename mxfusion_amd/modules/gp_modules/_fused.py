@@ -112,6 +112,7 @@ class Float32Guard(object):
         self.cond_last = 0.0
         self._checked_first = False
         self.switches = 0
+        self._range_wide, self._range_by_module, self.range_radius = False, False, 0.0
         cls._instances.add(self)
 
     # ---- class-level views (reports, tests, backwards compatibility) ----------------------------------------------------------------
@@ -196,6 +197,7 @@ class Float32Guard(object):
 
     def range_too_wide(self, X, Z, ls):
         if not (Float32Guard.enabled and Float32Guard.force is None and X.is_cuda):
+            self._range_wide = False
             return False
         n = getattr(self, '_range_calls', 0)
         self._range_calls = n + 1

@@ -301,3 +301,42 @@ def test_inputs_spanning_many_length_scales_run_in_float64():
             assert abs(float(logL[0]) - float(ref[0])) <= 1e-5 * abs(float(ref[0]))
             nrm = lambda a, b: float(np.linalg.norm(a.ravel() - b.ravel()) / np.linalg.norm(b.ravel()))
             assert nrm(t['X'].grad.double().cpu().numpy(), gX.numpy()) <= 1e-4 and nrm(t['Z'].grad.double().cpu().numpy(), gZ.numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize('mode', ['disabled', 'forced-whitened', 'forced-explicit'])
+def test_module_call_with_the_guard_disabled_or_forced(mode):
+    """bench.py --no-f32-guard / --f32-form: the module's training call with the guard switched off or pinned to one form (the input-range check
+    is skipped there as well) -- runs, and agrees with the guarded call on a benign problem."""
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard as G
+    rng = np.random.default_rng(3)
+    B, M, Q = 512, 128, 4
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()[None]
+    X, Z = rng.uniform(-2, 2, (B, Q)), rng.uniform(-2, 2, (M, Q))
+    Y = np.sin(X.sum(1))[:, None]
+    args = lambda: (t(X).requires_grad_(True), t(Y), t(Z), t([0.05]), t(0.1 * rng.standard_normal((M, 1))), t(np.zeros((M, M))), t(np.ones(M)))
+    kern = RBF(input_dim=Q, ARD=True, dtype='float32')
+    params = {kern.name + '_lengthscale': t(np.full(Q, 0.5)), kern.name + '_variance': t([1.0])}          # (cond ~ 10: every form holds the bar)
+
+    def call():
+        fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
+        fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, 1.0, G('mode-' + mode)
+        a = args()
+        out = fn._compute_columns(None, *a, kern, params)
+        out.sum().backward()
+        return float(out[0]), a[0].grad.clone()
+    rng = np.random.default_rng(3)
+    ref, gref = call()
+    rng = np.random.default_rng(3)
+    old = (G.enabled, G.force)
+    try:
+        if mode == 'disabled':
+            G.enabled = False
+        else:
+            G.force = G.WHITENED if mode == 'forced-whitened' else G.EXPLICIT
+        got, g = call()
+    finally:
+        G.enabled, G.force = old
+    assert abs(got - ref) <= 1e-5 * abs(ref)
+    assert float((g - gref).norm() / gref.norm()) <= 1e-3
