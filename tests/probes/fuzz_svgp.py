@@ -39,11 +39,12 @@ for it in range(n):
     r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)      # every run sees the SAME (float32-representable) inputs: arithmetic, not input rounding
     Y = r32(Y)
     vals = tuple((k, r32(v)) for k, v in (('X', X), ('Z', Z), ('noise', noise), ('qm', qm[None]), ('qW', qW[None]), ('qd', qd[None]), ('ls', ls), ('var', var)))
+    scal = float(rng.choice([1.0, 1.0, 8.0]))               # log_pdf_scaling (minibatch steps)
     res = {}
     for dt in (torch.float32, torch.float64):
         kern = KINDS[kind][0](input_dim=Q, ARD=ard, dtype='float32' if dt == torch.float32 else 'float64')
         fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
-        fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, 1.0, Float32Guard('fuzz%d' % it)
+        fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, scal, Float32Guard('fuzz%d' % it)
         lv = {k: torch.as_tensor(v, dtype=dt).cuda().requires_grad_(True) for k, v in vals}
         out = fn._compute_columns(None, lv['X'], torch.as_tensor(Y, dtype=dt).cuda()[None], lv['Z'], lv['noise'], lv['qm'], lv['qW'], lv['qd'], kern,
                                   {kern.name + '_lengthscale': lv['ls'], kern.name + '_variance': lv['var']})
@@ -62,7 +63,7 @@ for it in range(n):
         ok = KINDS[kind][1](Q, ARD=ard)
         lo = {k: O.T(v - off if k in ('X', 'Z') else v) for k, v in vals}
         ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
-                             {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6).numpy()
+                             {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6, log_pdf_scaling=scal).numpy()
         eo = float(np.abs(v64 - ref).max() / np.abs(ref).max())
     bad = (not np.isfinite(ev)) or ev > 2e-5 or eg > 5e-3 or (eo is not None and eo > max(1e-9, 1e-14 * cond)) or not all(np.isfinite(x).all() for x in g32)
     print('%s  f32-f64 value %.1e grad %.1e  f64-oracle %s %s' % (tag, ev, eg, ('%.1e' % eo) if eo is not None else '-', 'BAD' if bad else ''), flush=True)
