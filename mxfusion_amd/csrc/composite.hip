@@ -1075,7 +1075,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // [T; U] = [H0; w^T] Kuf_all
     // (training step on the split path whose reverse pass runs on the matrix pipe: T is written in 16-column blocks, so that each 16 x 16
     //  tile that pass reads is one contiguous KB instead of 16 pieces of 64 bytes, 4 SB bytes apart)
-    const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_is_mfma(kind, dtype, SB, B, Q, P, Text)) ? 1 : 0;
+    const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_reads_blocked(kind, dtype, SB, B, Q, P, Text)) ? 1 : 0;
     if (use_split) {
         unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
         if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st, false); if (rc) return rc; }      // (word cleared by svgp_init_kernel)

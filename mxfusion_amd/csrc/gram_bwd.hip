@@ -34,6 +34,7 @@ struct GramBwdArgs {
     int64_t sY, B;
     double a1;
     int P, dY_shared;
+    int tblk;        // fused: T (= dK) in 16-column blocks, element (m, n) at ((n / 16) * N + m) * 16 + n % 16 (the split GEMM's blocked output)
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
               T pre[UNR];
 #pragma unroll
               for (int u = 0; u < UNR; ++u)
-                  pre[u] = (cvalid && r0_ + u < rmax) ? dK[(rt + r0_ + u) * a.lddk + col] : (T)0;
+                  pre[u] = (cvalid && r0_ + u < rmax) ? (a.tblk ? dK[((col >> 4) * a.N + (rt + r0_ + u)) * 16 + (col & 15)] : dK[(rt + r0_ + u) * a.lddk + col]) : (T)0;
 #pragma unroll
               for (int u = 0; u < UNR; ++u) {
                 const int r = r0_ + u;
@@ -1101,7 +1102,9 @@ int fused_typed(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, i
                                (const float*)Y, sY, (const float*)w, (const float*)noise, a1, (float*)dZ, (float*)dXall, (float*)dls, (float*)dvar,
                                (float*)dY, dY_shared, (float*)R, scal, st, t_blocked, h0max, tmax);
     }
-    if (t_blocked) MXF_FAIL(h, -2, "svgp fused reverse pass: only the matrix-pipe pass reads T in blocks");
+    if (t_blocked && !mxf_svgp_bwd_reads_blocked(kind, sizeof(T) == 4 ? MXF_F32 : MXF_F64, SB, B, Q, P, Text))
+        MXF_FAIL(h, -2, "svgp fused reverse pass: this shape reads T row-major");
+    a.tblk = t_blocked;
     if (P == 1) return launch_kind<T, 1>(h, kind, a, 1, st);
     return launch_kind<T, PMAX_ALL>(h, kind, a, 1, st);
 }
@@ -1127,6 +1130,12 @@ bool mxf_svgp_bwd_is_mfma(int kind, int dtype, int64_t SB, int64_t B, int Q, int
     // difference-form pass (tests/probes/bwd_form_accuracy.py).  MXF_BWD_MFMA=2 (probe build) puts the Matern kinds back on it.
     if (kind != MXF_K_RBF && mf_env != 2) return false;
     return mf_env && dtype == MXF_F32 && P == 1 && Q <= 8 && SB % 4 == 0 && SB >= 16 && B % 16 == 0 && ((uintptr_t)Text % 16) == 0;
+}
+
+// may T be handed over in 16-column blocks?  The matrix-pipe pass (RBF) requires it; the difference-form pass (Matern kinds, P > 1, Q > 8) reads
+// either layout for Q <= 16 -- so that those calls keep the wide blocked-output T product (11.3 instead of 13.4 ms at the bench shape)
+bool mxf_svgp_bwd_reads_blocked(int kind, int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text) {
+    return mxf_svgp_bwd_is_mfma(kind, dtype, SB, B, Q, P, Text) || (dtype == MXF_F32 && Q <= 16 && P <= PMAX_ALL && SB % 16 == 0);
 }
 
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,

@@ -27,6 +27,7 @@ int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int
 // true if mxf_svgp_bwd_fused_internal takes the matrix-pipe pass for these arguments; that pass reads T in 16-column blocks
 // (element (m, n) at ((n / 16) * M + m) * 16 + n % 16: mxf_gemm_split_internal's c_blocked output) when called with t_blocked = 1
 bool mxf_svgp_bwd_is_mfma(int kind, int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text);
+bool mxf_svgp_bwd_reads_blocked(int kind, int dtype, int64_t SB, int64_t B, int Q, int P, const void* Text);
 // SVGP-fused reverse pass over Text = [H0; w^T] Kuf_all (never materialises dKuf); see gram_bwd.hip
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
