@@ -53,12 +53,18 @@ class GPRegressionLogPdf(VariationalInference):
             logL, L, LinvY, info = GPLogPdfFn.apply(kind, ard, float(self.jitter), X, Y, noise_var, ls, var)
             Xs = X
         else:   # combination kernels: K through the kernel's own (HIP, autograd-capable) K(), then Cholesky
+            narrow = X.is_cuda and X.dtype == torch.float32        # (r04: float32 evaluated in float64 inside, as the fused call: _fused.GPLogPdfFn)
+            if narrow:
+                X, Y, noise_var = X.double(), Y.double(), noise_var.double()
+                kern_params = {k: v.double() for k, v in kern_params.items()}
             X, Y, noise_var, kern_params = arrays_as_samples(F, [X, Y, noise_var, kern_params])
             N = X.shape[-2]
             eye = torch.eye(N, dtype=X.dtype, device=X.device).unsqueeze(0)
             K = kern.K(F, X, **kern_params) + eye * (noise_var.unsqueeze(-2) + self.jitter)
             logL, L, LinvY, info = _chol_logpdf_generic(F, K, Y)
             Xs = X
+            if narrow:
+                logL, L, LinvY, Xs = logL.float(), L.float(), LinvY.float(), X.float()
         self._last_info = info
         with torch.no_grad():      # gp_regression.py:72-75: only sample 0 is persisted
             self.set_parameter(variables, self.posterior.X, Xs[0].detach())

@@ -71,6 +71,12 @@ class SparseGPRegressionLogPdf(VariationalInference):
         import math
         if self.model.F.factor.has_mean:
             Y = Y - variables[self.model.mean]
+        # r04: float32 on the GPU is evaluated in float64 inside (inputs widened, bound and the persisted posterior narrowed): two float32
+        # Cholesky factorisations in a row (Kuu, then I + ...) lose cond(Kuu) 2^-24 of the bound, and this generic path is not the fast one anyway
+        narrow = X.is_cuda and X.dtype == torch.float32
+        if narrow:
+            X, Y, Z, noise_var = [t.double() for t in (X, Y, Z, noise_var)]
+            kern_params = {k: v.double() for k, v in kern_params.items()}
         D, M = Y.shape[-1], Z.shape[-2]
         eye = torch.eye(M, dtype=Z.dtype, device=Z.device).unsqueeze(0)
         nv = noise_var.unsqueeze(-2)                                   # (S, 1, 1)
@@ -94,10 +100,11 @@ class SparseGPRegressionLogPdf(VariationalInference):
         with torch.no_grad():      # :99-106 persist sample 0 only
             wv = ops.trsm_(L[:1].contiguous(), ops.trsm_(LA[:1].contiguous(), LAInvLinvKufY[:1].detach().contiguous().clone(), transpose=True),
                            transpose=True) / nv[:1]
-            self.set_parameter(variables, self.graphs[1].wv, wv[0])
-            self.set_parameter(variables, self.graphs[1].L, L[0].detach())
-            self.set_parameter(variables, self.graphs[1].LA, LA[0].detach())
-        return logL
+            nf = (lambda t: t.float()) if narrow else (lambda t: t)
+            self.set_parameter(variables, self.graphs[1].wv, nf(wv[0]))
+            self.set_parameter(variables, self.graphs[1].L, nf(L[0].detach()))
+            self.set_parameter(variables, self.graphs[1].LA, nf(LA[0].detach()))
+        return logL.float() if narrow else logL
 
 
 class SparseGPRegressionMeanVariancePrediction(SamplingAlgorithm):

@@ -648,3 +648,50 @@ def test_float32_exact_gp_holds_the_bar_at_small_noise():
     for n, g in zip(lv, gref):
         e = float(np.linalg.norm(t[n].grad.double().cpu().numpy().ravel() - g.numpy().ravel()) / np.linalg.norm(g.numpy().ravel()))
         assert e <= 1e-3, (n, e)
+
+
+@pytest.mark.parametrize('module', ['gp', 'sgp'])
+def test_float32_combination_kernel_modules_hold_the_bar_at_small_noise(module):
+    """GPRegression / SparseGPRegression with AddKernel(Matern52, RBF) in FLOAT32 through the API, noise 1e-4 on N = 600 points (GP:
+    cond(K + noise I) ~ 1e7): the generic paths factor in the model's dtype as the reference does -- 1e-3 on the log-pdf in float32 -- and
+    are evaluated in float64 inside since r04: 1e-5 against the oracle."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern52
+    from mxfusion_amd.modules.gp_modules import GPRegression, SparseGPRegression
+    from mxfusion_amd.inference import Inference, MAP
+    rng = np.random.RandomState(0)
+    N, Q, M = 600, 4, 40
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = r32(rng.uniform(-2, 2, (N, Q)))
+    Y = r32(np.sin(X.sum(-1, keepdims=True)) + 0.01 * rng.randn(N, 1))
+    Z = r32(rng.uniform(-2, 2, (M, Q)))
+    ls1, ls2, v1, v2, noise = r32([1.3]), r32([1.7]), r32([0.9]), r32([0.4]), r32([1e-4])
+    f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).cuda()
+    kern = Matern52(Q, variance=f(v1), lengthscale=f(ls1), dtype='float32') + RBF(Q, variance=f(v2), lengthscale=f(ls2), dtype='float32')
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=f(noise))
+    if module == 'gp':
+        m.Y = GPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, shape=(m.N, 1), dtype='float32')
+    else:
+        m.Z = Variable(shape=(M, Q), initial_value=f(Z))
+        m.Y = SparseGPRegression.define_variable(X=m.X, kernel=kern, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype='float32')
+        m.Y.factor.sgp_log_pdf.jitter = 1e-6
+    infr = Inference(MAP(model=m, observed=[m.X, m.Y]), dtype='float32')
+    loss, _ = infr.run(X=f(X), Y=f(Y))
+    ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
+    kp = {'add_matern52_lengthscale': O.T(ls1)[None], 'add_matern52_variance': O.T(v1)[None], 'add_rbf_lengthscale': O.T(ls2)[None], 'add_rbf_variance': O.T(v2)[None]}
+    # (the parameters pass through softplus / its inverse in float32: compare at the values the inference holds)
+    val = lambda v: infr.params[v].double().cpu().numpy()
+    sub = {k.name: k for k in kern.sub_kernels}
+    kp = {'add_matern52_lengthscale': O.T(val(sub['matern52'].lengthscale))[None], 'add_matern52_variance': O.T(val(sub['matern52'].variance))[None],
+          'add_rbf_lengthscale': O.T(val(sub['rbf'].lengthscale))[None], 'add_rbf_variance': O.T(val(sub['rbf'].variance))[None]}
+    nz = O.T(val(m.noise_var))[None]
+    if module == 'gp':
+        ref = O.gp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], nz, kp)
+    else:
+        ref = O.sgp_log_pdf(ok, O.T(X)[None], O.T(Y)[None], O.T(val(m.Z))[None], nz, kp, jitter=1e-6)
+    assert loss.dtype == torch.float32
+    assert abs(float(-loss) - float(ref[0])) <= 1e-5 * abs(float(ref[0])), (float(-loss), float(ref[0]))
