@@ -1,0 +1,78 @@
+"""A fixed-seed slice of the randomised sweep that found the float32 defects of r04 (tests/probes/fuzz_svgp.py): the SVGP module's training call
+over random kernel kinds, shapes (tile multiples and not: the padded paths), output columns, sampled hyper-parameters, input offsets, per-row
+noise and log_pdf_scaling -- float32 (whatever path and guard level the case takes) against float64 on IDENTICAL float32-representable
+inputs, float64 against the oracle.  Cases whose Kuu is ill-conditioned beyond what any arithmetic holds (cond > 1e5 here) are generated but
+only checked for finiteness."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _case(rng):
+    kind = ['rbf', 'matern12', 'matern32', 'matern52'][rng.randint(4)]
+    S = [1, 1, 2, 3][rng.randint(4)]
+    B = int(rng.choice([37, 256, 300, 1000, 1024, 2049]))
+    M = int(rng.choice([7, 64, 100, 128, 130, 200, 256]))
+    Q = int(rng.choice([3, 5, 8, 12, 16, 20]))
+    P = int(rng.choice([1, 1, 2, 3, 8]))
+    ard = bool(rng.randint(2))
+    sampled = S > 1 and bool(rng.randint(2))
+    off = float(rng.choice([0., 0., 50., 3000.]))
+    return kind, S, B, M, Q, P, ard, sampled, off
+
+
+@pytest.mark.parametrize('seed', list(range(24)))
+def test_svgp_module_call_random_case(seed):
+    from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern12, Matern32, Matern52
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    KINDS = {'rbf': (RBF, O.RBF), 'matern12': (Matern12, O.Matern12), 'matern32': (Matern32, O.Matern32), 'matern52': (Matern52, O.Matern52)}
+    rng = np.random.RandomState(1000 + seed)
+    kind, S, B, M, Q, P, ard, sampled, off = _case(rng)
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    ell = float(rng.choice([0.5, 1.0, 2.0])) * np.sqrt(Q)
+    X = off + rng.uniform(-2., 2., (S, B, Q))
+    Y = r32(np.sin((X[0] - off) @ rng.standard_normal((Q, P))) + 0.05 * rng.standard_normal((B, P)))
+    Z = off + rng.uniform(-2., 2., (S if sampled else 1, M, Q))
+    qm, qW, qd = 0.3 * rng.standard_normal((M, P)), 0.3 * rng.standard_normal((M, M)) / np.sqrt(M), rng.uniform(0.05, 0.5, M)
+    ls = rng.uniform(0.8, 1.2, (S if sampled else 1, Q if ard else 1)) * ell
+    var, noise = rng.uniform(0.9, 1.3, (S if sampled else 1, 1)), np.array([[0.05]])
+    if (not sampled) and rng.randint(4) == 0:
+        noise = rng.uniform(0.02, 0.2, (1, B, 1 if (P == 1 or rng.randint(2)) else P))
+    scal = float(rng.choice([1.0, 1.0, 8.0]))
+    vals = tuple((k, r32(v)) for k, v in (('X', X), ('Z', Z), ('noise', noise), ('qm', qm[None]), ('qW', qW[None]), ('qd', qd[None]), ('ls', ls), ('var', var)))
+    res = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for dt in (torch.float32, torch.float64):
+            kern = KINDS[kind][0](input_dim=Q, ARD=ard, dtype='float32' if dt == torch.float32 else 'float64')
+            fn = SVGPRegressionLogPdf.__new__(SVGPRegressionLogPdf)
+            fn.jitter, fn.log_pdf_scaling, fn._guard = 1e-6, scal, Float32Guard('sweep%d' % seed)
+            lv = {k: torch.as_tensor(v, dtype=dt).cuda().requires_grad_(True) for k, v in vals}
+            out = fn._compute_columns(None, lv['X'], torch.as_tensor(Y, dtype=dt).cuda()[None], lv['Z'], lv['noise'], lv['qm'], lv['qW'], lv['qd'], kern,
+                                      {kern.name + '_lengthscale': lv['ls'], kern.name + '_variance': lv['var']})
+            g = torch.autograd.grad(out.mean(), list(lv.values()))
+            torch.cuda.synchronize()
+            fn._guard.poll(torch.device('cuda', torch.cuda.current_device()))
+            res[dt] = (out.detach().double().cpu().numpy(), [x.double().cpu().numpy() for x in g], fn._guard.cond_max)
+    v32, g32, cond = res[torch.float32]
+    v64, g64, _ = res[torch.float64]
+    assert np.isfinite(v32).all() and all(np.isfinite(x).all() for x in g32), (kind, S, B, M, Q, P)
+    if cond > 1e5:
+        return
+    nrm = lambda a, b: float(np.linalg.norm(a.ravel() - b.ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+    tag = (kind, S, B, M, Q, P, ard, sampled, off, scal, '%.1e' % cond)
+    assert np.abs(v32 - v64).max() <= 4e-5 * np.abs(v64).max(), tag
+    assert max(nrm(a, b) for a, b in zip(g32, g64)) <= 5e-3, tag
+    if B * M <= 300000:
+        ok = KINDS[kind][1](Q, ARD=ard)
+        lo = {k: O.T(v - off if k in ('X', 'Z') else v) for k, v in vals}
+        ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
+                             {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6, log_pdf_scaling=scal).numpy()
+        assert np.abs(v64 - ref).max() <= max(1e-9, 1e-13 * cond) * np.abs(ref).max(), tag
