@@ -730,8 +730,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // r04: per-row noise (B, 1) with one output column on the float32 split path runs the STREAMING form (het_* kernels above); every other
     // heteroscedastic shape keeps the generic (materialised dKuf) path
     static const int het_stream_env = MXF_KNOB("MXF_SVGP_HET_STREAM", 1);
+    // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
+    static const int split_env = MXF_KNOB("MXF_SVGP_SPLIT", 1);
     const int64_t SBh = ((sX == 0) ? (int64_t)1 : (int64_t)S) * B;
-    const bool het_stream = het_stream_env && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
+    const bool het_stream = het_stream_env && split_env && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
                             (B % 16 == 0) && (M % 16 == 0) && M >= 128 && h->svgp_form == MXF_SVGP_EXPLICIT && mxf_svgp_bwd_is_mfma(kind, dtype, SBh, B, Q, P, X);
     const bool het = (nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16) && !het_stream;
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
@@ -750,8 +752,6 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     acc(MP, 8); acc(16, 8); acc(2 * (size_t)S, 8); acc(8, sizeof(int));
     acc((size_t)(M + P) * M, sizeof(T)); acc(MP, sizeof(T));
     acc((size_t)(M + P) * SB, sizeof(T)); acc((size_t)SB, sizeof(T));
-    // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
-    static const int split_env = MXF_KNOB("MXF_SVGP_SPLIT", 1);
     const bool use_split = split_env && want_grad && sizeof(T) == 4 && !het && (SB % 16 == 0) && (M % 16 == 0) && M >= 128 && Q <= 16;
     // operand format of the split GEMMs: two scaled f16 terms / three products (default) or three bf16 terms / six products
     static const int split_mode = MXF_KNOB("MXF_SPLIT_BF16X3", 0) ? MXF_SPLIT_BF16X3 : MXF_SPLIT_F16X2;
@@ -763,10 +763,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const bool whiten = sizeof(T) == 4 && want_grad && h->svgp_form == MXF_SVGP_WHITENED;
     if (whiten && !(use_split && split_mode == MXF_SPLIT_F16X2 && (M % 128) == 0 && (SB % 256) == 0))
         MXF_FAIL(h, -3, "mxf_svgp_logpdf: the whitened float32 form needs M %% 128 == 0, S B %% 256 == 0, Q <= 16, homoscedastic noise (see mxf_svgp_whitened_ok)");
+    // (each branch mirrors one carve below, in the same order)
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
+    else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); acc((size_t)(M / 128) * SB, sizeof(float)); }
     if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
-    else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
@@ -802,6 +803,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         Gw = cv.take<D>(MP); dmud = cv.take<D>(MP); dZc = cv.take<D>(M * Q); dlsc = cv.take<D>(lsn); dvc = cv.take<D>(4);
     }
     // sc: [0]=sumlogdiag L, [1]=sumlogdiag Ls, [2]=tr(Ki Su), [3]=mu.w, [4]=dnoise, [5]=dvar_direct
+    // the accounting above and the carve must stay in step (a dangling else once had them 4 GB apart)
+    if (cv.off > need) MXF_FAIL(h, -6, "mxf_svgp_logpdf: internal error, scratch carve %zu exceeds its accounting %zu", cv.off, need);
+#ifdef MXF_PROBES
+    if (cv.off != need) MXF_FAIL(h, -6, "mxf_svgp_logpdf: internal error, scratch carve %zu != accounting %zu", cv.off, need);
+#endif
 
 #define CONV(n, src, dst) hipLaunchKernelGGL((convert_kernel<T, D>), dim3(gridn(n)), dim3(256), 0, st, (int64_t)1, (int64_t)(n), src, (int64_t)(n), dst, (int64_t)(n))
     // (W and diag(s) are converted on the second side stream, where Su is formed: two launches less in front of the Kuu chain)

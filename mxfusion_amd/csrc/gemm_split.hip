@@ -144,6 +144,12 @@ struct SplitArgs {
     unsigned short* Cp; int64_t pC;
     int64_t rot_div;
     int a_lower;                         // A is lower triangular (A[m][k] = 0 for k > m): a row tile's k loop ends at its last row
+    // a_lower, CPL instantiations (r05): work items are PAIRS over two neighbouring column strips -- role r takes row tile r of the first
+    // strip with k ASCENDING, then row tile tm - 1 - r of the second strip with k DESCENDING: every role carries tm + 1 units of k blocks,
+    // and when the tm roles of a pair start together (rendezvous) every one of them reads k block j of the first strip at time j and k
+    // block j of the second strip at time (tm + 1) units - j -- the strip's B planes are fetched from the fabric once instead of once per
+    // row tile (r04 PMC: 21.6 GB for an 8.6 GB operand = (1 + 2 + 3 + 4) / 4)
+    int pair;
     // CPL instantiations, optional: the same values ALSO as the planes of the transposed (N x K' = M) operand, element (n, m) at
     // ((m / 16) * N + n) * 16 + m % 16 (through a wave-private LDS tile, 16-byte stores), and with avec the partial sums
     // Upart[(m / 128) * N + n] = sum over the 128-row band of avec[m] * (hi + lo)(m, n)  (the whitened SVGP tier's V^T and a^T V)
@@ -418,7 +424,9 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     // Persistent over the (tile, k split) work items: workgroup b takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so its items
     // stay on its XCD's run of tiles).  The epilogue's stores of one item drain while the next item's first loads are in flight; with one
     // item per workgroup every tile paid a dispatch + an un-overlapped pipeline fill + a store burst (~30 % of a K = 1024 tile).
-    for (int64_t wid0 = blockIdx.x; wid0 < g.nwg; wid0 += gridDim.x) {
+    const int nsub = (CPL && g.pair) ? 2 : 1;
+    for (int64_t wid0 = blockIdx.x; wid0 < g.nwg; wid0 += gridDim.x)
+    for (int sub = 0; sub < nsub; ++sub) {
     int64_t wid = wid0;
     {   // XCD-aware mapping: every XCD owns a contiguous run of tiles
         const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
@@ -435,13 +443,24 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
         tile_m = t % g.tm; tile_n = t / g.tm;       // the row tiles of one column tile are neighbours: they share the B columns in L2
         // triangular A: row tile r carries (r + 1) / tm of the work, and a persistent workgroup would meet the SAME row tile in every
         // round (its items are a multiple of tm apart) -- rotate the row tile with the round
-        if constexpr (CPL) { if (g.a_lower && g.rot_div > 0) tile_m = (tile_m + tile_n / g.rot_div) % g.tm; }
+        if constexpr (CPL) {
+            if (g.pair) {            // item t = (strip pair t / tm, role t % tm); see SplitArgs::pair
+                const int64_t role = t % g.tm, sp = t / g.tm;
+                tile_n = 2 * sp + sub;
+                tile_m = sub ? g.tm - 1 - role : role;
+                if (tile_n >= g.tn) break;          // odd strip count: the last pair has no second strip (workgroup-uniform)
+            } else if (g.a_lower && g.rot_div > 0) tile_m = (tile_m + tile_n / g.rot_div) % g.tm;
+        }
     }
     const int64_t m0 = tile_m * WBMt, n0 = tile_n * WBN;
     const int64_t kbeg = split * g.kchunk;
     int64_t kend = (kbeg + g.kchunk < g.K16) ? kbeg + g.kchunk : g.K16;
     if constexpr (CPL) { if (g.a_lower) { const int64_t kl = (m0 + WBMt + 15) / 16; kend = kl < kend ? kl : kend; } }
-    if (g.sync && g.sync_period == 0) wg_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
+    // k order of this item: block KMAP(i), i = 0 .. nk - 1 (descending for the second item of a pair; compile-time ascending otherwise)
+    const bool kdesc = CPL && g.pair && sub == 1;
+    const int64_t korg = kdesc ? kend - 1 : kbeg, kdir = kdesc ? -1 : 1, nk = kend - kbeg;
+#define KMAP(i) (korg + kdir * (i))
+    if (g.sync && g.sync_period == 0 && sub == 0) wg_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
     // (Measured and dropped, r03: skipping the MFMAs of the waves / 32 x 32 fragments that lie strictly above the diagonal of a lower-only
     //  product -- 10 % / 17 % of Psi2's matrix work.  Any branch around the MFMA block costs the kernel its schedule: 231 -> 251 VGPRs with
     //  the wave-uniform form, T 11.5 -> 12.5 ms although T never takes the branch; spills with the per-fragment form.)
@@ -535,7 +554,8 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     // barrier that closed block kk - 1 --, then the MFMAs, then the wait for block kk + 1 (registers BRN) with block kk + 2 in flight
 #define W_STEP(kk, SLOT, BR, SLOT2, BR2, BRN)                                                                                       \
     do {                                                                                                                            \
-        const int64_t k2_ = (kk) + 2 < kend ? (kk) + 2 : klast;                                                                     \
+        const int64_t i2_ = (kk) + 2 < nk ? (kk) + 2 : nk - 1;                                                                      \
+        const int64_t k2_ = KMAP(i2_);                                                                                              \
         W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
         W_COMPUTE(SLOT, BR);                                                                                                        \
         W_WAIT1(BRN);                                                                                                               \
@@ -551,7 +571,8 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     } while (0)
 #define W_STEP_PP(kk, SLOT, BR, SLOT2, BR2, BRN)                                                                                    \
     do {                                                                                                                            \
-        const int64_t k2_ = (kk) + 2 < kend ? (kk) + 2 : klast;                                                                     \
+        const int64_t i2_ = (kk) + 2 < nk ? (kk) + 2 : nk - 1;                                                                      \
+        const int64_t k2_ = KMAP(i2_);                                                                                              \
         W_ISSUE(k2_, SLOT2, BR2);                                                                                                   \
         u32x4 a_[XT][2];                                                                                                            \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) { a_[x][0] = smem[SLOT][0][ua[x]]; a_[x][1] = smem[SLOT][1][ua[x]]; }         \
@@ -609,23 +630,22 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
 #undef W_ISSUE_A
         }
     } else
-    if (kbeg < kend) {
-        const int64_t klast = kend - 1;
-        int64_t kb = kbeg;
+    if (nk > 0) {
+        int64_t kb = 0;                            // index into this item's k order (KMAP)
         // the block count modulo 3 first, unpipelined (request, drain, multiply): the pipelined loop then runs whole trips of three
-        for (int i = (int)((kend - kbeg) % 3); i > 0; --i, ++kb) {
-            W_ISSUE(kb, 0, b0);
+        for (int i = (int)(nk % 3); i > 0; --i, ++kb) {
+            W_ISSUE(KMAP(kb), 0, b0);
             W_WAIT0(b0);
             W_COMPUTE(0, b0);
             __builtin_amdgcn_s_barrier();          // slot 0 is rewritten by the next request
         }
-        if (kb < kend) {
-            W_ISSUE(kb, 0, b0);
-            W_ISSUE(kb + 1, 1, b1);
+        if (kb < nk) {
+            W_ISSUE(KMAP(kb), 0, b0);
+            W_ISSUE(KMAP(kb + 1), 1, b1);
             W_WAIT1(b0);
             if constexpr (PP) { if (wh == 1) W_PHASE_END(); }         // the second half runs one phase behind from here on ...
             int trip = 0, sync_ix = 0;
-            for (; kb < kend; kb += 3) {           // three k blocks per trip: ring indices are compile-time constants, one loop exit
+            for (; kb < nk; kb += 3) {             // three k blocks per trip: ring indices are compile-time constants, one loop exit
                 if constexpr (PP) {
                     W_STEP_PP(kb, 0, b0, 2, b2, b1);
                     W_STEP_PP(kb + 1, 1, b1, 0, b0, b2);
@@ -653,6 +673,7 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[1][0]), "+v"(b1[0][0]), "+v"(b1[1][0])::"memory");
         }
     }
+#undef KMAP
 #undef W_STEP
 #undef W_STEP_PP
 #undef W_PHASE_END
@@ -942,6 +963,10 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     if (splitk < 1) splitk = 1;
     g.splitk = splitk; g.kchunk = kchunk; g.atomic = splitk > 1;
     g.tm = tm; g.tn = tn; g.ntiles = tiles; g.nwg = tiles * splitk;
+    // triangular planes-output products walk PAIRS of column strips (SplitArgs::pair); MXF_SPLIT_PAIR=0 (probe builds): the r04 rotation
+    static const int pair_env = (int)MXF_KNOB("MXF_SPLIT_PAIR", 1);
+    g.pair = (wide && Cplanes && a_lower && pair_env && tm >= 2 && tn >= 2) ? 1 : 0;
+    if (g.pair) { g.ntiles = tm * ((tn + 1) / 2); g.nwg = g.ntiles; }
     g.sync = nullptr; g.sync_n = 1; g.sync_period = 0; g.sync_slots = 0;
     if (g.nwg > 2147483647LL) MXF_FAIL(h, -3, "mxf_gemm_split: grid too large");
     if (g.atomic && beta != 1.0) {
@@ -955,13 +980,23 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         // persistent: as many workgroups as fit the chip (the kernel's occupancy) walk the work items; fewer items than that: one each
         static const int64_t wide_grid_env = MXF_KNOB("MXF_SPLIT_WIDE_GRID", 0);
         // (planes-output products honour reserve_cus: a caller that runs a latency-bound chain next to this product leaves it some CUs)
-        const int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? (Cplanes ? (256 - reserve_cus) / 8 * 8 : 256) : (Cplanes ? (256 - reserve_cus) / 8 * 8 * 2 : 512));
+        int64_t wide_grid = wide_grid_env > 0 ? wide_grid_env : (WBMh == 256 ? (Cplanes ? (256 - reserve_cus) / 8 * 8 : 256) : (Cplanes ? (256 - reserve_cus) / 8 * 8 * 2 : 512));
+        // paired items: the tm roles of a pair must be resident in the same persistent round -- workgroups per XCD a multiple of tm
+        if (g.pair && wide_grid / 8 >= tm) wide_grid = (wide_grid / 8) / tm * tm * 8;
         const int64_t grid = (wide_grid >= 8 && g.nwg > wide_grid) ? wide_grid / 8 * 8 : g.nwg;
         // rendezvous groups (wg_rendezvous): MXF_SPLIT_SYNC 0 = none; 1 = the row tiles of one column strip (full products) / the tiles of
         // one k split (split-K products); 2 = full products: all workgroups of an XCD, once per work item
         static const int sync_env = (int)MXF_KNOB("MXF_SPLIT_SYNC", 1);
         static const int sync_period_env = (int)MXF_KNOB("MXF_SPLIT_SYNC_PERIOD", 16);
-        if (Cplanes && a_lower) {
+        if (g.pair) {
+            // the tm roles of a strip pair = tm consecutive items of one XCD's run, taken in the same round by tm different workgroups: they
+            // start together (bounded rendezvous, a pacing hint) and then stay in step by construction -- every role does tm + 1 units
+            const int64_t q = g.nwg / 8, per_xcd = grid / 8;
+            if (sync_env && g.nwg % 8 == 0 && q % tm == 0 && per_xcd >= tm && per_xcd % tm == 0) {
+                g.sync = mxf_gsync(h, (unsigned)(g.nwg / tm));
+                if (g.sync) { g.sync_n = (int)tm; g.sync_period = 0; g.sync_slots = 0; }
+            }
+        } else if (Cplanes && a_lower) {
             g.rot_div = (grid / 8) / tm > 0 ? (grid / 8) / tm : 1;       // (no rendezvous: the row tiles of a strip carry unequal work)
         } else if (sync_env && !lower_only && splitk == 1 && g.nwg % 8 == 0 && g.nwg >= 16) {
             const int64_t q = g.nwg / 8, per_xcd = grid / 8;        // work items / resident workgroups per XCD

@@ -66,7 +66,7 @@ class BatchInferenceLoop(GradLoop):
             trainer.step(batch_size=1)
         self._trainer = trainer
         with torch.no_grad():                      # batch_loop.py:61: one extra forward, discarded
-            infr_executor(*data)
+            infr_executor(*self._local(data))
 
     def step(self, infr_executor, data, param_dict):
         """record -> forward -> backward (batch_loop.py:52-54) + the gradient exchange hook; returns the loss."""
@@ -129,28 +129,70 @@ class BatchInferenceLoop(GradLoop):
     def _exchange(self, param_dict):
         pass
 
+    def _local(self, data):
+        return data
+
 
 class DistributedBatchInferenceLoop(BatchInferenceLoop):
-    """Data-parallel batch loop: every rank evaluates its shard of the MC samples (the inference algorithm's
-    num_samples is the LOCAL count) with the loss weighted 1/world_size, then the flat gradient is summed with one
-    all-reduce.  backend 'nccl' is RCCL on ROCm; tests use 'gloo' on CPU tensors."""
+    """Data-parallel batch loop (backend 'nccl' is RCCL on ROCm; tests use 'gloo' on CPU tensors): one all-reduce of the flat gradient per
+    step; the returned loss is reduced over the ranks too.
 
-    def __init__(self, process_group=None, use_graph=False):
+    shard='samples': every rank evaluates its shard of the MC samples (the inference algorithm's num_samples is the LOCAL count); objective
+      and gradient are the mean over ranks.
+    shard='rows' (models without a sample axis; `row_variables` = the variables whose factors are sums over data rows, e.g. [m.Y] of an SVGP
+      model): every rank evaluates rows [r N / world, (r + 1) N / world) of the data -- every data tensor whose leading dimension is the row
+      count is split --, the row-independent factors carry weight 1 / world (see DistributedMinibatchInferenceLoop); gradient and loss are summed."""
+
+    def __init__(self, process_group=None, use_graph=False, shard='samples', row_variables=None):
         super(DistributedBatchInferenceLoop, self).__init__(use_graph=use_graph)
+        if shard not in ('samples', 'rows'):
+            raise ValueError("shard must be 'samples' or 'rows'")
+        if shard == 'rows' and not row_variables:
+            raise ValueError("shard='rows' needs row_variables: the variables whose factors are sums over data rows")
         self.process_group = process_group
+        self.shard = shard
+        self.rv_scaling = {v.uuid: 1.0 for v in row_variables} if shard == 'rows' else None
+        self._local_cache = None
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group)
+        return 1
+
+    def global_weight(self):
+        return 1.0 / self._world() if self.shard == 'rows' else None
+
+    def _local(self, data):
+        """This rank's rows of the data (row sharding); the slices are cached per data object so that a captured graph keeps its inputs."""
+        world = self._world()
+        if self.shard != 'rows' or world <= 1:
+            return data
+        import torch.distributed as dist
+        key = tuple(id(d) for d in data)
+        if self._local_cache is None or self._local_cache[0] != key:
+            r = dist.get_rank(self.process_group)
+            n = max(d.shape[0] for d in data if hasattr(d, 'shape') and d.dim() > 0)
+            loc = [torch.tensor_split(d, world)[r] if (hasattr(d, 'shape') and d.dim() > 0 and d.shape[0] == n) else d for d in data]
+            self._local_cache = (key, loc, list(data))         # (the data list is kept alive: ids are only unique among live objects)
+        return self._local_cache[1]
 
     def step(self, infr_executor, data, param_dict):
-        import torch.distributed as dist
-        if not getattr(self, '_synced', False) and dist.is_available() and dist.is_initialized() and \
-                dist.get_world_size(self.process_group) > 1:
+        world = self._world()
+        if not getattr(self, '_synced', False) and world > 1:
+            import torch.distributed as dist
             with torch.no_grad():           # replicas must start from identical parameters (un-set ones are drawn from the host RNG)
                 dist.broadcast(param_dict.flat.data, src=0, group=self.process_group)
             self._synced = True
-        return super(DistributedBatchInferenceLoop, self).step(infr_executor, data, param_dict)
+        loss = super(DistributedBatchInferenceLoop, self).step(infr_executor, self._local(data), param_dict)
+        from .minibatch_loop import _reduce_loss
+        return _reduce_loss(loss, world, self.process_group, mean=self.shard == 'samples')
 
     def _exchange(self, param_dict):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+        world = self._world()
+        if world > 1:
+            import torch.distributed as dist
             g = param_dict.flat.grad
-            g.div_(dist.get_world_size(self.process_group))
+            if self.shard == 'samples':
+                g.div_(world)
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group)

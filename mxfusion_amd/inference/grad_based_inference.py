@@ -16,9 +16,11 @@ class GradBasedInference(Inference):
         self._grad_loop = grad_loop
 
     def create_executor(self):
-        rv_scaling = self._grad_loop.rv_scaling if isinstance(self._grad_loop, MinibatchInferenceLoop) else None
+        rv_scaling = getattr(self._grad_loop, 'rv_scaling', None)          # (the minibatch loops; the row-sharded batch loop: scaling 1)
+        gw = getattr(self._grad_loop, 'global_weight', None)
+        gw = gw() if callable(gw) else gw                                  # 1 / world size for a row-sharded loop, else None
         return self._inference_algorithm.create_executor(data_def=self.observed_variable_UUIDs, params=self.params,
-                                                         var_ties=self.params.var_ties, rv_scaling=rv_scaling)
+                                                         var_ties=self.params.var_ties, rv_scaling=rv_scaling, global_weight=gw)
 
     def run(self, optimizer='adam', learning_rate=1e-3, max_iter=2000, verbose=False, permutations=None, generator=None, **kwargs):
         """grad_based_inference.py:73-104.  `permutations` / `generator`: the minibatch loop's shuffle seam (one index sequence per epoch /
@@ -34,6 +36,10 @@ class GradBasedInference(Inference):
                                       optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
                                       update_shape_constants=update_shape_constants, generator=generator, permutations=permutations)
         else:
+            local = self._grad_loop._local(data) if hasattr(self._grad_loop, '_local') else data
+            if local is not data:          # row-sharded batch loop: the executor sees this rank's rows -- shape constants (N) follow them
+                shapes = {i: tuple(d.shape) for i, d in zip(self.observed_variable_UUIDs, local)}
+                self.params.update_constants(discover_shape_constants(shapes, self._graphs))
             out = self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
                                       optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
         self._check_float32_validity()

@@ -68,8 +68,11 @@ class InferenceAlgorithm(object):
     def graphs(self):
         return self._graphs
 
-    def prepare_executor(self, rv_scaling=None):
-        """inference_alg.py:165-190: collect the variable transformations; push rv_scaling into the factors."""
+    def prepare_executor(self, rv_scaling=None, global_weight=None):
+        """inference_alg.py:165-190: collect the variable transformations; push rv_scaling into the factors.
+        `global_weight` (row-sharded data-parallel loops; no reference counterpart): every factor whose variable is NOT in rv_scaling -- priors
+        of global parameters, global latent variables, q(u) -- is evaluated in full by every rank and carries this weight (1 / world size), the
+        factors in rv_scaling see only this rank's rows: the ranks' objectives then add up to the single-process objective."""
         from ..modules.module import Module
         var_trans = {}
         excluded = set()
@@ -77,15 +80,26 @@ class InferenceAlgorithm(object):
             for v in g.variables.values():
                 if v.type == VariableType.PARAMETER and v.transformation is not None:
                     var_trans[v.uuid] = v.transformation
-                if v.type == VariableType.RANDVAR and v.factor is not None and rv_scaling is not None and v.uuid in rv_scaling:
-                    v.factor.log_pdf_scaling = rv_scaling[v.uuid]
+                if v.type == VariableType.RANDVAR and v.factor is not None and not isinstance(v.factor, Module):
+                    f = v.factor
+                    if rv_scaling is not None and v.uuid in rv_scaling:
+                        f.log_pdf_scaling = rv_scaling[v.uuid]
+                        f._mxf_global_weighted = False
+                    elif global_weight is not None:
+                        if not getattr(f, '_mxf_global_weighted', False):
+                            f._mxf_unweighted_scaling = f.log_pdf_scaling
+                        f.log_pdf_scaling = f._mxf_unweighted_scaling * global_weight
+                        f._mxf_global_weighted = True
+                    elif getattr(f, '_mxf_global_weighted', False):      # an earlier row-sharded run left its weight here
+                        f.log_pdf_scaling = f._mxf_unweighted_scaling
+                        f._mxf_global_weighted = False
             for f in getattr(g, '_factors', []):
                 if isinstance(f, Module):
-                    var_trans.update(f.prepare_executor(rv_scaling=rv_scaling))
+                    var_trans.update(f.prepare_executor(rv_scaling=rv_scaling, global_weight=global_weight))
         return var_trans, excluded
 
-    def create_executor(self, data_def, params, var_ties, rv_scaling=None):
-        var_trans, _ = self.prepare_executor(rv_scaling=rv_scaling)
+    def create_executor(self, data_def, params, var_ties, rv_scaling=None, global_weight=None):
+        var_trans, _ = self.prepare_executor(rv_scaling=rv_scaling, global_weight=global_weight)
         return ObjectiveBlock(infr_method=self, constants=params.constants, data_def=data_def, var_trans=var_trans,
                               var_ties=var_ties, infr_params=params)
 

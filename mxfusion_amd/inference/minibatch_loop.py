@@ -47,6 +47,7 @@ class MinibatchInferenceLoop(GradLoop):
         B = self.batch_size
         perms = iter(permutations) if permutations is not None else None
         carry = torch.empty(0, dtype=torch.long, device=data[0].device)
+        self.epoch_losses = []
         for e in range(max_iter):
             perm = self._next_permutation(N, data[0].device, generator, perms)
             idx = torch.cat([carry, perm])                       # 'rollover': the remainder opens the next epoch
@@ -59,25 +60,42 @@ class MinibatchInferenceLoop(GradLoop):
                 if verbose:
                     print('\repoch {} Iteration {} loss: {}\t\t\t'.format(e + 1, i + 1, float(loss.detach())), end='')
                 trainer.step(batch_size=B)
-                L_e += float(loss.detach())
+                # the epoch loss is accumulated ON THE DEVICE: the reference's `L_e += loss.asscalar()` (minibatch_loop.py:92) blocks the host on
+                # every minibatch -- with a 2.5 ms step that is a full drain of the launch queue per step; one read per epoch here
+                L_e = loss.detach() if n_batches == 0 else L_e + loss.detach()
                 n_batches += 1
             carry = idx[n_full * B:]
+            if n_batches:
+                self.epoch_losses.append(L_e / n_batches)             # device scalars; float() them when (if) they are wanted
             if verbose and n_batches:
-                print('epoch-loss: {} '.format(L_e / n_batches))
+                print('epoch-loss: {} '.format(float(L_e) / n_batches))
         self._trainer = trainer
 
 
 class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
-    """Minibatches x Monte-Carlo-sample sharding (one process per GPU; backend 'nccl' is RCCL on ROCm, tests use 'gloo'):
-      * every rank holds the full data set and walks the SAME shuffles (rank 0 draws each epoch's permutation and broadcasts it),
-      * every rank evaluates the minibatch with ITS shard of the MC samples (the inference algorithm's num_samples is the local count),
-        the loss weighted 1/world_size,
-      * the flat gradient is summed with ONE all-reduce per minibatch, then every rank takes the identical Trainer.step(batch_size=B).
+    """Data-parallel minibatch loop (one process per GPU; backend 'nccl' is RCCL on ROCm, tests use 'gloo').  Every rank holds the full data
+    set and walks the SAME shuffles (rank 0 draws each epoch's permutation and broadcasts it); ONE all-reduce of the flat gradient per
+    minibatch, then every rank takes the identical Trainer.step(batch_size=B); the returned loss is reduced over the ranks as well.
+
+    shard='samples' (BASELINE.json configs[3]): every rank evaluates the whole minibatch with ITS shard of the Monte-Carlo samples (the
+      inference algorithm's num_samples is the local count); objective and gradient are the mean over ranks.
+    shard='rows' (second axis -- for models WITHOUT a sample axis, e.g. MAP on observed inputs as in the reference's
+      svgp_regression notebook, where sample sharding leaves 7 of 8 GPUs idle): every rank evaluates rows [r B / world, (r + 1) B / world) of
+      the minibatch.  Factors of the variables named in rv_scaling are sums over rows (that is what makes them minibatch-able,
+      minibatch_loop.py:42-63) and see the rank's rows with the usual N / B scaling; every other factor -- priors of global parameters and,
+      inside an SVGP module, -KL(q(u) || p(u)) (svgp_regression.py:93-97) -- is evaluated by every rank with weight 1 / world
+      (InferenceAlgorithm.prepare_executor(global_weight=...)).  The ranks' objectives then ADD UP to the single-process objective: gradient
+      and loss are summed, not averaged.  Modules whose bound is not a sum over rows (exact GP, Titsias sparse GP) refuse.
     The reference has no counterpart (single ctx); 1 rank reproduces MinibatchInferenceLoop exactly."""
 
-    def __init__(self, batch_size=100, rv_scaling=None, process_group=None):
+    def __init__(self, batch_size=100, rv_scaling=None, process_group=None, shard='samples'):
         super(DistributedMinibatchInferenceLoop, self).__init__(batch_size=batch_size, rv_scaling=rv_scaling)
+        if shard not in ('samples', 'rows'):
+            raise ValueError("shard must be 'samples' or 'rows'")
+        if shard == 'rows' and not self.rv_scaling:
+            raise ValueError("shard='rows' needs rv_scaling: it names the variables whose factors are sums over data rows")
         self.process_group = process_group
+        self.shard = shard
         self._synced = False
 
     def _world(self):
@@ -85,6 +103,16 @@ class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group)
         return 1
+
+    def _rank(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.process_group)
+        return 0
+
+    def global_weight(self):
+        """Weight of the row-independent factors in this rank's objective (GradBasedInference.create_executor asks for it)."""
+        return 1.0 / self._world() if self.shard == 'rows' else None
 
     def _next_permutation(self, N, device, generator, permutations):
         perm = super(DistributedMinibatchInferenceLoop, self)._next_permutation(N, device, generator, permutations)
@@ -94,17 +122,36 @@ class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
         return perm
 
     def step(self, infr_executor, batch, param_dict, update_shape_constants=None):
-        if not self._synced and self._world() > 1:
+        world = self._world()
+        if not self._synced and world > 1:
             import torch.distributed as dist
             with torch.no_grad():           # replicas must start from identical parameters (un-set ones are drawn from the host RNG)
                 dist.broadcast(param_dict.flat.data, src=0, group=self.process_group)
             self._synced = True
-        return super(DistributedMinibatchInferenceLoop, self).step(infr_executor, batch, param_dict, update_shape_constants)
+        if self.shard == 'rows' and world > 1:
+            r = self._rank()
+            batch = [torch.tensor_split(d, world)[r] for d in batch]     # this rank's rows of the (identical) minibatch
+        loss = super(DistributedMinibatchInferenceLoop, self).step(infr_executor, batch, param_dict, update_shape_constants)
+        return _reduce_loss(loss, world, self.process_group, mean=self.shard == 'samples')
 
     def _exchange(self, param_dict):
         world = self._world()
         if world > 1:
             import torch.distributed as dist
             g = param_dict.flat.grad
-            g.div_(world)
+            if self.shard == 'samples':
+                g.div_(world)
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group)
+
+
+def _reduce_loss(loss, world, group, mean):
+    """The objective of the whole job from the ranks' shares ('flat gradient + scalar loss'): mean over ranks when the
+    samples are sharded, sum when the rows are.  Detached; on one rank the loss itself."""
+    if world <= 1:
+        return loss
+    import torch.distributed as dist
+    t = loss.detach().clone()
+    if mean:
+        t.div_(world)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

@@ -44,7 +44,22 @@ class SVGPRegressionLogPdf(VariationalInference):
 
     PMAX = 8     # output columns per fused call (register tile of the composites); wider Y is processed in column blocks
 
+    kl_weight = 1.0   # weight of the row-independent terms (-KL(q(u) || p(u))): 1 / world size when a data-parallel loop shards the rows
+
     def compute(self, F, variables):
+        """c * (data term over the rows handed in) + kl_weight * (-KL): with kl_weight = w != 1 evaluated as w * (c / w * data - KL), i.e. the
+        same fused call with the scaling c / w (the bound is linear in c: svgp_regression.py:109)."""
+        w = float(self.kl_weight)
+        if w == 1.0:
+            return self._compute(F, variables)
+        c = self.log_pdf_scaling
+        self.log_pdf_scaling = c / w
+        try:
+            return w * self._compute(F, variables)
+        finally:
+            self.log_pdf_scaling = c
+
+    def _compute(self, F, variables):
         has_mean = self.model.F.factor.has_mean
         X = variables[self.model.X]
         Y = variables[self.model.Y]
@@ -323,6 +338,8 @@ class SVGPRegressionSamplingPrediction(SVGPRegressionMeanVariancePrediction):
 
 class SVGPRegression(Module):
     """svgp_regression.py:283-457."""
+
+    row_additive = True      # the bound is a sum over data rows plus -KL(q(u) || p(u)) (svgp_regression.py:98-109): row shards add up
 
     def __init__(self, X, kernel, noise_var, inducing_inputs=None, num_inducing=10, mean=None, rand_gen=None, dtype=None, ctx=None):
         if not isinstance(X, Variable):

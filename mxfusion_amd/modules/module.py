@@ -73,13 +73,28 @@ class Module(Factor):
     def hidden_parameters(self):
         return [v.uuid for v in self.extra_parameters()]
 
-    def prepare_executor(self, rv_scaling=None):
-        """module.py:393-418: transformations of the hidden parameters; rv_scaling -> log_pdf_scaling."""
+    # True for modules whose log-pdf is a SUM over data rows plus row-independent terms (SVGP: svgp_regression.py:98-109): only those can be
+    # evaluated on a shard of the rows by each rank of a data-parallel loop (second axis)
+    row_additive = False
+
+    def prepare_executor(self, rv_scaling=None, global_weight=None):
+        """module.py:393-418: transformations of the hidden parameters; rv_scaling -> log_pdf_scaling.
+        `global_weight` (row-sharded data-parallel loops, no reference counterpart): the weight of the terms that do NOT depend on the data rows
+        (the module's KL term; the whole module when its outputs are not row-sharded), so that the ranks' objectives add up to the
+        single-process objective."""
         var_trans = {v.uuid: v.transformation for v in self.extra_parameters() if v.transformation is not None}
+        sharded = False
         if rv_scaling is not None:
             for _, v in self.outputs:
                 if v.uuid in rv_scaling:
                     self.log_pdf_scaling = rv_scaling[v.uuid]
+                    sharded = True
+        if global_weight is not None and sharded and not self.row_additive:
+            from ..common.exceptions import InferenceError
+            raise InferenceError('%s: the log-pdf of this module is not a sum over data rows -- it cannot be sharded by rows '
+                                 "(use shard='samples', or replicas)" % type(self).__name__)
+        self.global_weight = 1.0 if global_weight is None else float(global_weight)
+        self._rows_sharded = sharded
         return var_trans
 
     # ---- registry -----------------------------------------------------------------------------------
@@ -150,6 +165,15 @@ class Module(Factor):
         target_names, conditionals_names = self._names(variables, targets)
         alg = self._get_algorithm_for_target_conditional_pair(self._log_pdf_algorithms, target_names, conditionals_names, exact_match=True)
         alg.log_pdf_scaling = self.log_pdf_scaling
+        gw = getattr(self, 'global_weight', 1.0)
+        if gw != 1.0:
+            if getattr(self, '_rows_sharded', False):
+                alg.kl_weight = gw           # row-sharded: the data term is this rank's share already, the row-independent terms carry 1 / world
+                try:
+                    return alg.compute(F, variables)
+                finally:
+                    alg.kl_weight = 1.0
+            return gw * alg.compute(F, variables)       # a module every rank evaluates in full
         return alg.compute(F, variables)
 
     def draw_samples(self, F, variables, num_samples=1, targets=None):

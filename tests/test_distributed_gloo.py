@@ -257,3 +257,141 @@ def test_distributed_minibatch_loop_equals_the_single_process_loop():
         assert p.exitcode == 0
     for rank, got in outs:
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-10), (rank, np.abs(got - ref).max())
+
+
+# ---- row sharding (second axis): models WITHOUT a sample axis -- the reference's svgp_regression notebook (MAP on observed X) ---------
+# The PRODUCT classes run here end to end on CPU tensors -- Model / SVGPRegression / MAP / GradBasedInference / ObjectiveBlock /
+# FactorGraph.log_pdf / Module.log_pdf / the distributed loops with their weights (global_weight -> kl_weight) --; only the three places that
+# launch HIP kernels are swapped for the oracle: the SVGP bound of one call, softplus, Adam.
+def _cpu_patches():
+    import torch.nn.functional as Fn
+    from mxfusion_amd import ops
+    from mxfusion_amd.inference import batch_loop, minibatch_loop
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    ops.softplus = lambda x: Fn.softplus(x)
+    ops.softplus_bwd_ = lambda x, dy, out: out.copy_(dy * torch.sigmoid(x))
+
+    def _compute(self, F, variables):
+        kern = O.RBF(self.model.kernel.input_dim, ARD=True)
+        kp = {'rbf_' + k.split('_', 1)[1]: v for k, v in self.model.kernel.fetch_parameters(variables).items()}
+        return O.svgp_log_pdf(kern, variables[self.model.X], variables[self.model.Y], variables[self.model.inducing_inputs],
+                              variables[self.model.noise_var], variables[self.posterior.qU_mean], variables[self.posterior.qU_cov_W],
+                              variables[self.posterior.qU_cov_diag], kp, jitter=self.jitter, log_pdf_scaling=self.log_pdf_scaling)
+    SVGPRegressionLogPdf._compute = _compute
+
+    class CpuTrainer(object):
+        def __init__(self, params, lr, optimizer='adam'):
+            self.p, self.opt = params, O.MXNetAdam(lr)
+
+        def step(self, batch_size=1):
+            with torch.no_grad():
+                new = self.opt.step({'flat': self.p.flat.detach().clone()}, {'flat': self.p.flat.grad.clone()}, batch_size=batch_size)['flat']
+                self.p.flat.data.copy_(new)
+            self.p.zero_grad()
+    batch_loop._Adam = CpuTrainer
+    minibatch_loop._Adam = CpuTrainer
+
+
+def _notebook_model(rng, N, M):
+    """The model of examples/notebooks/svgp_regression.ipynb (:100-121), 2-D inputs."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    X = rng.uniform(-3, 3, (N, 2))
+    Y = np.sin(X[:, :1]) + 0.3 * X[:, 1:] + 0.1 * rng.randn(N, 1)
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 2))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.05)
+    m.kernel = RBF(input_dim=2, ARD=True, variance=1., lengthscale=np.ones(2))
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, inducing_inputs=None, num_inducing=M, shape=(m.N, 1))
+    m.Y.factor.svgp_log_pdf.jitter = 1e-6
+    return m, X, Y
+
+
+def _run_rows(loop_kind, world_rank=None):
+    """3+ Adam steps of MAP on the notebook model through GradBasedInference.run with the given loop; returns (flat parameters, last loss)."""
+    from mxfusion_amd.inference import (MAP, GradBasedInference, MinibatchInferenceLoop, BatchInferenceLoop, DistributedMinibatchInferenceLoop,
+                                        DistributedBatchInferenceLoop)
+    _cpu_patches()
+    rng = np.random.RandomState(11)
+    N, M, B = 64, 5, 32
+    m, X, Y = _notebook_model(rng, N, M)
+    init = dict(Z=rng.uniform(-3, 3, (M, 2)), mu=0.3 * rng.randn(M, 1), W=0.2 * rng.randn(M, M), d=rng.uniform(0.5, 1.0, M))
+    perms = [rng.permutation(N) for _ in range(2)]
+    if loop_kind == 'minibatch':
+        loop = MinibatchInferenceLoop(batch_size=B, rv_scaling={m.Y: N / B})
+    elif loop_kind == 'minibatch-rows':
+        loop = DistributedMinibatchInferenceLoop(batch_size=B, rv_scaling={m.Y: N / B}, shard='rows')
+    elif loop_kind == 'batch':
+        loop = BatchInferenceLoop()
+    else:
+        loop = DistributedBatchInferenceLoop(shard='rows', row_variables=[m.Y])
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), grad_loop=loop, dtype='float64', context=torch.device('cpu'))
+    infr.initialize(X=(N, 2), Y=(N, 1))
+    gp = m.Y.factor
+    post = gp._extra_graphs[0]
+    infr.params[gp.inducing_inputs] = init['Z']
+    infr.params[post.qU_mean] = init['mu']
+    infr.params[post.qU_cov_W] = init['W']
+    infr.params[post.qU_cov_diag] = init['d']
+    if world_rank:                               # replicas may start anywhere: the loop broadcasts rank 0's parameters
+        with torch.no_grad():
+            infr.params.flat.add_(0.1 * world_rank)
+    losses = []
+    orig_step = loop.step
+
+    def step(*a, **k):
+        out = orig_step(*a, **k)
+        losses.append(float(out.detach()))
+        return out
+    loop.step = step
+    if 'minibatch' in loop_kind:
+        infr.run(X=X, Y=Y, learning_rate=0.05, max_iter=2, permutations=perms if not world_rank else [p[::-1].copy() for p in perms])
+    else:
+        infr.run(X=X, Y=Y, learning_rate=0.05, max_iter=3)
+    return infr.params.flat.detach().clone().numpy(), losses
+
+
+def _rows_worker(rank, world, port, q, loop_kind):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flat, losses = _run_rows(loop_kind, world_rank=rank)
+    q.put((rank, flat, losses))
+    dist.destroy_process_group()
+
+
+def _single_worker(q, loop_kind):
+    torch.set_num_threads(1)
+    q.put(_run_rows(loop_kind))
+
+
+@pytest.mark.parametrize('loop_kind', ['minibatch', 'batch'])
+def test_world_8_row_sharded_loops_equal_the_single_process_loops(loop_kind):
+    """The reference's SVGP notebook model has NO sample axis (MAP on observed inputs): with shard='rows' each of 8 ranks evaluates 1/8 of the
+    rows of every (mini)batch, the module's KL term carries weight 1/8, gradient AND loss are summed over the ranks -- parameters after 4
+    (minibatch) / 3 (batch) Adam steps equal the single-process loop to 1e-10 on every rank, and so does every step's loss."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_single_worker, args=(q, loop_kind))      # (its own process: the CPU patches replace module attributes)
+    p0.start()
+    ref, ref_losses = q.get(timeout=300)
+    p0.join(timeout=60)
+    assert p0.exitcode == 0 and len(ref_losses) >= 3
+
+    world = 8
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q, loop_kind + '-rows')) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _, _ in outs) == list(range(world))
+    for rank, got, losses in outs:
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-10), (rank, np.abs(got - ref).max())
+        assert np.allclose(losses, ref_losses, rtol=1e-10), (rank, losses, ref_losses)        # the loss is reduced over the ranks too

@@ -16,7 +16,10 @@ def _dev(a, dt=torch.float32):
     return torch.as_tensor(np.asarray(a), dtype=dt).cuda()
 
 
-@pytest.mark.parametrize('M,N,K,lower', [(256, 512, 256, False), (256, 512, 256, True), (128, 256, 128, True), (512, 768, 512, True), (384, 256, 384, False)])
+@pytest.mark.parametrize('M,N,K,lower', [(256, 512, 256, False), (256, 512, 256, True), (128, 256, 128, True), (512, 768, 512, True), (384, 256, 384, False),
+                                         # r05: triangular products walk PAIRS of column strips (ascending / descending k): four row tiles, three 128-row
+                                         # tiles, an odd strip count (the last pair has one strip)
+                                         (1024, 2048, 1024, True), (384, 1024, 384, True), (1024, 1280, 1024, True)])
 def test_planes_output_product_and_transposition(M, N, K, lower):
     """mxf_gemm_f16x2_planes_out: alpha A B^T as f16 planes == the float64 product to f32 accuracy (also with a triangular A whose k loop
     is cut short); mxf_f16x2_planes_transpose: the planes of the transpose hold the same values, and its fused U = scale a^T X."""
