@@ -114,6 +114,55 @@ def build_minibatch(N, Q, M, B, S_local, dtype, Z, prior_var=1e-2):
     return m, infr, loop
 
 
+def build_minibatch_rows(N, Q, M, B, dtype, Z, proxy_world=0):
+    """Row-sharded data parallelism for a model WITHOUT a sample axis (the reference's svgp_regression notebook: MAP on observed inputs, one
+    evaluation of the bound per minibatch): Y ~ SVGP(X), minibatches of B rows, every rank takes B / world rows of each minibatch, the KL term
+    weighted 1 / world, gradient and loss summed (DistributedMinibatchInferenceLoop(shard='rows')).  proxy_world = W > 0: ONE process evaluates
+    the share of one rank of a W-GPU run (B / W rows, KL weight 1 / W, no collective) -- the per-rank cost without a W-GPU node."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP, DistributedMinibatchInferenceLoop
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, Q))
+    m.Z = Variable(shape=(M, Q), initial_value=Z)
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    kernel = RBF(input_dim=Q, ARD=True, variance=1., lengthscale=np.ones(Q), dtype=dtype)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=dtype)
+    gp = m.Y.factor
+    gp.svgp_log_pdf.jitter = 1e-6
+
+    class ProxyLoop(DistributedMinibatchInferenceLoop):
+        def _world(self):
+            return proxy_world
+
+        def _rank(self):
+            return 0
+
+        def _next_permutation(self, N_, device, generator, permutations):
+            return super(DistributedMinibatchInferenceLoop, self)._next_permutation(N_, device, generator, permutations)
+
+        def _exchange(self, param_dict):
+            pass
+
+        def step(self, infr_executor, batch, param_dict, update_shape_constants=None):
+            batch = [torch.tensor_split(d, proxy_world)[0] for d in batch]
+            return super(DistributedMinibatchInferenceLoop, self).step(infr_executor, batch, param_dict, update_shape_constants)
+    cls = ProxyLoop if proxy_world > 1 else DistributedMinibatchInferenceLoop
+    loop = cls(batch_size=B, rv_scaling={m.Y: N / B}, shard='rows')
+    infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=loop, dtype=dtype)
+    infr.initialize(X=(B, Q), Y=(B, 1))
+    post = gp._extra_graphs[0]
+    dev = infr.mxnet_context
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    infr.params[post.qU_mean] = torch.zeros(M, 1, dtype=td, device=dev)
+    infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td, device=dev)
+    infr.params[post.qU_cov_diag] = torch.ones(M, dtype=td, device=dev)
+    return m, infr, loop
+
+
 _RANK_TIMES = {}      # filled by _finish_timing: this rank's own time of the timed region, gathered over the ranks
 
 
@@ -187,6 +236,22 @@ def time_minibatch_steps(infr, loop, Xd, Yd, B, steps, warmup, lr, distributed):
     for i in range(steps):
         loss = one(warmup + i)
     return _finish_timing(t0, distributed) + (float(loss.detach()),)
+
+
+def time_minibatch_run(infr, data_kw, epochs, lr, distributed):
+    """The same minibatch steps through the PRODUCT entry point, GradBasedInference.run (initialise, executor, shuffles, slicing, the loop's
+    epoch-loss bookkeeping, Trainer): one untimed epoch, then `epochs` timed ones; returns seconds per minibatch step."""
+    import torch.distributed as dist
+    N = next(iter(data_kw.values())).shape[0]
+    nb = N // infr._grad_loop.batch_size
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    infr.run(max_iter=1, learning_rate=lr, generator=gen, **data_kw)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infr.run(max_iter=epochs, learning_rate=lr, generator=gen, **data_kw)
+    return _finish_timing(t0, distributed)[0] / (epochs * nb)
 
 
 def build_deepgp(N, Q, M, Dh, S_local, dtype, X, Y, distributed):
@@ -663,6 +728,10 @@ def main():
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--workload', default='svgp', choices=['svgp', 'gp', 'deepgp', 'pilco'], help="'svgp' = the headline (configs[2]); 'gp' = configs[1] (exact GP); 'deepgp' = configs[4]")
     ap.add_argument('--minibatch', type=int, default=0, help="svgp workload: minibatch size (0 = full batch = configs[2]; 8192 = configs[3])")
+    ap.add_argument('--shard', default='samples', choices=['samples', 'rows'], help="--minibatch: what the ranks divide -- the MC samples of the "
+                    "uncertain-input model (configs[3]) or, 'rows', the rows of every minibatch of the observed-input MAP model (no sample axis)")
+    ap.add_argument('--proxy-world', type=int, default=0, help="--minibatch --shard rows on ONE GPU: evaluate the share of one rank of a W-GPU run "
+                    "(B / W rows, KL weight 1 / W, no collective)")
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--horizon', type=int, default=100, help='time steps of the PILCO rollout workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
@@ -797,13 +866,41 @@ def main():
         return
     N, Q, M = args.N, args.Q, args.M
     X, Y, Z = synth(N, Q, M)
+    if args.minibatch and args.shard == 'rows':      # row-sharded data parallelism for a model without a sample axis (second axis)
+        B = args.minibatch
+        td = torch.float32 if args.dtype == 'float32' else torch.float64
+        m, infr, loop = build_minibatch_rows(N, Q, M, B, args.dtype, Z, proxy_world=args.proxy_world)
+        Xd, Yd = torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()
+        dt, last_loss = time_minibatch_steps(infr, loop, Xd, Yd, B, args.steps, args.warmup, args.lr, distributed)
+        run_s = time_minibatch_run(infr, {'X': Xd, 'Y': Yd}, max(2, args.steps // (N // B)), args.lr, distributed)
+        rep = dist_report(world, args.steps, infr.params.flat.numel(), td)
+        w = args.proxy_world if args.proxy_world > 1 else world
+        if rank == 0:
+            emit(dict({"metric": "ELBO-steps/sec (minibatch steps), SVGP MAP on observed inputs N=65k D=8 M=1024 minibatch=%d, rows sharded" % B,
+                  "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": dt / args.steps * 1e3, "ms_per_step_through_run": run_s * 1e3, "higher_is_better": True, "scaling": "strong",
+                  "vs_baseline": None, "dtype": "f32" if args.dtype == 'float32' else "f64", "data": "synthetic",
+                  "config": {"workload": "SVGPRegression RBF-ARD N=%d Q=%d M=%d, MAP on observed inputs (no sample axis: the reference's svgp_regression "
+                                         "notebook), minibatch %d (rv_scaling %g), step = minibatch ELBO + reverse mode + grad all-reduce + Adam"
+                                         % (N, Q, M, B, N / B),
+                             "rows_per_rank": B // w, "kl_weight": 1.0 / w,
+                             "parallelism": ("one-GPU proxy of one rank of a %d-GPU run (no collective)" % w) if args.proxy_world > 1 else
+                                            "rows of each minibatch sharded x%d, 1 RCCL all-reduce of the flat gradient + the loss per step" % world},
+                  "last_loss": last_loss, "potrf_info": int(m.Y.factor.svgp_log_pdf._last_info.abs().sum())}, **rep, **guard_report()))
+        if distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.minibatch:          # BASELINE.json configs[3]: minibatch x sample sharding
         B = args.minibatch
         td = torch.float32 if args.dtype == 'float32' else torch.float64
         m, infr, loop = build_minibatch(N, Q, M, B, S_local, args.dtype, Z)
-        dt, last_loss = time_minibatch_steps(infr, loop, torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda(), B, args.steps,
-                                             args.warmup, args.lr, distributed)
+        Xd_, Yd_ = torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()
+        dt, last_loss = time_minibatch_steps(infr, loop, Xd_, Yd_, B, args.steps, args.warmup, args.lr, distributed)
+        # the same steps through GradBasedInference.run (what a user calls): r04's loop synchronised the device on every minibatch
+        run_s = time_minibatch_run(infr, {'Xobs': Xd_, 'Y': Yd_}, max(2, args.steps // (N // B)), args.lr, distributed)
         rep = dist_report(world, args.steps, infr.params.flat.numel(), td)          # collective: every rank
+        rep["ms_per_step_through_run"] = run_s * 1e3
         if rank == 0:
             emit(dict({"metric": "ELBO-steps/sec (minibatch steps), SVGP N=65k D=8 M=1024 minibatch=%d (BASELINE.json configs[3])" % B,
                   "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -853,6 +950,7 @@ def main():
         set_trained_like(m, infr, Q, M, td)
         dtt, _ = time_steps(infr, loop, Yd, nst, 2, args.lr, False)
         out["ms_per_step_trained_like"] = dtt / nst * 1e3
+        out["value_trained_like"] = nst / dtt           # ELBO-steps/sec in the regime training spends its time in (whitened float32 form)
         out["trained_like"] = dict(guard_report(), **step_breakdown(infr, loop, Yd, args.lr, M, N * S_local))
         Float32Guard.force = Float32Guard.WHITENED
         try:

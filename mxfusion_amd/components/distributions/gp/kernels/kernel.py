@@ -59,6 +59,9 @@ class _Gram2Fn(torch.autograd.Function):
         grads = []
         for (kind, ard, ls, var, other, gi) in ((k1, a1, ls1, var1, (k2, a2, ls2, var2), 3), (k2, a2, ls2, var2, (k1, a1, ls1, var1), 5)):
             nd = list(need) + (['ls'] if ctx.needs_input_grad[gi] else []) + (['var'] if ctx.needs_input_grad[gi + 1] else [])
+            if not nd:                    # nothing of this sub-kernel is differentiated: no recomputed Gram, no reverse pass
+                grads += [None, None]
+                continue
             dKi = dK if op == ops.ACC_ADD else dK * ops.gram(other[0], X, X2, other[2], other[3], other[1])
             dX, dX2, dls, dvar = ops.gram_bwd(kind, X, X2, ls, var, ard, dKi, need=nd)
             out[0] = dX if out[0] is None else (out[0] if dX is None else out[0] + dX)
@@ -239,6 +242,8 @@ class CombinationKernel(Kernel):
             return None
         Xs, X2s = ks[0]._slice(X), ks[0]._slice(X2)
         if Xs.shape[-1] > 16:
+            return None
+        if Xs.shape[-2] > 16 * 65535:         # one launch of mxf_gram2 covers 65 535 row blocks of 16: larger Grams take the per-kernel path
             return None
         p0, p1 = ks[0]._strip(params), ks[1]._strip(params)
         spec = (ks[0]._kind, bool(ks[0].ARD), ks[1]._kind, bool(ks[1].ARD), op)

@@ -105,7 +105,12 @@ class Float32Guard(object):
         if cls._instances is None:
             cls._instances = weakref.WeakSet()
         cls._counter += 1
-        self.slot = 1 + (cls._counter - 1) % (_lib.COND_SLOTS - 1)      # slot 0: calls that never configured one
+        # a condition slot no LIVE guard holds (slot 0: calls that never configured one).  More live guards than slots: the surplus share the
+        # last slot and are pinned to float64 (`shared_slot`) -- a shared slot's readings cannot be attributed
+        used = {g.slot for g in cls._instances}
+        free = [k for k in range(1, _lib.COND_SLOTS) if k not in used]
+        self.shared_slot = not free
+        self.slot = free[0] if free else _lib.COND_SLOTS - 1
         self.name = name
         self.tier = self.EXPLICIT
         self.cond_max = 0.0         # largest condition number this owner has seen
@@ -146,11 +151,14 @@ class Float32Guard(object):
                 if mx > 0 and not getattr(g, '_stale', False):
                     g.cond_max, g.cond_last = max(g.cond_max, mx), last
         gs = [g for g in cls.instances() if g.cond_max > 0]
+        # the level an owner's calls really RUN at: an owner without a whitened form (combination kernels: the materialised path) evaluates in
+        # float64 as soon as it leaves the explicit form
+        eff = lambda g: cls.F64 if (g.tier != cls.EXPLICIT and getattr(g, 'no_whitened_form', False)) else g.tier
         return {'kuu_cond_max': max([g.cond_max for g in gs] or [0.0]),
-                'float32_fallback_active': any(g.tier == cls.F64 for g in gs),
-                'float32_whitened_active': any(g.tier == cls.WHITENED for g in gs),
+                'float32_fallback_active': any(eff(g) == cls.F64 for g in gs),
+                'float32_whitened_active': any(eff(g) == cls.WHITENED for g in gs),
                 'float32_tiers': {('%s#%d' % (g.name, g.slot)): ('float64 inputs' if getattr(g, 'f64_inputs', False) else
-                                                                    cls.NAMES[g.tier if cls.force is None else cls.force] + ('' if cls.force is None else ' (forced)'))
+                                                                    cls.NAMES[eff(g) if cls.force is None else cls.force] + ('' if cls.force is None else ' (forced)'))
                                   for g in gs},
                 'float32_guard': bool(cls.enabled)}
 
@@ -227,6 +235,8 @@ class Float32Guard(object):
         """The level this call runs at (enabled guards only; the caller holds float32 CUDA inputs)."""
         if not Float32Guard.enabled:
             return self.EXPLICIT
+        if getattr(self, 'shared_slot', False):          # no condition slot of its own: cannot be watched, runs where every call is valid
+            return self.F64
         self.poll(dev)
         if Float32Guard.force is not None:
             self._checked_first = True
@@ -243,9 +253,10 @@ class Float32Guard(object):
         if not Float32Guard.enabled or self._checked_first:
             return False
         self._checked_first = True
-        c = ops.svgp_last_cond(dev)
-        _lib.svgp_cond_slot(ops._device_index(dev), self.slot, reset=True)
-        self._move(c)
+        c = ops.svgp_last_cond(dev)                  # (synchronises the device: the slot below is complete)
+        # a call over S samples of the hyper-parameters publishes one condition number per sample: act on their MAXIMUM, not on the last one
+        _, mx = _lib.svgp_cond_slot(ops._device_index(dev), self.slot, reset=True)
+        self._move(max(c, mx))
         need = self.F64 if (self.tier == self.WHITENED and not whitened_ok) else self.tier
         return need > ran_at
 
@@ -254,20 +265,26 @@ def _guarded(guard, dev, is_f32, whitened_ok, run, wide=False):
     """Run `run(tier)` under `guard`: picks the level, configures the handle (form + condition slot), re-runs an owner's first call when its
     synchronous check asks for a higher level.  run(tier) evaluates the call in float32 (EXPLICIT / WHITENED) or widened to float64 (F64)."""
     g = guard if guard is not None else Float32Guard.default
-    g.f64_inputs = not is_f32
-    if not is_f32:
-        g.configure(dev, g.EXPLICIT)
-        return run(g.EXPLICIT)
-    tier = g.form(dev, whitened_ok)
-    if wide:                    # (range_too_wide: float64 whatever the condition number says)
-        tier = g.F64
-    g.configure(dev, tier)
-    r = run(tier)
-    if g.first_call_needs_rerun(dev, tier, whitened_ok):
-        tier = g.F64 if (wide or (g.tier == g.WHITENED and not whitened_ok)) else g.tier
+    g.f64_inputs = not is_f32 and not getattr(g, '_widened_by_owner', False)
+    try:
+        if not is_f32:
+            g.configure(dev, g.EXPLICIT)
+            return run(g.EXPLICIT)
+        tier = g.form(dev, whitened_ok)
+        if wide:                    # (range_too_wide: float64 whatever the condition number says)
+            tier = g.F64
         g.configure(dev, tier)
         r = run(tier)
-    return r
+        if g.first_call_needs_rerun(dev, tier, whitened_ok) and not getattr(g, '_owner_reruns', False):
+            tier = g.F64 if (wide or (g.tier == g.WHITENED and not whitened_ok)) else g.tier
+            g.configure(dev, tier)
+            r = run(tier)
+        return r
+    finally:
+        # the form and the condition slot are state of the per-(thread, device) HANDLE: left behind, a later direct ops.svgp_logpdf call
+        # (bench, tests, user code) would run the whitened form -- or fail on a shape it does not cover -- and publish its condition number
+        # into this owner's slot (ADVICE r04)
+        _lib.svgp_configure(ops._device_index(dev), _lib.FORM_EXPLICIT, 0)
 
 
 def _narrow(r):

@@ -195,13 +195,24 @@ class SVGPRegressionLogPdf(VariationalInference):
         from ._fused import Float32Guard
         if X.is_cuda and X.dtype == torch.float32 and Float32Guard.enabled and Float32Guard.force is None:
             g = self._f32_guard()
-            wide = lambda: self._compute_materialised(F, *[t.double() for t in (X, Y, Z, noise_var, mu, S_W, S_diag)], kern,
+            g.no_whitened_form = True            # (reports: this owner's calls run in float64 above the explicit limit)
+
+            def wide():
+                g._widened_by_owner = True       # (the float64 operands below belong to a float32 model: not "float64 inputs" in the report)
+                try:
+                    return self._compute_materialised(F, *[t.double() for t in (X, Y, Z, noise_var, mu, S_W, S_diag)], kern,
                                                       {k: v.double() for k, v in kern_params.items()}).float()
+                finally:
+                    g._widened_by_owner = False
             g.poll(X.device)
             if g.tier != Float32Guard.EXPLICIT:
                 return wide()
             first = not g._checked_first
-            out = self._materialised_core(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
+            g._owner_reruns = first              # an ill-conditioned first call is recomputed HERE, Gram matrices included: the bridge's own
+            try:                                 # widened-afterwards rerun would be a third evaluation
+                out = self._materialised_core(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
+            finally:
+                g._owner_reruns = False
             return wide() if (first and g.tier != Float32Guard.EXPLICIT) else out        # (an owner's first call checks synchronously)
         return self._materialised_core(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
 

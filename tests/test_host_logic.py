@@ -193,7 +193,8 @@ def test_float32_guard_levels_first_call_and_hysteresis(monkeypatch):
         warnings.simplefilter('always')
         # first call, ill-conditioned: runs explicit, the synchronous check re-runs it whitened
         assert call(1e5) == G.WHITENED and ran == [G.EXPLICIT, G.WHITENED] and g.tier == G.WHITENED
-        assert fake.configured[-1] == (_lib.FORM_WHITENED, g.slot) and len(w) == 1
+        assert fake.configured[-2] == (_lib.FORM_WHITENED, g.slot) and len(w) == 1
+        assert fake.configured[-1] == (_lib.FORM_EXPLICIT, 0)     # the handle's form / slot never outlive the guarded call
         # further calls poll the slot (no synchronous check any more); a call the whitened form does not cover runs float64 without moving the owner
         assert call(1e5) == G.WHITENED
         assert call(1e5, whitened_ok=False) == G.F64 and g.tier == G.WHITENED
@@ -332,3 +333,44 @@ def test_replicate_and_reconcile_gp_model(tmp_path):
     loaded = FactorGraph.load_graphs([json.load(open(f))])[0]
     cmap2 = FactorGraph.reconcile_graphs([m1], loaded)
     assert {k: v for k, v in cmap2.items() if k in uuids(m3)} == {k: v for k, v in cmap.items() if k in uuids(m3)}
+
+
+def test_row_sharding_weights_global_factors_and_refuses_non_additive_modules():
+    """prepare_executor(rv_scaling, global_weight) of a row-sharded data-parallel loop: factors named in rv_scaling keep their N / B scaling,
+    every other distribution factor (a prior of a global variable) carries the weight 1 / world -- restored by a later unsharded run --; an
+    SVGP module takes the weight on its KL term only; a module whose bound is not a sum over rows (exact GP) refuses."""
+    from mxfusion_amd.common.exceptions import InferenceError
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 3))
+    m.w = Normal.define_variable(mean=0., variance=1., shape=(3,))                 # a global latent variable with a prior
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
+    m.Y = SVGPRegression.define_variable(X=m.X, kernel=RBF(3, ARD=True), noise_var=m.noise_var, num_inducing=4, shape=(m.N, 1))
+    alg = MAP(model=m, observed=[m.X, m.Y])
+    alg.prepare_executor(rv_scaling={m.Y.uuid: 8.0}, global_weight=0.125)
+    assert m.w.factor.log_pdf_scaling == 0.125
+    assert m.Y.factor.log_pdf_scaling == 8.0 and m.Y.factor.global_weight == 0.125 and m.Y.factor._rows_sharded
+    alg.prepare_executor(rv_scaling={m.Y.uuid: 8.0}, global_weight=0.25)           # (weights do not compound)
+    assert m.w.factor.log_pdf_scaling == 0.25
+    alg.prepare_executor(rv_scaling={m.Y.uuid: 8.0})
+    assert m.w.factor.log_pdf_scaling == 1 and m.Y.factor.global_weight == 1.0
+
+    class Probe(object):                                                           # what Module.log_pdf hands its algorithm
+        kl_weight, seen = 1.0, None
+
+        def compute(self, F, variables):
+            Probe.seen = (self.log_pdf_scaling, self.kl_weight)
+            return torch.ones(1)
+    gp = m.Y.factor
+    alg.prepare_executor(rv_scaling={m.Y.uuid: 8.0}, global_weight=0.125)
+    gp._get_algorithm_for_target_conditional_pair = lambda *a, **k: Probe()
+    variables = {v.uuid: None for _, v in gp.inputs}
+    variables[m.Y.uuid] = None
+    assert float(gp.log_pdf(None, variables)) == 1.0 and Probe.seen == (8.0, 0.125)
+    alg.prepare_executor(rv_scaling={}, global_weight=0.125)                       # the module's output not sharded: the whole module is global
+    gp.log_pdf_scaling = 1
+    assert float(gp.log_pdf(None, variables)) == 0.125 and Probe.seen == (1, 1.0)
+
+    g = _gp()
+    with pytest.raises(InferenceError):
+        MAP(model=g, observed=[g.X, g.Y]).prepare_executor(rv_scaling={g.Y.uuid: 1.0}, global_weight=0.5)
