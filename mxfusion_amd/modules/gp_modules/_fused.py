@@ -153,7 +153,7 @@ class Float32Guard(object):
         gs = [g for g in cls.instances() if g.cond_max > 0]
         # the level an owner's calls really RUN at: an owner without a whitened form (combination kernels: the materialised path) evaluates in
         # float64 as soon as it leaves the explicit form
-        eff = lambda g: cls.F64 if (g.tier != cls.EXPLICIT and getattr(g, 'no_whitened_form', False)) else g.tier
+        eff = lambda g: cls.F64 if ((g.tier != cls.EXPLICIT and getattr(g, 'no_whitened_form', False)) or getattr(g, 'small_f64', False)) else g.tier
         return {'kuu_cond_max': max([g.cond_max for g in gs] or [0.0]),
                 'float32_fallback_active': any(eff(g) == cls.F64 for g in gs),
                 'float32_whitened_active': any(eff(g) == cls.WHITENED for g in gs),

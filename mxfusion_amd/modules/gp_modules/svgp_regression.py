@@ -90,7 +90,29 @@ class SVGPRegressionLogPdf(VariationalInference):
             return total
         return self._compute_columns(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)
 
+    # float32 calls on SMALL problems are evaluated in float64 inside (inputs widened, result narrowed; the exact GP and every prediction do the
+    # same): below ~4 M covariances per call the float64 streaming kernels cost < 0.3 ms -- the call is launch-bound either way -- and the
+    # float32 forms' condition limits are calibrated on BASELINE-sized problems: r04's randomised sweep found 3-5e-5 on the bound for
+    # M = 7 ... 100 / B ~ 1 000 problems right below them (relative to a small |ELBO|).  Large problems keep the three-level guard.
+    SMALL_F64_ELEMS = 1 << 22
+
+    def _small_in_float64(self, X, Z):
+        from ._fused import Float32Guard
+        if not (X.is_cuda and X.dtype == torch.float32 and Float32Guard.enabled and Float32Guard.force is None):
+            return False
+        return X.shape[0] * X.shape[-2] * max(Z.shape[-2], 128) <= self.SMALL_F64_ELEMS
+
     def _compute_columns(self, F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params):
+        if self._small_in_float64(X, Z):
+            g = self._f32_guard()
+            g.small_f64, g._widened_by_owner = True, True
+            try:
+                return self._compute_columns(F, *[t.double() for t in (X, Y, Z, noise_var, mu, S_W, S_diag)], kern,
+                                             {k: v.double() for k, v in kern_params.items()}).float()
+            finally:
+                g._widened_by_owner = False
+        if X.is_cuda and X.dtype == torch.float32 and getattr(self, '_guard', None) is not None:
+            self._guard.small_f64 = False
         spec = kern.fused_spec()
         if spec is None:
             return self._compute_materialised(F, X, Y, Z, noise_var, mu, S_W, S_diag, kern, kern_params)

@@ -75,6 +75,29 @@ def test_full_size_exact_gp_factorisation_reconstructs():
     assert abs(float(r['dnoise'].sum()) - float(torch.trace(dK))) <= 1e-10 * abs(float(torch.trace(dK)))
 
 
+def test_full_size_exact_gp_map_step_vs_oracle():
+    """configs[1] at its FULL size against the ORACLE (missing 4): the oracle's gp_log_pdf (gp_regression.py:55-70 op for op: Gram,
+    potrf, trsm, sumlogdiag on the host, float64) and its autograd gradients at N = 8 192, Q = 8, P = 1 -- log marginal likelihood and
+    dX, dY, dnoise, dlengthscale, dvariance of the HIP path to 1e-9."""
+    from oracle import gp_oracle as O
+    from mxfusion_amd import ops
+    N, Q = 8192, 8
+    rng, X, Y, _ = _synth(N, Q, 1, seed=1)
+    ls, var, noise = rng.uniform(0.8, 1.3, Q), np.array([1.2]), np.array([0.013])
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    lv = {k: O.T(v).clone().requires_grad_(True) for k, v in (('X', X[None]), ('Y', Y[None]), ('noise', noise[None]), ('ls', ls[None]), ('var', var[None]))}
+    ref = O.gp_log_pdf(O.RBF(Q, ARD=True), lv['X'], lv['Y'], lv['noise'], {'rbf_lengthscale': lv['ls'], 'rbf_variance': lv['var']}, jitter=0.)
+    gref = torch.autograd.grad(ref.sum(), list(lv.values()))
+    d = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64).cuda()
+    r = ops.gp_logpdf('rbf', d(X)[None], d(Y)[None], d(noise)[None], d(ls)[None], d(var)[None], True, jitter=0.0, want_grad=True)
+    torch.cuda.synchronize()
+    assert int(r['info'].abs().sum()) == 0
+    assert abs(float(r['logL'][0]) - float(ref.detach())) <= 1e-9 * abs(float(ref.detach()))
+    for key, g in zip(('dX', 'dY', 'dnoise', 'dls', 'dvar'), gref):
+        a, b = r[key].double().cpu().numpy().ravel(), g.numpy().ravel()
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (key, np.abs(a - b).max(), np.abs(b).max())
+
+
 def test_full_size_svgp_training_call_properties():
     """configs[2] shapes (N = 65 536, Q = 8, M = 1 024; 2 samples): (i) float32 training path (split GEMMs on the f16 pipe) vs float64:
     ELBO to 1e-5 (north_star), gradients to the f32 tolerance; (ii) float64 central differences of the ELBO in the noise and the kernel

@@ -1,8 +1,8 @@
 """A fixed-seed slice of the randomised sweep that found the float32 defects of r04 (tests/probes/fuzz_svgp.py): the SVGP module's training call
 over random kernel kinds, shapes (tile multiples and not: the padded paths), output columns, sampled hyper-parameters, input offsets, per-row
 noise and log_pdf_scaling -- float32 (whatever path and guard level the case takes) against float64 on IDENTICAL float32-representable
-inputs, float64 against the oracle.  Cases whose Kuu is ill-conditioned beyond what any arithmetic holds (cond > 1e5 here) are generated but
-only checked for finiteness."""
+inputs, and BOTH against the oracle (r05: the float32 call itself is held to 1e-5 on the bound).  Cases whose Kuu is ill-conditioned beyond
+what float64 holds to that bar (cond > 1e7) are generated but only checked for finiteness."""
 import warnings
 
 import numpy as np
@@ -14,9 +14,16 @@ pytestmark = pytest.mark.gpu
 from oracle import gp_oracle as O  # noqa: E402
 
 
-def _case(rng):
+def _case(rng, large=False):
     kind = ['rbf', 'matern12', 'matern32', 'matern52'][rng.randint(4)]
     S = [1, 1, 2, 3][rng.randint(4)]
+    if large:      # above SVGPRegressionLogPdf.SMALL_F64_ELEMS: the float32 forms themselves (split GEMMs, whitened tier, padded shapes) run
+        S = [1, 2][rng.randint(2)]
+        B = int(rng.choice([4096, 5000, 8192]))
+        M = int(rng.choice([256, 500, 512, 640]))
+        Q = int(rng.choice([3, 5, 8, 12, 16]))
+        P = int(rng.choice([1, 1, 2]))
+        return kind, S, B, M, Q, P, bool(rng.randint(2)), S > 1 and bool(rng.randint(2)), float(rng.choice([0., 0., 50., 3000.]))
     B = int(rng.choice([37, 256, 300, 1000, 1024, 2049]))
     M = int(rng.choice([7, 64, 100, 128, 130, 200, 256]))
     Q = int(rng.choice([3, 5, 8, 12, 16, 20]))
@@ -27,14 +34,17 @@ def _case(rng):
     return kind, S, B, M, Q, P, ard, sampled, off
 
 
-@pytest.mark.parametrize('seed', list(range(24)))
+@pytest.mark.parametrize('seed', list(range(24)) + list(range(100, 116)))
 def test_svgp_module_call_random_case(seed):
+    """seeds 0-23: the r04 slice (small problems -- since r05 evaluated in float64 inside, SVGPRegressionLogPdf.SMALL_F64_ELEMS); seeds 100-115:
+    problems large enough to run the float32 forms.  The FLOAT32 call is held to north_star's 1e-5 on the bound against the ORACLE (the
+    host evaluates every case here), gradients against the float64 call."""
     from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern12, Matern32, Matern52
     from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard
     KINDS = {'rbf': (RBF, O.RBF), 'matern12': (Matern12, O.Matern12), 'matern32': (Matern32, O.Matern32), 'matern52': (Matern52, O.Matern52)}
     rng = np.random.RandomState(1000 + seed)
-    kind, S, B, M, Q, P, ard, sampled, off = _case(rng)
+    kind, S, B, M, Q, P, ard, sampled, off = _case(rng, large=seed >= 100)
     r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     ell = float(rng.choice([0.5, 1.0, 2.0])) * np.sqrt(Q)
     X = off + rng.uniform(-2., 2., (S, B, Q))
@@ -64,15 +74,14 @@ def test_svgp_module_call_random_case(seed):
     v32, g32, cond = res[torch.float32]
     v64, g64, _ = res[torch.float64]
     assert np.isfinite(v32).all() and all(np.isfinite(x).all() for x in g32), (kind, S, B, M, Q, P)
-    if cond > 1e5:
+    if cond > 1e7:       # beyond what float64 itself holds to the bar (error ~ cond 1e-16 of sums that cancel): finiteness only
         return
     nrm = lambda a, b: float(np.linalg.norm(a.ravel() - b.ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
     tag = (kind, S, B, M, Q, P, ard, sampled, off, scal, '%.1e' % cond)
-    assert np.abs(v32 - v64).max() <= 4e-5 * np.abs(v64).max(), tag
+    ok = KINDS[kind][1](Q, ARD=ard)
+    lo = {k: O.T(v - off if k in ('X', 'Z') else v) for k, v in vals}
+    ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
+                         {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6, log_pdf_scaling=scal).numpy()
+    assert np.abs(v64 - ref).max() <= max(1e-9, 1e-13 * cond) * np.abs(ref).max(), tag
+    assert np.abs(v32 - ref).max() <= 1e-5 * np.abs(ref).max(), tag                   # north_star's bar, float32 call vs the ORACLE
     assert max(nrm(a, b) for a, b in zip(g32, g64)) <= 5e-3, tag
-    if B * M <= 300000:
-        ok = KINDS[kind][1](Q, ARD=ard)
-        lo = {k: O.T(v - off if k in ('X', 'Z') else v) for k, v in vals}
-        ref = O.svgp_log_pdf(ok, lo['X'], O.T(Y)[None], lo['Z'], lo['noise'], lo['qm'], lo['qW'], lo['qd'],
-                             {ok.name + '_lengthscale': lo['ls'], ok.name + '_variance': lo['var']}, jitter=1e-6, log_pdf_scaling=scal).numpy()
-        assert np.abs(v64 - ref).max() <= max(1e-9, 1e-13 * cond) * np.abs(ref).max(), tag

@@ -1,0 +1,81 @@
+"""float32 TRAINING against float64 (missing 3): the reference trains in one dtype (batch_loop.py:46-61, minibatch_loop.py:65-93); here
+the float32 step's gradients carry 1e-4 .. 2e-3 normwise error at trained-like conditioning (tests/test_gpu_fullsize_oracle.py), and what Adam
+makes of them over a run is what a user sees.  BASELINE.json configs[3]'s model (uncertain-input SVGP, N = 65 536, Q = 8, M = 1 024, minibatches
+of 8 192 rows, rv_scaling 8, 4 MC samples = one GPU's share) is optimised for 200 Adam steps twice -- guarded float32 (explicit -> whitened as
+Kuu's condition number grows) and float64 -- on IDENTICAL minibatches and IDENTICAL injected noise, and compared step by step."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _SharedNoise(object):
+    """The rand_gen seam (random_gen.py:26-28) fed from ONE float64 Philox stream per run: both precisions see the same draws."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator(device='cuda').manual_seed(seed)
+
+    def sample_normal(self, loc=0, scale=1, shape=None, dtype=None, out=None, ctx=None, F=None):
+        from mxfusion_amd.common import config
+        return torch.randn(tuple(shape), dtype=torch.float64, device='cuda', generator=self.gen).to(config.torch_dtype(dtype))
+
+
+def _train(dtype, X, Y, Z, B, S, steps, lr):
+    from tests.test_gpu_config4 import build_uncertain_input_svgp
+    from mxfusion_amd.inference.batch_loop import _Adam
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    N, Q = X.shape
+    M = Z.shape[0]
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    m, q, infr, loop, kernel = build_uncertain_input_svgp(N, Q, M, B, S, dtype, torch.as_tensor(Z, dtype=td).cuda())
+    post = m.Y.factor._extra_graphs[0]
+    infr.params[post.qU_mean] = torch.zeros(M, 1, dtype=td).cuda()
+    infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td).cuda()
+    infr.params[post.qU_cov_diag] = torch.ones(M, dtype=td).cuda()
+    q[m.X].factor._rand_gen = _SharedNoise(77)
+    Xd, Yd = torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()
+    ex = infr.create_executor()
+    opt = _Adam(infr.params, lr)
+    perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+    nb = N // B
+    losses = []
+    for it in range(steps):
+        sel = perm[(it % nb) * B:(it % nb + 1) * B]
+        losses.append(loop.step(ex, [Xd[sel], Yd[sel]], infr.params).detach().double())
+        opt.step(batch_size=B)
+    torch.cuda.synchronize()
+    g = m.Y.factor.svgp_log_pdf._f32_guard()
+    g.poll(torch.device('cuda', torch.cuda.current_device()))
+    out = dict(loss=torch.stack(losses).cpu().numpy(), ls=infr.params[kernel.lengthscale].double().cpu().numpy(),
+               var=float(infr.params[kernel.variance]), noise=float(infr.params[m.noise_var]), qx=float(infr.params[q.qx_var]),
+               mu=infr.params[post.qU_mean].double().cpu().numpy(), info=int(m.Y.factor.svgp_log_pdf._last_info.abs().sum()),
+               tier=Float32Guard.NAMES[g.tier], cond=g.cond_max, switches=g.switches)
+    del infr, ex, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_200_adam_steps_in_guarded_float32_track_float64():
+    import bench
+    N, Q, M, B, S, steps, lr = 65536, 8, 1024, 8192, 4, 200, 1e-2
+    X, Y, Z = bench.synth(N, Q, M)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r32 = _train('float32', X, Y, Z, B, S, steps, lr)
+        r64 = _train('float64', X, Y, Z, B, S, steps, lr)
+    assert r32['info'] == 0 and r64['info'] == 0
+    rel = np.abs(r32['loss'] - r64['loss']) / np.abs(r64['loss'])
+    print('\nloss f64 first / last: %.6e / %.6e;  max rel diff of the trajectory %.2e (at step %d), last step %.2e'
+          % (r64['loss'][0], r64['loss'][-1], rel.max(), int(rel.argmax()), rel[-1]))
+    print('float32 run ended on: %s (cond max %.2e, %d switches)' % (r32['tier'], r32['cond'], r32['switches']))
+    prel = {k: float(np.abs(np.asarray(r32[k]) - np.asarray(r64[k])).max() / np.abs(np.asarray(r64[k])).max()) for k in ('ls', 'var', 'noise', 'qx', 'mu')}
+    print('learned parameters, relative difference:', {k: '%.1e' % v for k, v in prel.items()}, ' length-scales f64:', np.round(r64['ls'], 4))
+    # the optimiser moved: the loss fell by a large factor and the length-scales left their initial value
+    assert r64['loss'][-1] < 0.5 * r64['loss'][0] and np.abs(r64['ls'] - 1.0).max() > 0.2
+    # loss trajectory <= 1e-4 relative, learned length-scale / variance / noise <= 1e-3
+    assert rel.max() <= 1e-4, rel.max()
+    assert max(prel['ls'], prel['var'], prel['noise'], prel['qx']) <= 1e-3, prel
+    assert prel['mu'] <= 5e-3, prel
