@@ -204,10 +204,18 @@ static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
 
 static inline bool mxf_side_init(mxf_ctx* h) {
     if (h->side) return true;
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
     // (a CU-masked side2 via hipExtStreamCreateWithCUMask was measured: 83 -> 114 ms per step; stream priorities -- bulk stream lowest,
-    //  Su-chain stream highest -- were measured too: no change at 1, 4 or 32 samples; plain streams kept)
+    //  Su-chain stream highest -- were measured in r01 and again in r05 (probe knob MXF_STREAM_PRIO=1); plain streams kept)
+    static const int prio_env = (int)MXF_KNOB("MXF_STREAM_PRIO", 0);
+    int lo = 0, hi = 0;
+    if (prio_env && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }      // lo = least urgent (numerically largest)
+    if (prio_env) {
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) { h->side = nullptr; return false; }
+        if (hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, hi) != hipSuccess) { h->side2 = nullptr; return false; }
+    } else {
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
     if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) { h->side2 = nullptr; return false; }
+    }
     if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess ||

@@ -991,8 +991,11 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         if (g.pair) {
             // the tm roles of a strip pair = tm consecutive items of one XCD's run, taken in the same round by tm different workgroups: they
             // start together (bounded rendezvous, a pacing hint) and then stay in step by construction -- every role does tm + 1 units
+            // (r05 measurement: the pairing alone takes the fabric fetch from 21.5 to 13.5 GB -- with or without the rendezvous -- and the
+            //  product is 0.1 ms faster without it: 8.40 vs 8.50 ms.  Off by default; MXF_SPLIT_PAIR_SYNC=1 in probe builds.)
+            static const int pair_sync_env = (int)MXF_KNOB("MXF_SPLIT_PAIR_SYNC", 0);
             const int64_t q = g.nwg / 8, per_xcd = grid / 8;
-            if (sync_env && g.nwg % 8 == 0 && q % tm == 0 && per_xcd >= tm && per_xcd % tm == 0) {
+            if (sync_env && pair_sync_env && g.nwg % 8 == 0 && q % tm == 0 && per_xcd >= tm && per_xcd % tm == 0) {
                 g.sync = mxf_gsync(h, (unsigned)(g.nwg / tm));
                 if (g.sync) { g.sync_n = (int)tm; g.sync_period = 0; g.sync_slots = 0; }
             }

@@ -30,3 +30,15 @@ def _fresh_float32_guard():
     except Exception:       # noqa: BLE001 -- CPU-only runs, library absent: nothing to reset
         pass
     yield
+
+
+@pytest.fixture
+def float32_forms_on_small_problems():
+    """Since r05 a float32 SVGP call below SVGPRegressionLogPdf.SMALL_F64_ELEMS covariances is evaluated in float64 inside.  The tests of the
+    float32 forms THEMSELVES (explicit / whitened tiers, the guard's moves, the padded shapes) use small shapes to stay fast: they switch
+    that rule off and exercise the forms they were written for."""
+    from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
+    old = SVGPRegressionLogPdf.SMALL_F64_ELEMS
+    SVGPRegressionLogPdf.SMALL_F64_ELEMS = 0
+    yield
+    SVGPRegressionLogPdf.SMALL_F64_ELEMS = old

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('float32_forms_on_small_problems')]
 
 from oracle import gp_oracle as O  # noqa: E402
 
