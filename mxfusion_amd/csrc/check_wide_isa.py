@@ -28,8 +28,23 @@ def kernel_starts(lines):
 
 def check(lines, start):
     errors, pending, n_loads, n_waits = [], [], 0, 0
+    skipping = False
     for ln in lines[start + 1:]:
         s = ln.strip()
+        # the fused reverse pass (wide_body<..., FUSE>) is ordinary compiler-tracked code with control flow of its own, between two markers: no
+        # inline-asm load may be in flight when it begins, and the linear scan resumes behind it
+        if 'mxf_fz_epilogue_begin' in s:
+            if any(p for p in pending):
+                errors.append('an inline-asm load is still in flight at the start of the fused epilogue')
+            skipping, pending = True, []
+            continue
+        if 'mxf_fz_epilogue_end' in s:
+            skipping = False
+            continue
+        if skipping:
+            if s.split(';')[0].strip().startswith('s_endpgm'):
+                break
+            continue
         if not s or s.startswith(';') or s.startswith('.'):
             continue
         s = s.split(';')[0].strip()

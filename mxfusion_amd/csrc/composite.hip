@@ -1093,7 +1093,23 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     MXF_T0(h, MXF_T_TGEMM, st);
-    if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
+    // r05: the reverse pass as the EPILOGUE of the T product (gemm_split.hip wide_body<..., FUSE>): T is never written
+    const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 &&
+                          mxf_svgp_bwd_fuse_ok(kind, dtype, M, SB, B, Q, P) != 0;
+    mxf_fuse_args fza;
+    if (fuse_bwd) {
+        rc = mxf_svgp_bwd_fuse_prepare(h, M, SB, B, Q, (const float*)Z, (const float*)X, (const float*)ls, ard, (const float*)var,
+                                       (const float*)(Text + M * SB), (const float*)Y, sY, (const float*)wT, (const float*)noise, a1, (float*)dX, (float*)dY,
+                                       (sY == 0 && SS > 1) ? 1 : 0, scal, (const unsigned*)(info2 + 2), &fza, st);
+        if (rc) return rc;
+    }
+    if (fuse_bwd && whiten)
+        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plVt, pVt, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
+                                     sigf, 1, (const unsigned*)(info2 + 2), nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, &fza);
+    else if (fuse_bwd)
+        rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
+                                     split_var, 1, (const unsigned*)(info2 + 2), nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, &fza);
+    else if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plVt, pVt, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
     else if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
@@ -1197,6 +1213,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // (dY, dZ, dls, dvar, dX, R were cleared on the second side stream at the start of the call: early_clear)
         // one pass over T: q_n, |e_n|^2, dY, R = Kuf E, and the Kuf-side reverse mode (dX, dZ, dls, dvar) without materialising dKuf
         MXF_T0(h, MXF_T_BWD, st);
+        if (fuse_bwd) rc = mxf_svgp_bwd_fuse_finish(h, M, Q, ard, (const float*)ls, (const float*)var, &fza, (float*)dZ, (float*)dls, (float*)dvar, (float*)R, st);
+        else
         rc = mxf_svgp_bwd_fused_internal(h, kind, dtype, M, SB, B, Q, P, Z, X, ls, ard, var, Text, het_stream ? (const T*)hys : Y, sY, wT,
                                          het_stream ? (const T*)hnz : noise, a1, dZ, dX, dls, dvar,
                                          dY, dY_shared, R, scal, st, t_blocked,

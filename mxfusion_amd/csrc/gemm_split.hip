@@ -25,6 +25,7 @@
 #include "common.h"
 #include "internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -156,6 +157,7 @@ struct SplitArgs {
     unsigned short* Ct; int64_t pCt;
     const float* avec; float* Upart;
     int cp_nt;                           // bit 0: the planes, bit 1: the transposed planes are stored non-temporally
+    mxf_fuse_args fz;                    // FUSE instantiation: the SVGP reverse pass in the epilogue (internal.h)
 };
 
 __device__ __forceinline__ int lds_unit(int row, int kh) { return row * 2 + (kh ^ ((row >> 3) & 1)); }
@@ -409,8 +411,19 @@ __device__ __forceinline__ u32x4 gload16_o1024(unsigned voff, const void* sbase)
 // BFI (probe builds only, MXF_SPLIT_BF16MFMA=1): the SAME kernel with v_mfma_f32_32x32x16_bf16 on the same bits -- the numbers mean nothing,
 // the time does: it separates the operand FORMAT (11-bit f16 mantissas vs 8-bit bf16 ones toggling the multiplier array; the guide's MFMA
 // microbenchmark gives 2178 vs 2382 TF) from the schedule when this kernel is compared with the guide's bf16 GEMM template.
-template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false, bool CPL = false, bool BFI = false>
+// FUSE (r05): the product is the T = H0 Kuf (or Hh V) of the SVGP training call and its epilogue IS the reverse pass of that call (see
+// mxf_fuse_args, internal.h): nothing of C is written.  Per 32 x 32 accumulator fragment (rows m on lanes, 16 columns n per lane):
+//   dots   x_n . z_m in the SAME accumulator layout, four v_mfma_f32_32x32x2_f32 (true float32: they feed r2 of near pairs);
+//   k = 2^(esc - r2), u = T + w_m e_n, W = u k  (the RBF weight up to -(c1 variance) 2^-esc, applied when the sums are flushed);
+//   row side  [B | S]_m += W [X | 1]: W's accumulator quads, converted to f16 hi + lo and paired by v_permlane32_swap, ARE the A operand
+//             (k = n) of v_mfma_f32_32x32x16_f16; the B operand [x_n | 1] (hi / lo) comes from an LDS table built per item;
+//   col side  [D | C]_n += W^T [Z | 1]: the same f16 pairs go through a wave-private LDS tile [m][n] and come back TRANSPOSED through
+//             ds_read_b64_tr_b16 (lane n, 8 consecutive m) as the A operand (k = m); B = [z_m | 1] from an LDS table built per row tile.
+// Row sums accumulate in LDS across all items of the workgroup (a persistent workgroup keeps its row tile) and leave as float64 atomics at
+// the end; column sums leave per item as float32 atomics into dX (two row halves x M / 256 row tiles per element).
+template <int XT, int NH, bool PP, bool BLO = true, bool LSKIP = false, bool CPL = false, bool BFI = false, bool FUSE = false>
 __device__ __forceinline__ void wide_body(const SplitArgs& g) {
+    static_assert(!FUSE || (XT == 4 && NH == 2 && !PP && BLO && !LSKIP && !CPL && !BFI), "the fused reverse pass lives in the eight-wave 256 x 256 product");
     static_assert(!PP || NH == 2, "ping-pong needs the two row halves");
     static_assert(!LSKIP || (!PP && BLO), "the idle-wave loop mirrors the plain pipelined loop");
     constexpr int WBMt = 32 * XT * NH;             // A rows per tile
@@ -421,6 +434,58 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
     int patience = 2;
     float cmax = 0.f;                              // max |C| over this thread's outputs (g.maxout)
+    // ---- FUSE: tables and constants of the fused reverse pass -------------------------------------------------------------------------
+    // fz_xb / fz_zb [plane][block of 16 k][j = 16 output columns][16 k] halves: B operands of the two accumulating products ([x | 1] of the
+    // item's 256 columns, [z | 1] of the row tile's 256 rows; j = 8 is the ones column, j > 8 zero); fz_col [|x_n|^2 - esc | e_n]; fz_row
+    // [256 rows][12]: 0..7 B_mq, 8 S_m, 9 R_m in the pass's units
+    constexpr int FZN = FUSE ? 2 * 16 * 16 * 16 : 8;
+    __shared__ __attribute__((aligned(16))) unsigned short fz_xb[FZN], fz_zb[FZN];
+    __shared__ __attribute__((aligned(16))) float fz_col[FUSE ? 2 * 256 : 4];
+    // float32 copies for the dot products and the flushes (LDS latency instead of a global round trip per fragment: the first form of this
+    // epilogue fetched them from global memory fragment by fragment and spent 97 us per item, mostly waiting): [z (8) | |z|^2 | w | - | -] per row
+    // of the row tile, [x (8)] per column of the item
+    __shared__ __attribute__((aligned(16))) float fz_zf[FUSE ? 256 * 12 : 4], fz_xf[FUSE ? 256 * 8 : 4];
+    __shared__ __attribute__((aligned(16))) float fz_row[FUSE ? 256 * 12 : 4];
+    float fz_escf = 0.f, fz_unsc = 1.f, fz_fl = 1.f, fz_var = 1.f, fz_ilj = 0.f, fz_dl3 = 0.f;
+    int64_t fz_m0 = -1;
+    constexpr float FZ_CS = 0.84932180028801904272f;       // the coordinates carry sqrt(log2(e) / 2): k = 2^-r2 (bwd_prescale_kernel)
+    if constexpr (FUSE) {
+        const mxf_fuse_args& z = g.fz;
+        fz_var = z.var[0];
+        const float c1 = (float)z.a1 / z.noise[0];
+        // |u k| <= bound: |T| <= max(variance, sqrt(variance)) M max |A operand| (explicit form: Gram planes hold k / variance, alpha carries
+        // the variance; whitened: V / sigma), |w e| <= max |w| max |e|.  (The separate pass took max |T| itself from the product: ~2^13 tighter;
+        // a loose bound costs absolute precision of the f16 pairs only -- dX 1.6e-6 -> 5e-6 when this bound was first tried, r03.)
+        const float vb = fmaxf(fz_var, sqrtf(fz_var));
+        const float bnd = vb * (float)g.M * __builtin_bit_cast(float, z.h0max[0]) + __builtin_bit_cast(float, z.mx[0]) * __builtin_bit_cast(float, z.mx[1]);
+        const int ex = (int)((__builtin_bit_cast(unsigned, bnd) >> 23) & 0xff);
+        int esc = (ex == 0 || ex == 0xff) ? 0 : 13 - (ex - 127);
+        esc = esc > 60 ? 60 : (esc < -60 ? -60 : esc);
+        fz_escf = (float)esc;
+        fz_unsc = __builtin_bit_cast(float, (unsigned)(127 - esc) << 23);
+        fz_fl = -c1 * fz_var * fz_unsc;
+        const int lj = lane & 31;
+        fz_ilj = (lj < z.Q) ? 1.f / z.ls[z.ard ? lj : 0] : 0.f;
+        for (int i = tid; i < FZN; i += NTH) {           // zero, and 1.0 in the hi plane's ones column
+            const unsigned short one = ((i >> 4) & 15) == 8 && i < FZN / 2 ? (unsigned short)0x3C00 : (unsigned short)0;
+            fz_xb[i] = one; fz_zb[i] = one;
+        }
+        for (int i = tid; i < 256 * 12; i += NTH) fz_row[i] = 0.f;
+        __syncthreads();
+    }
+    // rows of fz_row -> the float64 accumulators (when the workgroup's row tile changes, and at the end)
+    auto fz_flush_rows = [&](int64_t m0_) {
+        if constexpr (FUSE) {
+            __syncthreads();
+            for (int i = tid; i < 256 * 10; i += NTH) {
+                const int r = i / 10, cc = i % 10;
+                const float v = fz_row[r * 12 + cc];
+                if (v != 0.f) atomic_add(g.fz.zacc + (m0_ + r) * 16 + cc, (double)v * (double)(cc == 9 ? fz_var * fz_unsc : fz_fl));
+                fz_row[r * 12 + cc] = 0.f;
+            }
+            __syncthreads();
+        }
+    };
     // Persistent over the (tile, k split) work items: workgroup b takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so its items
     // stay on its XCD's run of tiles).  The epilogue's stores of one item drain while the next item's first loads are in flight; with one
     // item per workgroup every tile paid a dispatch + an un-overlapped pipeline fill + a store burst (~30 % of a K = 1024 tile).
@@ -692,7 +757,178 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
     const bool atomic = g.atomic != 0;
     // D = B A^T: accumulator register r of tile (x, y) is C[m0 + 32 XT wh + 32 x + (lane & 31)][n0 + 64 wq + 32 y + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)]
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if constexpr (CPL) {
+    if constexpr (FUSE) {
+        const mxf_fuse_args& z = g.fz;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        constexpr int RS = 40;                                   // row stride (halves) of the wave-private transposition tile [32 m][32 n]
+        // every wave has left the k loop: the A ring is dead until the next item's first request
+        asm volatile("; mxf_fz_epilogue_begin" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+        if (m0 != fz_m0) {                                       // (a persistent workgroup keeps its row tile: once per launch)
+            if (fz_m0 >= 0) fz_flush_rows(fz_m0);
+            fz_m0 = m0;
+            const int mm = tid >> 1, hq = tid & 1;               // row mm of the tile, coordinates 4 hq .. + 3
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(z.Zs + (m0 + mm) * 8 + 4 * hq);
+            *reinterpret_cast<f32x4*>(&fz_zf[mm * 12 + 4 * hq]) = zv;
+            if (hq == 0) { fz_zf[mm * 12 + 8] = z.Zn[m0 + mm]; fz_zf[mm * 12 + 9] = z.w[m0 + mm]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 fh = (_Float16)zv[e];
+                const _Float16 fo = (_Float16)(zv[e] - (float)fh);
+                const int ix = (((mm >> 4) * 16) + 4 * hq + e) * 16 + (mm & 15);
+                fz_zb[ix] = __builtin_bit_cast(unsigned short, fh);
+                fz_zb[FZN / 2 + ix] = __builtin_bit_cast(unsigned short, fo);
+            }
+        }
+        const int64_t smp = n0 / z.B;                            // B % 256 == 0: the item's columns lie in one sample
+        {   // the item's column tables
+            const int nn = tid >> 1, hq = tid & 1;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(z.Xs + (n0 + nn) * 8 + 4 * hq);
+            *reinterpret_cast<f32x4*>(&fz_xf[nn * 8 + 4 * hq]) = xv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 fh = (_Float16)xv[e];
+                const _Float16 fo = (_Float16)(xv[e] - (float)fh);
+                const int ix = (((nn >> 4) * 16) + 4 * hq + e) * 16 + (nn & 15);
+                fz_xb[ix] = __builtin_bit_cast(unsigned short, fh);
+                fz_xb[FZN / 2 + ix] = __builtin_bit_cast(unsigned short, fo);
+            }
+            if (hq == 0) {
+                fz_col[nn] = z.Xn[n0 + nn] - fz_escf;
+                fz_col[256 + nn] = z.Y[smp * z.sY + (n0 + nn - smp * z.B)] - z.U[n0 + nn];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+        unsigned short* const wt = reinterpret_cast<unsigned short*>(&smem[0][0][0]) + wave * (2 * 32 * RS);      // [plane][32 m][RS]
+        const int g16 = lane >> 4, p16 = lane & 15;              // transposing read: 16-lane group (n block of 16 = g16 & 1, k half = g16 >> 1)
+        float qn = 0.f;
+        // (column fragments outside, row fragments inside: ONE column-side accumulator is live across the four row fragments, the row-side
+        //  sums of a fragment leave for LDS at once -- the 128 accumulators of T leave little room: the other order spilled 209 registers)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int nf = 64 * wq + 32 * y;                     // first column of this fragment column inside the tile
+            const f32x4 xf = *reinterpret_cast<const f32x4*>(&fz_xf[(nf + li) * 8 + 4 * lk]);
+            f32x16 colacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) colacc[r] = 0.f;
+#pragma unroll
+            for (int x = 0; x < XT; ++x) {
+                const int ml = 32 * XT * wh + 32 * x;            // first row of this fragment inside the tile
+                const f32x4 zf = *reinterpret_cast<const f32x4*>(&fz_zf[(ml + li) * 12 + 4 * lk]);
+                const f32x2 zw2 = *reinterpret_cast<const f32x2*>(&fz_zf[(ml + li) * 12 + 8]);
+                const float zzm = zw2[0], wmm = zw2[1];
+                f32x16 dots;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dots[r] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dots = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[e], zf[e], dots, 0, 0, 0);      // [i = n][j = m], q = 4 lk + e
+                unsigned hi[8], lo[8];
+                float racc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 xn4 = *reinterpret_cast<const f32x4*>(&fz_col[nf + 8 * q + 4 * lk]);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(&fz_col[256 + nf + 8 * q + 4 * lk]);
+                    float wv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float r2 = fmaf(-2.f, dots[4 * q + t], zzm + xn4[t]);
+                        const float k = __builtin_amdgcn_exp2f(-r2);                     // k 2^esc
+                        const float tv = alpha * c[x][y][4 * q + t];
+                        const float u = fmaf(wmm, e4[t], tv);
+                        wv[t] = u * k;
+                        qn = fmaf(k, tv, qn);
+                        racc = fmaf(k, e4[t], racc);
+                    }
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const f32x2 v = {wv[2 * d], wv[2 * d + 1]};
+                        const f16x2 fh = __builtin_convertvector(v, f16x2);
+                        const f16x2 fo = __builtin_convertvector(v - __builtin_convertvector(fh, f32x2), f16x2);
+                        hi[2 * q + d] = __builtin_bit_cast(unsigned, fh); lo[2 * q + d] = __builtin_bit_cast(unsigned, fo);
+                    }
+                }
+                // quads (0, 1) and (2, 3): afterwards lane lk owns the EIGHT consecutive columns 16 c + 8 lk .. + 7 of k block c in
+                // {hi[4 c], .., hi[4 c + 3]} -- the A operand (k = n) of the row-side product
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi[4 * cb + d]), "+v"(hi[4 * cb + 2 + d]));
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo[4 * cb + d]), "+v"(lo[4 * cb + 2 + d]));
+                    }
+                f32x16 rowf;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rowf[r] = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const u32x4 ah = {hi[4 * cb], hi[4 * cb + 1], hi[4 * cb + 2], hi[4 * cb + 3]}, al = {lo[4 * cb], lo[4 * cb + 1], lo[4 * cb + 2], lo[4 * cb + 3]};
+                    const int bix = ((((nf >> 4) + cb) * 16) + (li & 15)) * 16 + 8 * lk;
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(&fz_xb[bix]), bl = *reinterpret_cast<const u32x4*>(&fz_xb[FZN / 2 + bix]);
+                    rowf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), rowf, 0, 0, 0);
+                    rowf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), rowf, 0, 0, 0);
+                    rowf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), rowf, 0, 0, 0);
+                    // the same eight columns of row li into the transposition tile [m = li][n = 16 cb + 8 lk ..]
+                    *reinterpret_cast<u32x4*>(wt + li * RS + 16 * cb + 8 * lk) = ah;
+                    *reinterpret_cast<u32x4*>(wt + 32 * RS + li * RS + 16 * cb + 8 * lk) = al;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // column side: k = m.  16-lane group g16 = (n block of 16, k half): lane p16 fetches the 4 halves tile[m = 8 kh + 4 rr + p16 / 4]
+                // [n = 16 nb + 4 (p16 % 4) ..] and receives tile[m = 8 kh + 4 rr + 0 .. 3][n = 16 nb + p16] (ds_read_b64_tr_b16)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {                 // k blocks of 16 rows m
+                    u32x4 th, tl;
+                    {
+                        const unsigned short* ph = wt + (16 * cc + 8 * (g16 >> 1) + (p16 >> 2)) * RS + 16 * (g16 & 1) + 4 * (p16 & 3);
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ph));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ph + 4 * RS));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ph + 32 * RS));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ph + 32 * RS + 4 * RS));
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 a0 = __builtin_bit_cast(u32x2, h0), a1 = __builtin_bit_cast(u32x2, h1), b0_ = __builtin_bit_cast(u32x2, l0), b1_ = __builtin_bit_cast(u32x2, l1);
+                        th = u32x4{a0[0], a0[1], a1[0], a1[1]}; tl = u32x4{b0_[0], b0_[1], b1_[0], b1_[1]};
+                    }
+                    const int zix = ((((ml >> 4) + cc) * 16) + (li & 15)) * 16 + 8 * lk;
+                    const u32x4 zh = *reinterpret_cast<const u32x4*>(&fz_zb[zix]), zl = *reinterpret_cast<const u32x4*>(&fz_zb[FZN / 2 + zix]);
+                    colacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, tl), __builtin_bit_cast(f16x8, zh), colacc, 0, 0, 0);
+                    colacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, th), __builtin_bit_cast(f16x8, zl), colacc, 0, 0, 0);
+                    colacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, th), __builtin_bit_cast(f16x8, zh), colacc, 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // row side of this fragment: rowf[r] = [B | S] of row ml + 8 (r >> 2) + 4 lk + (r & 3), entry j = li
+                if (li < 9) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) __hip_atomic_fetch_add(&fz_row[(ml + 8 * (r >> 2) + 4 * lk + (r & 3)) * 12 + li], rowf[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                racc += __shfl_xor(racc, 32, 64);
+                if (lk == 0) __hip_atomic_fetch_add(&fz_row[(ml + li) * 12 + 9], racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);       // keep the unrolled fragments apart: hoisting the next fragment's reads costs registers that are not there
+            }
+            // column side: colacc[r] = [D | C] of column nf + 8 (r >> 2) + 4 lk + (r & 3), entry j = li (this wave's 128 rows)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float Cn = __shfl(colacc[r], (lane & 32) | 8, 64);
+                const int nl = nf + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (li < z.Q) {
+                    const float xq = fz_xf[nl * 8 + li];
+                    const float pr = xq * Cn;
+                    fz_dl3 = fmaf(xq, pr, fz_dl3);
+                    if (z.dX) atomic_add(z.dX + (n0 + nl) * z.Q + li, (pr - colacc[r]) * (fz_ilj * (1.f / FZ_CS) * fz_fl));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            double qs = (double)(qn * (fz_var * fz_unsc));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) qs += __shfl_xor(qs, o, 64);
+            if (lane == 0) atomic_add(z.scal + 2 * smp, qs);
+        }
+        // the tables and the transposition tiles are rewritten by the next item (its first A request lands in the ring)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("; mxf_fz_epilogue_end" ::: "memory");
+    } else if constexpr (CPL) {
         // planes output: lane (li, lk) holds columns 8 q + 4 lk .. + 3 of quad q.  v_permlane32_swap trades quad q + 1 of the lanes lk = 0 for
         // quad q of the lanes lk = 1: afterwards lane lk owns EIGHT consecutive columns 8 (q + lk) .. + 7 (q even) = one 16-byte unit per
         // plane, and a store instruction covers 32 rows x 32 bytes = 1 KB contiguous of the 16-column block.
@@ -832,6 +1068,12 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
             }
     }
     }   // work items
+    if constexpr (FUSE) {
+        if (fz_m0 >= 0) fz_flush_rows(fz_m0);
+        float v = ((lane & 31) < g.fz.Q) ? fz_dl3 * fz_fl : 0.f;         // sum_n x_nq^2 C_n: lane (q = li) holds its share
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 32 && lane < g.fz.Q) atomic_add(g.fz.dls3 + lane, (double)v);
+    }
     if (g.maxout) {                                // one atomic per wave, and only if it can raise the word (non-negative floats order as their bits)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
@@ -851,6 +1093,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256lo(SplitArgs
 #ifdef MXF_PROBES
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256bf(SplitArgs g) { wide_body<4, 2, false, true, false, false, true>(g); }
 #endif
+// the T product of the SVGP training call with the reverse pass as its epilogue (r05)
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256fz(SplitArgs g) { wide_body<4, 2, false, true, false, false, false, true>(g); }
 // planes-output forms (c_blk == 2; the whitened SVGP tier's V = L^-1 Kuf)
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pl(SplitArgs g) { wide_body<4, 2, false, true, false, true>(g); }
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128pl(SplitArgs g) { wide_body<4, 1, false, true, false, true>(g); }
@@ -896,9 +1140,15 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
                             const unsigned short* B, int64_t pB, double beta, float* C, int64_t ldc, int lower_only, hipStream_t st,
                             int reserve_cus, int mode, const float* ad0, int pow0, const unsigned* maxbits, const unsigned* maxbits2, int c_blocked,
                             unsigned* maxout, unsigned short* Cplanes, int64_t pC, int a_lower, unsigned short* Ct, int64_t pCt,
-                            const float* avec, float* Upart) {
+                            const float* avec, float* Upart, const mxf_fuse_args* fuse) {
     if (M <= 0 || N <= 0) return 0;
     SplitArgs g;
+    memset(&g.fz, 0, sizeof(g.fz));
+    if (fuse) {
+        if (mode != MXF_SPLIT_F16X2 || (M % 256) != 0 || (N % WBN) != 0 || (fuse->B % 256) != 0 || Cplanes || lower_only || beta != 0.0 || K < 128)
+            MXF_FAIL(h, -2, "mxf_gemm_split: the fused reverse pass needs the f16x2 format, M %% 256 == 0, whole 256-column tiles per sample and a plain product");
+        g.fz = *fuse;
+    }
     g.c_blk = c_blocked; g.maxout = nullptr;
     g.Cp = Cplanes; g.pC = pC; g.a_lower = a_lower; g.rot_div = 0;
     g.Ct = Ct; g.pCt = pCt; g.avec = avec; g.Upart = Upart;
@@ -925,14 +1175,14 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     // (rows are 64 bytes apart) and for the small square Psi2, 16-byte pieces 4 N bytes apart for a wide row-major C -- the T shape then
     // takes 16.7 ms instead of 13.4 on the 128 x 128 kernel, blocked it takes 12.3.  (Before the kernel walked its work items persistently
     // the blocked T lost 1.9 ms on it as well.)
-    const bool wide = Cplanes != nullptr ||
+    const bool wide = Cplanes != nullptr || fuse != nullptr ||
                       (wide_env && (wide_env == 1 || lower_only || (wide_env == 3 && c_blocked)) && mode == MXF_SPLIT_F16X2 && g.use_dma && (M % 128) == 0 && (N % WBN) == 0 && (ldc % 4) == 0 &&
                        (((uintptr_t)C) % 16) == 0 && g.nprod >= 3 && (!lower_only || M == N));
     // rows per tile of the wide kernel: 256 when the shape allows, else 128 (four waves, two workgroups per CU).  MXF_SPLIT_XT: 4 = always
     // 128; 8 = 256 rows by four 512-register waves (one per SIMD); 16 (default) = 256 rows by eight waves, two row halves (two per SIMD)
     static const int xt_env = (int)MXF_KNOB("MXF_SPLIT_XT", 16);
-    const int XT = (wide && !Cplanes && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
-    const int NH = (wide && (xt_env == 16 || Cplanes) && (M % 256) == 0) ? 2 : 1;
+    const int XT = (wide && !Cplanes && !fuse && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
+    const int NH = (wide && (xt_env == 16 || Cplanes || fuse) && (M % 256) == 0) ? 2 : 1;
     const int64_t WBMh = 32 * XT * NH;
     int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
     if (lower_only && tm != tn) MXF_FAIL(h, -2, "mxf_gemm_split: lower_only needs a square output");
@@ -949,7 +1199,7 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     // sized for the four-per-CU kernel: ~216 workgroups, one per CU on 216 CUs, whichever kernel runs.
     const int64_t slots = wide ? (reserve_cus >= 128 ? (int64_t)(256 - reserve_cus) * 4 : (int64_t)(256 - reserve_cus) * (WBMh == 256 ? 1 : 2))
                                : (int64_t)(256 - reserve_cus) * (mode == MXF_SPLIT_F16X2 ? 4 : 3);
-    if (tiles < slots && g.K16 >= 16 && !Cplanes) {
+    if (tiles < slots && g.K16 >= 16 && !Cplanes && !fuse) {
         int64_t sk = slots / tiles;
         if (sk * tiles < (slots * 3) / 4) sk = (2 * slots) / tiles;
         const int64_t maxsplit = g.K16 / 8 > 0 ? g.K16 / 8 : 1;
@@ -1028,7 +1278,8 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         static const int bfi_env = (int)MXF_KNOB("MXF_SPLIT_BF16MFMA", 0);
         if (bfi_env && NH == 2 && !Cplanes && !lower_only) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256bf, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
 #endif
-        if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
+        if (fuse) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256fz, dim3((unsigned)grid), dim3(512), 0, st, g);
+        else if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (Cplanes) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128pl, dim3((unsigned)grid), dim3(256), 0, st, g);
         else if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);

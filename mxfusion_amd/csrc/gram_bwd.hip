@@ -1138,6 +1138,76 @@ bool mxf_svgp_bwd_reads_blocked(int kind, int dtype, int64_t SB, int64_t B, int 
     return mxf_svgp_bwd_is_mfma(kind, dtype, SB, B, Q, P, Text) || (dtype == MXF_F32 && Q <= 16 && P <= PMAX_ALL && SB % 16 == 0);
 }
 
+// ---- r05: the reverse pass as the epilogue of the T product (mxf_fuse_args, internal.h; gemm_split.hip wide_body<..., FUSE>) ----------------------
+// dY = -c1 e and sum_n e_n^2 per sample (the separate pass did this on its first row band)
+__global__ __launch_bounds__(256) void fuse_resid_kernel(int64_t SB, int64_t B, const float* __restrict__ U, const float* __restrict__ Y, int64_t sY,
+                                                         const float* __restrict__ noise, double a1, float* __restrict__ dY, int dY_shared,
+                                                         double* __restrict__ scal) {
+    __shared__ double red[16];
+    const int64_t smp = blockIdx.y;
+    const float c1 = (float)a1 / noise[0];
+    double es = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = smp * B + i;
+        const float e = Y[smp * sY + i] - U[n];
+        es += (double)e * (double)e;
+        if (dY) { const float gy = -c1 * e; if (dY_shared) atomic_add(dY + i, gy); else dY[n] = gy; }
+    }
+    es = block_sum<double>(es, red);
+    if (threadIdx.x == 0) atomic_add(scal + 2 * smp + 1, es);
+}
+
+int mxf_svgp_bwd_fuse_ok(int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P) {
+    static const int env = (int)MXF_KNOB("MXF_SVGP_FUSE", 0);
+    return env && kind == MXF_K_RBF && dtype == MXF_F32 && P == 1 && Q <= 8 && (M % 256) == 0 && M >= 256 && (B % 256) == 0 && (SB % B) == 0 &&
+           SB / B <= 65535 && SB < 2147483647LL - 4096;
+}
+
+int mxf_svgp_bwd_fuse_prepare(mxf_ctx* h, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
+                              const float* var, const float* U, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dX,
+                              float* dY, int dY_shared, double* scal, const unsigned* h0max, mxf_fuse_args* out, hipStream_t st) {
+    const size_t nacc = ((size_t)M * 16 + 16) * sizeof(double);
+    const size_t need = nacc + (((size_t)M + (size_t)SB) * 8 + (size_t)SB + (size_t)M) * sizeof(float);      // + scaled coordinates, |x_n|^2, |z_m|^2
+    if (need > h->bwd_acc_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) MXF_FAIL(h, -4, "svgp reverse pass: scratch must be allocated before a stream capture (run one eager step first)");
+        if (h->bwd_acc) { (void)hipDeviceSynchronize(); (void)hipFree(h->bwd_acc); h->bwd_acc = nullptr; h->bwd_acc_bytes = 0; ++h->ws_generation; }
+        if (hipMalloc((void**)&h->bwd_acc, need) != hipSuccess) { h->bwd_acc = nullptr; MXF_FAIL(h, -4, "svgp reverse pass: cannot allocate %zu bytes", need); }
+        h->bwd_acc_bytes = need;
+    }
+    MXF_HIP(h, hipMemsetAsync(h->bwd_acc, 0, nacc, st));
+    double* zacc = reinterpret_cast<double*>(h->bwd_acc);
+    float* Zs = reinterpret_cast<float*>(reinterpret_cast<char*>(h->bwd_acc) + nacc);
+    float* Xs = Zs + (size_t)M * 8;
+    float* Xn = Xs + (size_t)SB * 8;
+    float* Zn = Xn + (size_t)SB;
+    const float cs = 0.84932180028801904272f;
+    unsigned* mx = reinterpret_cast<unsigned*>(zacc + (size_t)M * 16 + 8);
+    float* centre = reinterpret_cast<float*>(zacc + (size_t)M * 16 + 9);
+    const int64_t nsamp = SB / B;
+    hipLaunchKernelGGL(bwd_centre_kernel, dim3((unsigned)Q), dim3(256), 0, st, M < 64 ? M : (int64_t)64, Q, Z, centre);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, st, Z, M, Q, ls, ard, (const float*)centre, Zs, Zn, cs,
+                       w, (const float*)nullptr, (int64_t)0, mx);
+    hipLaunchKernelGGL(bwd_prescale_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)nsamp), dim3(256), 0, st, X, B, Q, ls, ard, (const float*)centre, Xs, Xn, cs,
+                       U, Y, sY, mx + 1);
+    const int64_t gx = (B + 255) / 256 > 64 ? 64 : (B + 255) / 256;
+    hipLaunchKernelGGL(fuse_resid_kernel, dim3((unsigned)gx, (unsigned)nsamp), dim3(256), 0, st, SB, B, U, Y, sY, noise, a1, dY, dY_shared, scal);
+    MXF_LAUNCH_CHECK(h);
+    out->Zs = Zs; out->Zn = Zn; out->Xs = Xs; out->Xn = Xn; out->U = U; out->Y = Y; out->w = w; out->ls = ls; out->var = var; out->noise = noise;
+    out->dX = dX; out->zacc = zacc; out->dls3 = zacc + (size_t)M * 16; out->scal = scal; out->h0max = h0max; out->mx = mx;
+    out->B = B; out->sY = sY; out->Q = Q; out->ard = ard; out->a1 = a1;
+    return 0;
+}
+
+int mxf_svgp_bwd_fuse_finish(mxf_ctx* h, int64_t M, int Q, int ard, const float* ls, const float* var, const mxf_fuse_args* fz, float* dZ, float* dls,
+                             float* dvar, float* R, hipStream_t st) {
+    hipLaunchKernelGGL(svgp_bwd_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, Q, ard, fz->Zs, ls, (const double*)fz->zacc,
+                       (const double*)fz->dls3, dZ, dls, R, (double)0.84932180028801904272f, var, dvar);
+    MXF_LAUNCH_CHECK(h);
+    return 0;
+}
+
 int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P, const void* Z,
                                 const void* Xall, const void* ls, int ard, const void* var, const void* Text, const void* Y,
                                 int64_t sY, const void* w, const void* noise, double a1, void* dZ, void* dXall, void* dls,

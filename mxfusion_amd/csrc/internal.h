@@ -38,6 +38,27 @@ int mxf_svgp_bwd_fused_internal(mxf_ctx* h, int kind, int dtype, int64_t M, int6
 //  accumulate its RBF weights as hi + lo f16; nullptr: float32 accumulation.  tmax: bit pattern of max |T| if the GEMM reported it
 //  (word != 0): the tight bound)
 
+// r05: the SVGP reverse pass FUSED into the epilogue of the T product (gemm_split.hip wide_body<..., FUSE>): the 256 x 256 accumulator tile IS T --
+// the pass's weights W = -(c1 variance) (T + w e) k, its row sums [B | S] = W [X | 1], R and its column sums [D | C] = W^T [Z | 1] are formed
+// from registers, T is never written (8.6 GB less written and 8.6 GB less read per 32-sample step, one bulk kernel less).  RBF, Q <= 8, one
+// output column, M % 256 == 0, B % 256 == 0.  Filled by mxf_svgp_bwd_fuse_prepare (gram_bwd.hip), consumed by mxf_gemm_split_internal.
+struct mxf_fuse_args {
+    const float* Zs; const float* Zn;    // scaled, centred inducing inputs (8 per row) and their squared norms
+    const float* Xs; const float* Xn;    // the same for the data columns
+    const float* U; const float* Y; const float* w; const float* ls; const float* var; const float* noise;
+    float* dX; double* zacc; double* dls3; double* scal;
+    const unsigned* h0max; const unsigned* mx;      // bit patterns: max |A operand| of the product, {max |w|, max |y - U|}
+    int64_t B, sY;
+    int Q, ard;
+    double a1;
+};
+int mxf_svgp_bwd_fuse_ok(int kind, int dtype, int64_t M, int64_t SB, int64_t B, int Q, int P);
+int mxf_svgp_bwd_fuse_prepare(mxf_ctx* h, int64_t M, int64_t SB, int64_t B, int Q, const float* Z, const float* X, const float* ls, int ard,
+                              const float* var, const float* U, const float* Y, int64_t sY, const float* w, const float* noise, double a1, float* dX,
+                              float* dY, int dY_shared, double* scal, const unsigned* h0max, mxf_fuse_args* out, hipStream_t st);
+int mxf_svgp_bwd_fuse_finish(mxf_ctx* h, int64_t M, int Q, int ard, const float* ls, const float* var, const mxf_fuse_args* fz, float* dZ, float* dls,
+                             float* dvar, float* R, hipStream_t st);
+
 // f32-accurate GEMM on the bf16 matrix pipe (three-term bf16 splitting, gemm_split.hip)
 size_t mxf_split_plane_elems(int64_t R, int64_t K);    // elements (bf16) of ONE plane of an (R x K) operand
 // operand formats of the split GEMM (gemm_split.hip): three bf16 terms / two scaled f16 terms
@@ -51,7 +72,8 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
                             int reserve_cus = 0, int mode = MXF_SPLIT_BF16X3, const float* ad0 = nullptr, int pow0 = 0,
                             const unsigned* maxbits = nullptr, const unsigned* maxbits2 = nullptr, int c_blocked = 0,
                             unsigned* maxout = nullptr, unsigned short* Cplanes = nullptr, int64_t pC = 0, int a_lower = 0,
-                            unsigned short* Ct = nullptr, int64_t pCt = 0, const float* avec = nullptr, float* Upart = nullptr);
+                            unsigned short* Ct = nullptr, int64_t pCt = 0, const float* avec = nullptr, float* Upart = nullptr,
+                            const mxf_fuse_args* fuse = nullptr);
 // (Ct: the planes output ALSO in the transposed orientation, ((m / 16) * N + n) * 16 + m % 16, plane stride pCt; avec (M floats) / Upart
 //  ((M / 128) x N floats): per 128-row band the sums of avec[m] * (hi + lo)(m, n), in the planes' units -- deterministic, summed by the caller)
 // (Cplanes != nullptr: the product is written as two f16 planes (hi + lo of alpha * A B^T, plane stride pC) in the layout of an (M x K' = N)
