@@ -29,6 +29,6 @@ for w in t psi2 v; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o g -- python $R/tests/probes/split_pmc.py $w > $O/pmc_${w}_sq.log 2>&1
   python $R/profiles/pmc_summary.py gemm_f16x2 $O/gemm_${w}_pmc.json $O/pmc_${w}_fetch $O/pmc_${w}_write $O/pmc_${w}_sq > $O/gemm_${w}_pmc.txt 2>&1
 done
-for d in trace_full trace_step trace_whitened trace_s4; do cp $(find $O/$d -name "*kernel_stats.csv" | head -1) $O/${d}_kernel_stats.csv; done
+for d in trace_full trace_step trace_whitened trace_s4; do cp $(find $O/$d -name "*kernel_stats.csv" | head -1) $O/stats_${d}.csv; done
 rm -rf $O/trace_* $O/pmc_*_fetch $O/pmc_*_write $O/pmc_*_sq $O/pmc_gram_write $O/pmc_gram_fetch 2>/dev/null
 ls $O | head -80
