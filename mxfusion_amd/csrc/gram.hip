@@ -623,8 +623,20 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
 // covariance.  At length-scale 0.2 on [-2, 2] (a deep GP's hidden layer) the pre-scaled form's Gram error, amplified by |T| ~ sqrt(cond) in
 // q_n = k_n . T_n, was 2/3 of the whitened tier's ELBO error (3.9e-5 -> 4e-6 relative; tests/test_gpu_f32_guard.py two-layer case).
 // One more packed multiply per two coordinates.
+// MXF_PLANES_WAVES (compile time, r05 experiment): at most this many waves of the planes pass per SIMD.  Its one-wave workgroups otherwise take
+// every wave slot (and with ~64 registers each the whole register file) of every CU, and the float64 workgroups of the Kuu chain that runs
+// next to it (4 waves of ~128 registers, tens of KB of LDS) wait for a CU to drain by chance -- the r05 timelines show a 60 us GEMM of
+// that chain taking 1.26 ms next to this pass.
+#ifndef MXF_PLANES_WAVES
+#define MXF_PLANES_WAVES 0
+#endif
+#if MXF_PLANES_WAVES > 0
+#define MXF_PLANES_OCC __attribute__((amdgpu_waves_per_eu(MXF_PLANES_WAVES, MXF_PLANES_WAVES)))
+#else
+#define MXF_PLANES_OCC
+#endif
 template <int QT, int KIND, int PT, bool ACC = false>
-__global__ __launch_bounds__(64) void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
+__global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                               const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
                                                               int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
                                                               int64_t ldU, const float* __restrict__ ls = nullptr, int ard = 0, int Q = 0,

@@ -57,6 +57,40 @@ def flat_gradient(loop_cls, eps, S, weight_note):
     return infr.params.flat.grad.detach().clone(), float(loss.detach()), loop
 
 
+def rows_gradients():
+    """(flat gradient, loss) of one MAP step on the SVGP notebook model through DistributedBatchInferenceLoop(shard='rows') and through the
+    single-process BatchInferenceLoop on all rows."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import SVGPRegression
+    from mxfusion_amd.inference import MAP, GradBasedInference, BatchInferenceLoop, DistributedBatchInferenceLoop
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64).cuda()
+    out = []
+    for dist_loop in (True, False):
+        rng = np.random.RandomState(12)
+        N, Q, M = 128, 3, 16
+        X = rng.uniform(-2, 2, (N, Q)); Y = np.sin(X[:, :1]) + 0.1 * rng.randn(N, 1)
+        m = Model()
+        m.N = Variable()
+        m.X = Variable(shape=(m.N, Q))
+        m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=t([0.05]))
+        kernel = RBF(input_dim=Q, ARD=True, variance=t([1.2]), lengthscale=t(rng.rand(Q) + 0.8), dtype='float64')
+        m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, num_inducing=M, shape=(m.N, 1), dtype='float64')
+        m.Y.factor.svgp_log_pdf.jitter = 1e-6
+        loop = DistributedBatchInferenceLoop(shard='rows', row_variables=[m.Y]) if dist_loop else BatchInferenceLoop()
+        infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=loop, dtype='float64')
+        infr.initialize(X=(N, Q), Y=(N, 1))
+        gp = m.Y.factor
+        post = gp._extra_graphs[0]
+        infr.params[gp.inducing_inputs] = t(rng.uniform(-2, 2, (M, Q)))
+        infr.params[post.qU_mean], infr.params[post.qU_cov_W], infr.params[post.qU_cov_diag] = t(0.3 * rng.randn(M, 1)), t(0.1 * rng.randn(M, M)), t(rng.rand(M) + 0.3)
+        ex = infr.create_executor()
+        loss = loop.step(ex, [t(X), t(Y)], infr.params)
+        out += [infr.params.flat.grad.detach().clone(), float(loss.detach())]
+    return out
+
+
 def main():
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
     torch.cuda.set_device(local)
@@ -71,9 +105,13 @@ def main():
     scale = float(g_all.abs().max())
     err = float((g_dist - g_all).abs().max()) / scale
     assert err < 1e-10, ('torch.distributed nccl exchange', rank, err)
-    lt = torch.tensor([loss_loc], dtype=torch.float64, device='cuda')
-    dist.all_reduce(lt)
-    assert abs(float(lt) - loss_all) < 1e-10 * abs(loss_all), (float(lt), loss_all)
+    # (r05: the loop reduces the loss over the ranks itself -- SURVEY 8(e) "flat gradient + scalar loss": every rank holds the job's objective)
+    assert abs(loss_loc - loss_all) < 1e-10 * abs(loss_all), (loss_loc, loss_all)
+    # rows sharded instead of samples (models without a sample axis): the SVGP notebook model, MAP on observed inputs -- every rank takes
+    # half of the rows, the KL term carries weight 1 / 2, gradient and loss are SUMMED
+    g_rows, loss_rows, g_ref, loss_ref = rows_gradients()
+    err_rows = float((g_rows - g_ref).abs().max()) / float(g_ref.abs().max())
+    assert err_rows < 1e-10 and abs(loss_rows - loss_ref) < 1e-10 * abs(loss_ref), ('row-sharded exchange', rank, err_rows, loss_rows, loss_ref)
     # the same sum through the C ABI: local gradient with weight 1 / world (single-process loop on the shard), mxf_allreduce_sum
     g_loc, _, _ = flat_gradient(BatchInferenceLoop, eps[lo:hi], S // world, 'this rank\'s samples, not exchanged')
     g_loc = g_loc / world
