@@ -40,42 +40,10 @@ class _Adam(object):
         self.params.zero_grad()
 
 
-class BatchInferenceLoop(GradLoop):
-    """use_graph=True: after two eager warm-up steps (scratch growth, lazy initialisation) the forward + reverse pass of one step
-    (~280 kernel launches on three streams) is captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; the gradient
-    exchange and the Adam kernel stay outside the graph.  The data tensors passed to step() must then be the same objects every
-    step (their contents may change)."""
-
-    def __init__(self, use_graph=False):
-        self.use_graph = use_graph
-        self._gstate = None
-
-    def _make_trainer(self, param_dict, learning_rate, optimizer):
-        """gluon.Trainer seam (batch_loop.py:29-44): the fused HIP optimiser over the flat buffer; CPU tests of the loop swap it."""
-        return _Adam(param_dict, learning_rate, optimizer)
-
-    def run(self, infr_executor, data, param_dict, ctx, optimizer='adam', learning_rate=1e-3, max_iter=1000, n_prints=10, verbose=False):
-        trainer = self._make_trainer(param_dict, learning_rate, optimizer)
-        iter_step = max(max_iter // n_prints, 1)
-        for i in range(max_iter):
-            loss = self.step(infr_executor, data, param_dict)
-            if verbose:
-                print('\rIteration {} loss: {}\t\t\t\t'.format(i + 1, float(loss.detach())), end='')
-                if ((i + 1) % iter_step == 0 and i > 0) or i == max_iter - 1:
-                    print()
-            trainer.step(batch_size=1)
-        self._trainer = trainer
-        with torch.no_grad():                      # batch_loop.py:61: one extra forward, discarded
-            infr_executor(*self._local(data))
-
-    def step(self, infr_executor, data, param_dict):
-        """record -> forward -> backward (batch_loop.py:52-54) + the gradient exchange hook; returns the loss."""
-        if getattr(self, 'use_graph', False) and param_dict.flat.is_cuda:
-            return self._graph_step(infr_executor, data, param_dict)
-        loss, loss_for_gradient = infr_executor(*data)
-        loss_for_gradient.backward()
-        self._exchange(param_dict)
-        return loss
+class _GraphStepMixin(object):
+    """Replay of one step's forward + reverse pass as a hipGraph (torch.cuda.CUDAGraph): shared by the batch loop and (r05) the minibatch loop,
+    whose small steps -- the reference's svgp_regression notebook runs minibatches of 10 rows with 20 inducing points -- are paced by the host's
+    ~280 launches per step (1.03 ms eager against 0.42 ms replayed, tests/probes/small_step.py)."""
 
     def _graph_step(self, infr_executor, data, param_dict):
         from .. import _lib
@@ -125,6 +93,44 @@ class BatchInferenceLoop(GradLoop):
         param_dict.flat.grad = st['grad']
         self._exchange(param_dict)
         return st['loss']
+
+
+class BatchInferenceLoop(GradLoop, _GraphStepMixin):
+    """use_graph=True: after two eager warm-up steps (scratch growth, lazy initialisation) the forward + reverse pass of one step
+    (~280 kernel launches on three streams) is captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed; the gradient
+    exchange and the Adam kernel stay outside the graph.  The data tensors passed to step() must then be the same objects every
+    step (their contents may change)."""
+
+    def __init__(self, use_graph=False):
+        self.use_graph = use_graph
+        self._gstate = None
+
+    def _make_trainer(self, param_dict, learning_rate, optimizer):
+        """gluon.Trainer seam (batch_loop.py:29-44): the fused HIP optimiser over the flat buffer; CPU tests of the loop swap it."""
+        return _Adam(param_dict, learning_rate, optimizer)
+
+    def run(self, infr_executor, data, param_dict, ctx, optimizer='adam', learning_rate=1e-3, max_iter=1000, n_prints=10, verbose=False):
+        trainer = self._make_trainer(param_dict, learning_rate, optimizer)
+        iter_step = max(max_iter // n_prints, 1)
+        for i in range(max_iter):
+            loss = self.step(infr_executor, data, param_dict)
+            if verbose:
+                print('\rIteration {} loss: {}\t\t\t\t'.format(i + 1, float(loss.detach())), end='')
+                if ((i + 1) % iter_step == 0 and i > 0) or i == max_iter - 1:
+                    print()
+            trainer.step(batch_size=1)
+        self._trainer = trainer
+        with torch.no_grad():                      # batch_loop.py:61: one extra forward, discarded
+            infr_executor(*self._local(data))
+
+    def step(self, infr_executor, data, param_dict):
+        """record -> forward -> backward (batch_loop.py:52-54) + the gradient exchange hook; returns the loss."""
+        if getattr(self, 'use_graph', False) and param_dict.flat.is_cuda:
+            return self._graph_step(infr_executor, data, param_dict)
+        loss, loss_for_gradient = infr_executor(*data)
+        loss_for_gradient.backward()
+        self._exchange(param_dict)
+        return loss
 
     def _exchange(self, param_dict):
         pass
