@@ -894,12 +894,17 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // whitened tier: only the Kfu planes (operand (n, k = m) of V = L^-1 Kuf); they need nothing from the core, so they are written
         // first; V, its transposition (+ U = a^T V) and Phi = V V^T follow on this stream once L^-1 exists (below, after the Kuu chain
         // has been queued)
+        // (r05 probe knob MXF_SVGP_WH_DEFER = 1 / 2: the pass held back until potrf(Kuu) / trtri(Kuu) has finished -- in this form the Kuu chain is a
+        //  serial prefix of everything, and next to the planes pass its float64 workgroups wait for CUs: a 60 us GEMM inside potrf took 1.26 ms)
+        static const int wh_defer = (int)MXF_KNOB("MXF_SVGP_WH_DEFER", 0);
+        if (!wh_defer) {
         MXF_T0(h, MXF_T_PLANES_A, sd_);
         rc = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
                                       (int64_t)pl_big, gscr1, sd_, split_mode);
         if (rc) return rc;
         MXF_T1(h, MXF_T_PLANES_A, sd_);
         MXF_STAGE(h, "Kfu planes (sd)", sd_);
+        }
     } else if (use_split) {
         // float32 training step: the Grams are written directly as split planes (two scaled f16 terms = 4 bytes per element, never as f32):
         // Kuf planes (operand (m, k = n)) feed Psi2 and come first so that Psi2 (MFMA bound) starts early; the Kfu planes (operand
@@ -968,9 +973,21 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
     MXF_STAGE(h, "potrf Kuu", st);
+    static const int wh_defer2 = (int)MXF_KNOB("MXF_SVGP_WH_DEFER", 0);
+    auto deferred_planes = [&]() -> int {        // (probe knob, see above)
+        MXF_HIP(h, hipEventRecord(h->ev_join2, st));
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join2, 0));
+        MXF_T0(h, MXF_T_PLANES_A, sd_);
+        int r_ = mxf_gram_planes_internal(h, kind, SB, M, Q, (const float*)X, (const float*)Z, (const float*)ls, ard, (const float*)var, plKfu,
+                                          (int64_t)pl_big, gscr1, sd_, split_mode);
+        MXF_T1(h, MXF_T_PLANES_A, sd_);
+        return r_;
+    };
+    if (whiten && wh_defer2 == 1) { rc = deferred_planes(); if (rc) return rc; }
     rc = mxf_trtri_internal(h, MXF_F64, 1, M, Lm, M, MM, Linv, M, MM, st);
     if (rc) return rc;
     MXF_STAGE(h, "trtri Kuu", st);
+    if (whiten && wh_defer2 == 2) { rc = deferred_planes(); if (rc) return rc; }
     unsigned* limax = (unsigned*)(info2 + 4);           // bit pattern of max |L^-1| (whitened tier; word cleared by svgp_init_kernel)
     if (whiten) {
         // L^-1 as f16x2 planes (the A operand of V = L^-1 Kuf); Aext is free until Hh is formed
