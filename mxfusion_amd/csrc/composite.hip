@@ -286,6 +286,8 @@ __global__ __launch_bounds__(256) void svgp_mid_kernel(int64_t SB, int64_t B, in
 
 // U[p][n] = sum_m w[m][p] * Kuf[m][n]  (the w^T row block of [H0; w^T] Kuf, kept out of the MFMA GEMM: a 1-row tile would waste
 // a whole 128-row tile).  HBM-read bound (M*SB*e bytes), 16-byte loads, lanes <-> columns.
+// gridDim.y > 1 (few columns: r05): the M rows are dealt to gridDim.y workgroups per column block, which ADD into U (zeroed by the caller) --
+// with 1 024 columns the one-workgroup-per-512-columns form is two workgroups walking 1 024 dependent rows each: 0.37 ms of a 2 ms step
 template <typename T, int PT>
 __global__ __launch_bounds__(256) void wt_kuf_kernel(int64_t M, int64_t SB, int P, const T* __restrict__ Kuf, const T* __restrict__ w,
                                                      T* __restrict__ U) {
@@ -293,6 +295,28 @@ __global__ __launch_bounds__(256) void wt_kuf_kernel(int64_t M, int64_t SB, int 
     typedef typename Vec16<T>::type V;
     const int64_t n0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (n0 >= SB) return;
+    if (gridDim.y > 1) {
+        const int64_t mc = (M + gridDim.y - 1) / gridDim.y, mb = (int64_t)blockIdx.y * mc, me = mb + mc < M ? mb + mc : M;
+        T a2[PT][VEC];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) a2[p][v] = 0;
+        for (int64_t m = mb; m < me; ++m)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const T k = (n0 + v < SB) ? Kuf[m * SB + n0 + v] : (T)0;
+#pragma unroll
+                for (int p = 0; p < PT; ++p) a2[p][v] = fma((p < P) ? w[m * P + p] : (T)0, k, a2[p][v]);
+            }
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            if (p < P)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (n0 + v < SB) atomic_add(U + (int64_t)p * SB + n0 + v, a2[p][v]);
+        return;
+    }
     T acc[PT][VEC];
 #pragma unroll
     for (int p = 0; p < PT; ++p)
@@ -1143,6 +1167,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     } else {
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));
+        if (gu.x < 128 && M >= 64) {             // few columns: split the rows as well (the kernel then adds into U)
+            int64_t ch = 512 / gu.x; if (ch > M / 16) ch = M / 16; if (ch > 64) ch = 64;
+            if (ch > 1) { gu.y = (unsigned)ch; MXF_HIP(h, hipMemsetAsync(Text + M * SB, 0, sizeof(T) * (size_t)P * SB, st)); }
+        }
         if (P == 1) hipLaunchKernelGGL((wt_kuf_kernel<T, 1>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);
         else hipLaunchKernelGGL((wt_kuf_kernel<T, 8>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);   // U = w^T Kuf
     }
