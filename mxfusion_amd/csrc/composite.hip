@@ -757,7 +757,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // float32 streaming: the two big GEMMs run on the 16-bit matrix pipe from split planes of their operands (gemm_split.hip)
     static const int split_env = MXF_KNOB("MXF_SVGP_SPLIT", 1);
     const int64_t SBh = ((sX == 0) ? (int64_t)1 : (int64_t)S) * B;
-    const bool het_stream = het_stream_env && split_env && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
+    const bool het_stream = (het_stream_env != 0) && (split_env != 0) && sizeof(T) == 4 && want_grad && nrows == B && nrows > 1 && ncols == 1 && P == 1 && !use_mat && !ysamp && Q <= 8 &&
                             (B % 16 == 0) && (M % 16 == 0) && M >= 128 && h->svgp_form == MXF_SVGP_EXPLICIT && mxf_svgp_bwd_is_mfma(kind, dtype, SBh, B, Q, P, X);
     const bool het = (nrows > 1 || ncols > 1 || use_mat || ysamp || Q > 16) && !het_stream;
     if (sX != 0 && sX != B * Q) MXF_FAIL(h, -2, "mxf_svgp_logpdf: X samples must be contiguous");
@@ -1167,10 +1167,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     } else {
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));
+#ifndef MXF_NO_WTSPLIT
         if (gu.x < 128 && M >= 64) {             // few columns: split the rows as well (the kernel then adds into U)
             int64_t ch = 512 / gu.x; if (ch > M / 16) ch = M / 16; if (ch > 64) ch = 64;
             if (ch > 1) { gu.y = (unsigned)ch; MXF_HIP(h, hipMemsetAsync(Text + M * SB, 0, sizeof(T) * (size_t)P * SB, st)); }
         }
+#endif
         if (P == 1) hipLaunchKernelGGL((wt_kuf_kernel<T, 1>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);
         else hipLaunchKernelGGL((wt_kuf_kernel<T, 8>), gu, dim3(256), 0, st, M, SB, P, (const T*)Kuf, (const T*)wT, Text + M * SB);   // U = w^T Kuf
     }

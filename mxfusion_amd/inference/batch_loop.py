@@ -51,17 +51,21 @@ class _GraphStepMixin(object):
         key = (id(infr_executor), tuple((tuple(d.shape), d.dtype) for d in data))
         st = getattr(self, '_gstate', None)
         if st is None or st.get('flat') is not param_dict.flat or st.get('key') != key:
+            if st is not None and 'graph' in st:
+                torch.cuda.synchronize()         # (never destroy a graph that may still be executing)
             st = self._gstate = {'n': 0, 'flat': param_dict.flat, 'key': key}
         from ..modules.gp_modules._fused import Float32Guard
         if 'graph' in st and st.get('f32_epoch') != Float32Guard.poll_all(dev):
             # an SVGP module's float32 guard changed its level (condition number of Kuu crossed a limit): the captured launches carry the OLD
             # form -- drop the graph, warm up once eagerly (the modules now pick the new form), capture again
-            for k in ('graph', 'loss', 'grad', 'data', 'ws_gen', 'f32_epoch'):
+            torch.cuda.synchronize()             # (the last replay may still be running: destroying an executing hipGraphExec crashed the
+            for k in ('graph', 'loss', 'grad', 'data', 'ws_gen', 'f32_epoch'):     #  HIP runtime's own thread -- r05, flaky segfault in the full suite)
                 st.pop(k, None)
             st['n'] = 1
         if 'graph' in st and st['ws_gen'] != _lib.workspace_generation(dev):
             # the library re-allocated its scratch since the capture (a larger call in between: a prediction, another module): the
             # captured kernels carry the OLD scratch addresses -- drop the graph, warm up once more eagerly, capture again
+            torch.cuda.synchronize()
             for k in ('graph', 'loss', 'grad', 'data', 'ws_gen'):
                 st.pop(k, None)
             st['n'] = 1
