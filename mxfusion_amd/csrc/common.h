@@ -211,7 +211,8 @@ static inline bool mxf_side_init(mxf_ctx* h) {
     if (prio_env && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }      // lo = least urgent (numerically largest)
     if (prio_env) {
         if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) { h->side = nullptr; return false; }
-        if (hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, hi) != hipSuccess) { h->side2 = nullptr; return false; }
+        // (1: the Su chain's stream most urgent; 2: BOTH side streams least urgent -- the caller's stream carries the Kuu chain at normal priority)
+        if (hipStreamCreateWithPriority(&h->side2, hipStreamNonBlocking, prio_env == 2 ? lo : hi) != hipSuccess) { h->side2 = nullptr; return false; }
     } else {
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return false; }
     if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) { h->side2 = nullptr; return false; }
