@@ -143,3 +143,29 @@ def test_float32_validity_guard_reports_the_condition_of_kuu():
         conds[l] = got
     lim = GradBasedInference.F32_COND_LIMIT
     assert conds[1.0] < lim and conds[3.0] > lim, conds
+
+
+def test_row_shards_add_up_through_the_c_abi():
+    """SURVEY 8(e), second axis, at the C ABI (what INTEGRATION.md tells a binder without the Python layer to do): rank r evaluates its rows with
+    scaling = c * world and gscale = 1 / world and scales the bound by 1 / world -- the shards' bounds and gradients then SUM to the one-process call
+    (float64, 1e-10); the KL term is counted once."""
+    from mxfusion_amd import ops
+    rng = np.random.RandomState(3)
+    B, M, Q, world, c = 1024, 128, 4, 4, 8.0
+    X = rng.uniform(-2, 2, (1, B, Q)); Y = np.sin(X[0, :, :1]) + 0.1 * rng.randn(B, 1)
+    Z = rng.uniform(-2, 2, (M, Q))
+    qm, qW, qd = 0.3 * rng.randn(M, 1), 0.2 * rng.randn(M, M) / np.sqrt(M), rng.rand(M) * 0.4 + 0.1
+    ls, var, noise = np.full(Q, 1.1), np.array([1.3]), np.array([0.05])
+    args = lambda rows: (_t(X[:, rows]), _t(Y[None][:, rows]), _t(Z), _t(noise), _t(qm), _t(qW), _t(qd), _t(ls), _t(var), True)
+    full = ops.svgp_logpdf('rbf', *args(slice(None)), jitter=1e-6, scaling=c, gscale=1.0, want_grad=True)
+    tot = None
+    for r in range(world):
+        rows = slice(r * B // world, (r + 1) * B // world)
+        part = ops.svgp_logpdf('rbf', *args(rows), jitter=1e-6, scaling=c * world, gscale=1.0 / world, want_grad=True)
+        contrib = {k: part[k].double() for k in ('dZ', 'dnoise', 'dmu', 'dW', 'dSdiag', 'dls', 'dvar')}
+        contrib['logL'] = part['logL'].double() / world
+        tot = contrib if tot is None else {k: tot[k] + v for k, v in contrib.items()}
+    torch.cuda.synchronize()
+    for k, v in tot.items():
+        ref = full[k].double()
+        assert float((v - ref).abs().max()) <= 1e-10 * float(ref.abs().max()), k
