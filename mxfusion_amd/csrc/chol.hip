@@ -883,7 +883,34 @@ __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A,
 }
 
 template <typename T>
-int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info) {
+int trtri_typed(mxf_ctx* h, int dtype, int S, int64_t n, const T* L, int64_t ldl, int64_t sL, T* Li, int64_t ldi, int64_t sI, hipStream_t st);
+template <typename T>
+__global__ void zero_block_kernel(T* __restrict__ P, int64_t rows, int64_t cols, int64_t ld, int64_t stride);
+
+// Row block i (rows [c0, pe)) of L^-1 from the finished leading part of the factor (r05; the merge step of trtri_typed with a first block of c0 rows
+// and a second of pe - c0):  I_ii = inv(L_ii),  X = -I_ii (L[i, :c0] I[:c0, :c0]),  the temporary (L[i, :c0] I[:c0, :c0])^T in the upper mirror block.
+// Needs L[:pe, :pe] only, i.e. it can run as soon as the outer panel ending at pe has been factored -- next to the rest of the factorisation.
+template <typename T>
+int trtri_row_block(mxf_ctx* h, int dtype, int64_t c0, int64_t pe, const T* L, int64_t ldl, T* Li, int64_t ldi, hipStream_t st) {
+    const int64_t b2 = pe - c0;
+    int rc = trtri_typed<T>(h, dtype, 1, b2, L + c0 * (ldl + 1), ldl, 0, Li + c0 * (ldi + 1), ldi, 0, st);
+    if (rc || c0 == 0) return rc;
+    static const int res = (int)MXF_KNOB("MXF_POTRF_EAGER_RES", 0);      // CUs these products leave to the factorisation's chain (probe knob)
+    rc = mxf_gemm_internal(h, dtype, 1, 1, c0, b2, c0, 1.0, Li, ldi, 0, L + c0 * ldl, ldl, 0, 0.0, Li + c0, ldi, 0, 1, 0, st, res, 1);
+    if (rc) return rc;
+    rc = mxf_gemm_internal(h, dtype, 0, 1, b2, c0, b2, -1.0, Li + c0 * (ldi + 1), ldi, 0, Li + c0, ldi, 0, 0.0, Li + c0 * ldi, ldi, 0, 1, 0, st, res, 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL((zero_block_kernel<T>), dim3((unsigned)((c0 * b2 + 255) / 256 > 1024 ? 1024 : (c0 * b2 + 255) / 256), 1), dim3(256), 0, st, Li + c0, c0, b2, ldi, (int64_t)0);
+    return 0;
+}
+
+// Ie != nullptr (float64, one matrix, the per-panel tile form with look-ahead): L^-1 is formed into Ie row block by row block on a third stream while
+// the factorisation goes on -- potrf(8192) is bound by its serial path (16 x (head update + chain + rows below)), the chip is ~40 % idle under it, and
+// trtri(8192) afterwards took 3.9 ms of a 15 ms MAP step.  *eager_done tells the caller whether Ie was filled (else: call trtri afterwards).
+template <typename T>
+int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info,
+                T* Ie = nullptr, int64_t ldie = 0, bool* eager_done = nullptr) {
+    if (eager_done) *eager_done = false;
     if (info && zero_info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
@@ -916,6 +943,12 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
     hipStream_t ax = look ? h->potrf_aux : st;
     bool pending_b = false, pending_h = false;
+    // row blocks of FOUR outer panels (2048 rows), from four row blocks on.  Measured at n = 8192 (MAP step of the exact GP, two alternating rounds,
+    // profiles/r05_potrf_eager_inverse_ab.txt): off 15.0 ms; every panel 18.1 (208 more launches, and products of a few tiles each that hold CUs the
+    // chain's tile workgroups are waiting for); every second 14.6-14.7; every fourth 14.5; two halves 15.0; leaving the products 64 / 128 CUs less changes nothing
+    static const int eager_env = MXF_KNOB("MXF_POTRF_EAGER_INV", 4);
+    const bool eager = Ie != nullptr && eager_env && sizeof(T) == 8 && S == 1 && panel_tiles && look && n % NBO == 0 &&
+                       n >= 4 * (eager_env >= 100 ? n / 8 : (int64_t)eager_env * NBO);
     static const int split_rows_g = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
     static const int rows_env_g = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
     static const int head_split_env = MXF_KNOB("MXF_POTRF_HEAD_SPLIT", 1);  // 1: the next panel's rows-below head update on the auxiliary stream
@@ -953,6 +986,18 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                     hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbr - npt, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
                 } else if (split)
                     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr - npt, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, (int)npt, 1);
+            }
+        }
+        // row block [rb0, pe) of L is final once the panel ending at pe has been factored (the rows above it in these columns are zero).  Row blocks
+        // of eager_rb outer panels (probe knob MXF_POTRF_EAGER_INV: 1 = every panel, 2 = every second, ..., 100 = two halves)
+        const int64_t rbw = eager_env >= 100 ? n / 2 : (int64_t)eager_env * NBO;
+        if (eager && (pe % rbw == 0 || pe == n)) {
+            const int64_t rb0 = (pe - 1) / rbw * rbw;
+            MXF_HIP(h, hipEventRecord(h->ev_pi, st));
+            MXF_HIP(h, hipStreamWaitEvent(h->potrf_inv, h->ev_pi, 0));
+            if constexpr (sizeof(T) == 8) {
+                int rc = trtri_row_block<T>(h, dtype, rb0, pe, A, lda, Ie, ldie, h->potrf_inv);
+                if (rc) return rc;
             }
         }
         for (int64_t j0 = c0; j0 < pe && !panel_tiles; j0 += NB) {
@@ -1008,6 +1053,11 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
             }
         }
     }
+    if (eager) {
+        MXF_HIP(h, hipEventRecord(h->ev_pj, h->potrf_inv));
+        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pj, 0));
+        if (eager_done) *eager_done = true;
+    }
     if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
     if (pending_h) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0));      // (never pending here today: the last panel has no successor; kept so that the caller's stream always joins the auxiliary one)
     if (n > 1 && zero_upper) {      // (internal callers that only ever read the lower triangle skip this pass)
@@ -1056,10 +1106,12 @@ int trsm_typed(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t n
 
 }  // namespace
 
-int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info) {
+int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info,
+                       void* Linv_eager, int64_t ldie, bool* eager_done) {
+    if (eager_done) *eager_done = false;
     if (n <= 0 || S <= 0) return 0;
     if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st, zero_upper, zero_info);
-    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper, zero_info);
+    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper, zero_info, (double*)Linv_eager, ldie, eager_done);
     MXF_FAIL(h, -2, "mxf_potrf: bad dtype %d", dtype);
 }
 

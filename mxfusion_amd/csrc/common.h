@@ -75,6 +75,8 @@ struct mxf_ctx {
     hipStream_t side2 = nullptr;
     hipStream_t potrf_aux = nullptr;                        // look-ahead stream of the blocked Cholesky (chol.hip)
     hipEvent_t ev_pa = nullptr, ev_pb = nullptr, ev_ph = nullptr;
+    hipStream_t potrf_inv = nullptr;                        // r05: the inverse of the factor, row block by row block NEXT TO the factorisation (chol.hip)
+    hipEvent_t ev_pi = nullptr, ev_pj = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
@@ -199,6 +201,8 @@ static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
     if (hipEventCreateWithFlags(&h->ev_pa, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pb, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ph, hipEventDisableTiming) != hipSuccess)
         return false;
+    if (hipStreamCreateWithFlags(&h->potrf_inv, hipStreamNonBlocking) != hipSuccess) { h->potrf_inv = nullptr; return false; }
+    if (hipEventCreateWithFlags(&h->ev_pi, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pj, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }
 

@@ -170,15 +170,17 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
     // K = k(X,X) + (noise + jitter) I   (gp_regression.py:55-60), built straight into the L buffer
     rc = mxf_gram(h, kind, dtype, S, N, N, Q, X, sX, nullptr, 0, ls, ard, sls, var, svar, noise, snoise, jitter, MXF_WRITE, L, N, NN, st);
     if (rc) return rc;
-    rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st);                        // :61
-    if (rc) return rc;
     // L^-1 Y (:66).  Large N with gradients: the reverse mode needs L^-1 anyway, and L^-1 Y as ONE product replaces N / 64 dependent
     // block steps (6.9 ms at N = 8192); small N keeps the reference's trsm.
     T* Linv = nullptr;
     const bool via_inverse = want_grad && N >= 2048;
+    if (via_inverse) Linv = cv.take<T>((size_t)S * NN);
+    // (r05) float64, one matrix: the factorisation forms L^-1 itself, row block by row block on a third stream next to its serial chain
+    bool inv_done = false;
+    rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st, true, true, (via_inverse && S == 1 && sizeof(T) == 8) ? (void*)Linv : nullptr, N, &inv_done);   // :61
+    if (rc) return rc;
     if (via_inverse) {
-        Linv = cv.take<T>((size_t)S * NN);
-        rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
+        if (!inv_done) rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
         if (rc) return rc;
         rc = mxf_gemm_internal(h, dtype, 0, 0, N, P, N, 1.0, Linv, N, NN, Y, P, sY, 0.0, LinvY, P, NP, S, 0, st);
         if (rc) return rc;

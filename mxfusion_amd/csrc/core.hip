@@ -40,6 +40,9 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ev_pa) (void)hipEventDestroy(h->ev_pa);
     if (h->ev_pb) (void)hipEventDestroy(h->ev_pb);
     if (h->ev_ph) (void)hipEventDestroy(h->ev_ph);
+    if (h->potrf_inv) (void)hipStreamDestroy(h->potrf_inv);
+    if (h->ev_pi) (void)hipEventDestroy(h->ev_pi);
+    if (h->ev_pj) (void)hipEventDestroy(h->ev_pj);
     delete h;
     return 0;
 }
