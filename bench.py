@@ -732,6 +732,8 @@ def main():
                     "uncertain-input model (configs[3]) or, 'rows', the rows of every minibatch of the observed-input MAP model (no sample axis)")
     ap.add_argument('--proxy-world', type=int, default=0, help="--minibatch --shard rows on ONE GPU: evaluate the share of one rank of a W-GPU run "
                     "(B / W rows, KL weight 1 / W, no collective)")
+    ap.add_argument('--concurrent-modules', action='store_true', help='deep GP workload: enqueue the two SVGP modules on streams and library handles of '
+                    'their own (r05 experiment, SLOWER: the first layer\'s small kernels starve under the second layer\'s persistent products)')
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--horizon', type=int, default=100, help='time steps of the PILCO rollout workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
@@ -847,6 +849,8 @@ def main():
     if args.workload == 'deepgp':      # secondary workload: BASELINE.json configs[4] (2-layer SVGP deep GP, Matern52+RBF, N=131072 D=16 M=512/layer)
         N, Q, M, Dh = (131072 if args.N == 65536 else args.N), (16 if args.Q == 8 else args.Q), (512 if args.M == 1024 else args.M), args.hidden
         X, Y, _ = synth(N, Q, M)
+        from mxfusion_amd.models.factor_graph import FactorGraph
+        FactorGraph.concurrent_modules = bool(args.concurrent_modules)  # (the layers' log-pdfs are independent given the samples of H: DESIGN.md section 8 item 5)
         infr, loop = build_deepgp(N, Q, M, Dh, S_local, args.dtype, X, Y, distributed)
         td = torch.float32 if args.dtype == 'float32' else torch.float64
         data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]

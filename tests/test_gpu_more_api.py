@@ -276,10 +276,14 @@ def test_svgp_with_add_kernel_through_the_api(latent):
         assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
 
 
-def test_two_layer_deep_gp_svi_step_matches_oracle():
+@pytest.mark.parametrize('concurrent', [False, True])
+def test_two_layer_deep_gp_svi_step_matches_oracle(concurrent, monkeypatch):
     """SURVEY 8f rank 1 (BASELINE config 5 in miniature): two chained SVGPRegression modules, first layer AddKernel(Matern52, RBF),
     hidden layer H with a mean-field q(H) (inference/meanfield.py:24-44), StochasticVariationalInference with injected noise.
-    Loss and flat gradient of the first step vs the oracle."""
+    Loss and flat gradient of the first step vs the oracle.  concurrent (r05): the two modules' log-pdfs enqueued on streams and library
+    handles of their own (FactorGraph.concurrent_modules, what bench.py --workload deepgp runs)."""
+    from mxfusion_amd.models.factor_graph import FactorGraph
+    monkeypatch.setattr(FactorGraph, 'concurrent_modules', concurrent)
     from mxfusion_amd import Model, Variable
     from mxfusion_amd.components.variables import PositiveTransformation
     from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
