@@ -144,8 +144,8 @@ def build_minibatch_rows(N, Q, M, B, dtype, Z, proxy_world=0):
         def _next_permutation(self, N_, device, generator, permutations):
             return super(DistributedMinibatchInferenceLoop, self)._next_permutation(N_, device, generator, permutations)
 
-        def _exchange(self, param_dict):
-            pass
+        def _exchange(self, param_dict, loss):
+            return loss
 
         def step(self, infr_executor, batch, param_dict, update_shape_constants=None):
             batch = [torch.tensor_split(d, proxy_world)[0] for d in batch]
@@ -166,12 +166,20 @@ def build_minibatch_rows(N, Q, M, B, dtype, Z, proxy_world=0):
 _RANK_TIMES = {}      # filled by _finish_timing: this rank's own time of the timed region, gathered over the ranks
 
 
+def _mark_loop(loop, steps):
+    """Called right before a timed region: remember the loop's collective counter so that the line can state collectives per step."""
+    _RANK_TIMES['mark'] = (loop, getattr(loop, 'collectives', 0), steps)
+
+
 def _finish_timing(t0, distributed):
     """Closing bracket of the timed region: synchronize, barrier, MAX over the ranks.  Also records every rank's own time up to its
     synchronize (before the barrier) in _RANK_TIMES['per_rank_s'] -- the spread shows load imbalance, max - own the wait in the barrier."""
     import torch.distributed as dist
     torch.cuda.synchronize()
     t_own = time.perf_counter() - t0
+    mark = _RANK_TIMES.pop('mark', None)
+    if mark is not None and distributed:
+        _RANK_TIMES['collectives_per_step'] = (getattr(mark[0], 'collectives', 0) - mark[1]) / float(mark[2])
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -192,10 +200,16 @@ def dist_report(world, steps, grad_elems, dtype):
     rank's own ms per step, and the cost of the step's one collective (all-reduce of a flat gradient of this model's size) measured on its
     own with HIP events -- 20 back-to-back all-reduces on RCCL's stream order, mean per call."""
     import torch.distributed as dist
-    rep = {"rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+    nranks = dist.get_world_size() if dist.is_initialized() else 1
+    backend = _RANK_TIMES.get('backend', 'nccl')
+    rep = {"ranks": nranks, "backend": backend if dist.is_initialized() else None, "same_device": bool(_RANK_TIMES.get('same_device', False)),
            "per_rank_ms_per_step": [round(t / steps * 1e3, 4) for t in _RANK_TIMES.get('per_rank_s', [])]}
+    if backend == 'nccl' or not dist.is_initialized():
+        rep["rccl_ranks"] = nranks
+    if 'collectives_per_step' in _RANK_TIMES:
+        rep["collectives_per_step"] = _RANK_TIMES['collectives_per_step']       # all-reduces the loop issued in the timed region / steps
     if dist.is_initialized():
-        buf = torch.zeros(int(grad_elems) + 1, dtype=dtype, device='cuda')
+        buf = torch.zeros(int(grad_elems) + 2, dtype=dtype, device='cuda')
         for _ in range(3):
             dist.all_reduce(buf)
         torch.cuda.synchronize()
@@ -232,6 +246,7 @@ def time_minibatch_steps(infr, loop, Xd, Yd, B, steps, warmup, lr, distributed):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    _mark_loop(loop, steps)
     t0 = time.perf_counter()
     for i in range(steps):
         loss = one(warmup + i)
@@ -451,6 +466,7 @@ def time_steps_multi(infr, loop, data, steps, warmup, lr, distributed):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    _mark_loop(loop, steps)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = loop.step(executor, data, infr.params)
@@ -526,6 +542,7 @@ def time_steps(infr, loop, Yd, steps, warmup, lr, distributed):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    _mark_loop(loop, steps)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = loop.step(executor, [Yd], infr.params)
@@ -732,12 +749,15 @@ def main():
                     "uncertain-input model (configs[3]) or, 'rows', the rows of every minibatch of the observed-input MAP model (no sample axis)")
     ap.add_argument('--proxy-world', type=int, default=0, help="--minibatch --shard rows on ONE GPU: evaluate the share of one rank of a W-GPU run "
                     "(B / W rows, KL weight 1 / W, no collective)")
-    ap.add_argument('--concurrent-modules', action='store_true', help='deep GP workload: enqueue the two SVGP modules on streams and library handles of '
-                    'their own (r05 experiment, SLOWER: the first layer\'s small kernels starve under the second layer\'s persistent products)')
     ap.add_argument('--hidden', type=int, default=2, help='hidden-layer width of the deep GP workload')
     ap.add_argument('--horizon', type=int, default=100, help='time steps of the PILCO rollout workload')
     ap.add_argument('--graph', type=int, default=0, help='1: capture forward + reverse pass of a step into a hipGraph after two eager steps')
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend of an N > 1 run: 'nccl' (= RCCL over xGMI, one rank per GPU; the default and what a measurement uses) or "
+                         "'gloo' on device tensors (the same product loops and HIP kernels, collectives staged through the host)")
+    ap.add_argument('--same-device', action='store_true',
+                    help='with --backend gloo: every rank runs on cuda:0 -- a software check of the multi-process path on a one-GPU box, not a measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the roofline micro-measurements and the f64 cross-check')
     ap.add_argument('--f32-form', default='auto', choices=['auto', 'explicit', 'whitened', 'float64'],
@@ -765,7 +785,9 @@ def main():
         import socket
         import subprocess
         ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        if args.same_device and args.backend != 'gloo':
+            raise SystemExit('bench.py --same-device needs --backend gloo (RCCL refuses two ranks on one GPU)')
+        if ndev < (1 if args.same_device else args.gpus):
             raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible to this process' % (args.gpus, ndev))
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
@@ -792,9 +814,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     if world != max(1, args.gpus) and not args.force_dist:
         raise SystemExit('bench.py: launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
-    if torch.cuda.device_count() < min(world, 1 + int(os.environ.get('LOCAL_RANK', '0'))):
+    local_rank = 0 if args.same_device else int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.device_count() < min(world, 1 + local_rank):
         raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1 or args.force_dist      # --force-dist: run the RCCL code path (init, broadcast, all-reduce, barriers) even with one rank
     torch.cuda.set_device(local_rank)
     if distributed:
@@ -803,7 +825,11 @@ def main():
         if args.force_dist and world == 1:          # stand-alone run of the RCCL code path: supply what the launcher would
             for k, v in (('RANK', '0'), ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0'), ('MASTER_PORT', '29517')):
                 os.environ.setdefault(k, v)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
+    _RANK_TIMES['backend'], _RANK_TIMES['same_device'] = args.backend, bool(args.same_device)
     if args.samples % world:
         raise SystemExit('--samples must be divisible by the number of GPUs')
     S_local = args.samples // world
@@ -849,8 +875,6 @@ def main():
     if args.workload == 'deepgp':      # secondary workload: BASELINE.json configs[4] (2-layer SVGP deep GP, Matern52+RBF, N=131072 D=16 M=512/layer)
         N, Q, M, Dh = (131072 if args.N == 65536 else args.N), (16 if args.Q == 8 else args.Q), (512 if args.M == 1024 else args.M), args.hidden
         X, Y, _ = synth(N, Q, M)
-        from mxfusion_amd.models.factor_graph import FactorGraph
-        FactorGraph.concurrent_modules = bool(args.concurrent_modules)  # (the layers' log-pdfs are independent given the samples of H: DESIGN.md section 8 item 5)
         infr, loop = build_deepgp(N, Q, M, Dh, S_local, args.dtype, X, Y, distributed)
         td = torch.float32 if args.dtype == 'float32' else torch.float64
         data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]

@@ -118,28 +118,9 @@ def load():
     return _lib
 
 
-_slot = threading.local()
-
-
-class handle_slot(object):
-    """`with handle_slot(k):` -- library calls made inside use a handle of their own (workspace, side streams, float32 form) instead of the thread's
-    default one: two module calls enqueued on DIFFERENT caller streams must not share a handle (its calls are not re-entrant; FactorGraph.log_pdf
-    with concurrent_modules, r05)."""
-
-    def __init__(self, k):
-        self.k = int(k)
-
-    def __enter__(self):
-        self.prev = getattr(_slot, 'k', 0)
-        _slot.k = self.k
-
-    def __exit__(self, *a):
-        _slot.k = self.prev
-
-
 def handle(device_index):
-    """One library handle per (thread, device) -- and per handle_slot when one is active."""
-    key = (threading.get_ident(), int(device_index), getattr(_slot, 'k', 0))
+    """One library handle per (thread, device): handle calls are not re-entrant (include/mxf_gp.h)."""
+    key = (threading.get_ident(), int(device_index))
     h = _handles.get(key)
     if h is None:
         lib = load()

@@ -74,6 +74,7 @@ struct mxf_ctx {
     hipStream_t side = nullptr;   // internal side streams: independent chains of the SVGP step run concurrently
     hipStream_t side2 = nullptr;
     hipStream_t potrf_aux = nullptr;                        // look-ahead stream of the blocked Cholesky (chol.hip)
+    bool potrf_aux_ready = false;                           // set only when EVERY auxiliary stream and event below exists
     hipEvent_t ev_pa = nullptr, ev_pb = nullptr, ev_ph = nullptr;
     hipStream_t potrf_inv = nullptr;                        // r05: the inverse of the factor, row block by row block NEXT TO the factorisation (chol.hip)
     hipEvent_t ev_pi = nullptr, ev_pj = nullptr;
@@ -196,13 +197,22 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
 }
 
 static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
-    if (h->potrf_aux) return true;
-    if (hipStreamCreateWithFlags(&h->potrf_aux, hipStreamNonBlocking) != hipSuccess) { h->potrf_aux = nullptr; return false; }
-    if (hipEventCreateWithFlags(&h->ev_pa, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pb, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_ph, hipEventDisableTiming) != hipSuccess)
+    if (h->potrf_aux_ready) return true;
+    // all or nothing: a partial failure leaves NO auxiliary stream / event behind (the callers gate look-ahead on the return value)
+    bool ok = hipStreamCreateWithFlags(&h->potrf_aux, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) h->potrf_aux = nullptr;
+    ok = ok && hipStreamCreateWithFlags(&h->potrf_inv, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) h->potrf_inv = nullptr;
+    hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj};
+    for (hipEvent_t* e : evs)
+        if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; ok = false; }
+    if (!ok) {
+        for (hipEvent_t* e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        if (h->potrf_inv) { (void)hipStreamDestroy(h->potrf_inv); h->potrf_inv = nullptr; }
+        if (h->potrf_aux) { (void)hipStreamDestroy(h->potrf_aux); h->potrf_aux = nullptr; }
         return false;
-    if (hipStreamCreateWithFlags(&h->potrf_inv, hipStreamNonBlocking) != hipSuccess) { h->potrf_inv = nullptr; return false; }
-    if (hipEventCreateWithFlags(&h->ev_pi, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_pj, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    h->potrf_aux_ready = true;
     return true;
 }
 

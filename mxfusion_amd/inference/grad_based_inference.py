@@ -36,12 +36,21 @@ class GradBasedInference(Inference):
                                       optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose,
                                       update_shape_constants=update_shape_constants, generator=generator, permutations=permutations)
         else:
+            if hasattr(self._grad_loop, 'bind_data'):
+                self._grad_loop.bind_data(self.observed_variable_UUIDs)
             local = self._grad_loop._local(data) if hasattr(self._grad_loop, '_local') else data
+            restore = None
             if local is not data:          # row-sharded batch loop: the executor sees this rank's rows -- shape constants (N) follow them
                 shapes = {i: tuple(d.shape) for i, d in zip(self.observed_variable_UUIDs, local)}
+                full = discover_shape_constants({i: tuple(d.shape) for i, d in zip(self.observed_variable_UUIDs, data)}, self._graphs)
+                restore = full
                 self.params.update_constants(discover_shape_constants(shapes, self._graphs))
-            out = self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
-                                      optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
+            try:
+                out = self._grad_loop.run(infr_executor=infr, data=data, param_dict=self.params, ctx=self.mxnet_context,
+                                          optimizer=optimizer, learning_rate=learning_rate, max_iter=max_iter, verbose=verbose)
+            finally:
+                if restore is not None:    # predictions / checkpoints seeded from infr.params see the FULL data's shape constants again
+                    self.params.update_constants(restore)
         self._check_float32_validity()
         return out
 

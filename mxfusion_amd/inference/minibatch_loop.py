@@ -4,7 +4,7 @@ last_batch='rollover', rv_scaling = N/B pushed into the factors as log_pdf_scali
 Monte-Carlo samples sharded over the GPUs of a node, one RCCL all-reduce of the flat gradient per minibatch)."""
 import torch
 
-from .batch_loop import _Adam, _GraphStepMixin
+from .batch_loop import _Adam, _GraphStepMixin, _OneCollectiveExchange
 from .grad_loop import GradLoop
 
 
@@ -34,9 +34,9 @@ class MinibatchInferenceLoop(GradLoop, _GraphStepMixin):
             return torch.as_tensor(next(permutations), dtype=torch.long).to(device)
         return torch.randperm(N, device=device, generator=generator)
 
-    def _exchange(self, param_dict):
-        """Gradient exchange hook between backward and the optimiser step (nothing to do on one GPU)."""
-        pass
+    def _exchange(self, param_dict, loss):
+        """Exchange hook between backward and the optimiser step; returns the job's loss (nothing to do on one GPU)."""
+        return loss
 
     # ---- one minibatch -----------------------------------------------------------------------------------------------------------------
     def step(self, infr_executor, batch, param_dict, update_shape_constants=None):
@@ -53,8 +53,7 @@ class MinibatchInferenceLoop(GradLoop, _GraphStepMixin):
             return self._graph_step(infr_executor, st, param_dict)            # (runs the exchange hook itself)
         loss, loss_for_gradient = infr_executor(*batch)
         loss_for_gradient.backward()
-        self._exchange(param_dict)
-        return loss
+        return self._exchange(param_dict, loss)
 
     def run(self, infr_executor, data, param_dict, ctx, optimizer='adam', learning_rate=1e-3, max_iter=1000, verbose=False,
             update_shape_constants=None, generator=None, permutations=None):
@@ -83,15 +82,17 @@ class MinibatchInferenceLoop(GradLoop, _GraphStepMixin):
             carry = idx[n_full * B:]
             if n_batches:
                 self.epoch_losses.append(L_e / n_batches)             # device scalars; float() them when (if) they are wanted
+                if len(self.epoch_losses) % 512 == 0:                  # long runs: the old entries become host floats (one drain per 512 epochs)
+                    self.epoch_losses[-512:-256] = [float(x) for x in self.epoch_losses[-512:-256]]
             if verbose and n_batches:
                 print('epoch-loss: {} '.format(float(L_e) / n_batches))
         self._trainer = trainer
 
 
-class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
+class DistributedMinibatchInferenceLoop(_OneCollectiveExchange, MinibatchInferenceLoop):
     """Data-parallel minibatch loop (one process per GPU; backend 'nccl' is RCCL on ROCm, tests use 'gloo').  Every rank holds the full data
-    set and walks the SAME shuffles (rank 0 draws each epoch's permutation and broadcasts it); ONE all-reduce of the flat gradient per
-    minibatch, then every rank takes the identical Trainer.step(batch_size=B); the returned loss is reduced over the ranks as well.
+    set and walks the SAME shuffles (rank 0 draws each epoch's permutation and broadcasts it); ONE all-reduce per minibatch carries the flat
+    gradient AND the loss (_OneCollectiveExchange), then every rank takes the identical Trainer.step(batch_size=B).
 
     shard='samples' (BASELINE.json configs[3]): every rank evaluates the whole minibatch with ITS shard of the Monte-Carlo samples (the
       inference algorithm's num_samples is the local count); objective and gradient are the mean over ranks.
@@ -114,18 +115,6 @@ class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
         self.shard = shard
         self._synced = False
 
-    def _world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_world_size(self.process_group)
-        return 1
-
-    def _rank(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(self.process_group)
-        return 0
-
     def global_weight(self):
         """Weight of the row-independent factors in this rank's objective (GradBasedInference.create_executor asks for it)."""
         return 1.0 / self._world() if self.shard == 'rows' else None
@@ -139,35 +128,8 @@ class DistributedMinibatchInferenceLoop(MinibatchInferenceLoop):
 
     def step(self, infr_executor, batch, param_dict, update_shape_constants=None):
         world = self._world()
-        if not self._synced and world > 1:
-            import torch.distributed as dist
-            with torch.no_grad():           # replicas must start from identical parameters (un-set ones are drawn from the host RNG)
-                dist.broadcast(param_dict.flat.data, src=0, group=self.process_group)
-            self._synced = True
+        self._sync_parameters(param_dict)
         if self.shard == 'rows' and world > 1:
             r = self._rank()
             batch = [torch.tensor_split(d, world)[r] for d in batch]     # this rank's rows of the (identical) minibatch
-        loss = super(DistributedMinibatchInferenceLoop, self).step(infr_executor, batch, param_dict, update_shape_constants)
-        return _reduce_loss(loss, world, self.process_group, mean=self.shard == 'samples')
-
-    def _exchange(self, param_dict):
-        world = self._world()
-        if world > 1:
-            import torch.distributed as dist
-            g = param_dict.flat.grad
-            if self.shard == 'samples':
-                g.div_(world)
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group)
-
-
-def _reduce_loss(loss, world, group, mean):
-    """The objective of the whole job from the ranks' shares ('flat gradient + scalar loss'): mean over ranks when the
-    samples are sharded, sum when the rows are.  Detached; on one rank the loss itself."""
-    if world <= 1:
-        return loss
-    import torch.distributed as dist
-    t = loss.detach().clone()
-    if mean:
-        t.div_(world)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+        return super(DistributedMinibatchInferenceLoop, self).step(infr_executor, batch, param_dict, update_shape_constants)

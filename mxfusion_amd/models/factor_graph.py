@@ -166,7 +166,6 @@ class FactorGraph(object):
         if targets is not None:
             targets = {t.uuid if isinstance(t, Variable) else t for t in targets}
         logL = 0.
-        pending = []
         for f in self.ordered_factors:
             if isinstance(f, FunctionEvaluation):
                 outcome = f.eval(F=F, variables=variables, always_return_tuple=True)
@@ -184,48 +183,10 @@ class FactorGraph(object):
                 else:
                     module_targets = [v.uuid for _, v in f.outputs if v.uuid in targets]
                 if len(module_targets) > 0:
-                    side = self._module_side_stream(f, variables, module_targets) if FactorGraph.concurrent_modules else None
-                    if side is not None:
-                        # (r05, opt-in) the modules' log-pdfs are independent given the variables: all but the last are enqueued on streams of
-                        # their own, each with its own library handle, and joined at the end -- the first layer of a deep GP (materialised
-                        # combination-kernel path: ~3.6 ms of small kernels) then runs under the second layer's bulk kernels
-                        from .. import _lib
-                        import torch
-                        cur = torch.cuda.current_stream()
-                        side.wait_stream(cur)
-                        with torch.cuda.stream(side), _lib.handle_slot(1 + len(pending)):
-                            val = expectation(F, f.log_pdf(F=F, variables=variables, targets=module_targets)).sum()
-                        pending.append((side, val))
-                    else:
-                        logL = logL + expectation(F, f.log_pdf(F=F, variables=variables, targets=module_targets)).sum()
+                    logL = logL + expectation(F, f.log_pdf(F=F, variables=variables, targets=module_targets)).sum()
             else:
                 raise ModelSpecificationError("There is an object in the factor graph that isn't a factor.")
-        if pending:
-            import torch
-            cur = torch.cuda.current_stream()
-            for side, val in pending:
-                cur.wait_stream(side)
-                val.record_stream(cur)
-                logL = logL + val
         return logL
-
-    concurrent_modules = False        # class-wide opt-in (bench.py --workload deepgp sets it)
-
-    def _module_side_stream(self, f, variables, module_targets):
-        """A side stream for this module's log-pdf, or None when it should run on the caller's stream: CPU tensors, the LAST module with targets
-        (it keeps the caller's stream and the default handle), or a single module."""
-        import torch
-        from ..modules.module import Module
-        mods = [g for g in self.ordered_factors if isinstance(g, Module) and any(v.uuid in variables for _, v in g.outputs)]
-        if len(mods) < 2 or f is mods[-1]:
-            return None
-        t = variables.get(module_targets[0])
-        if not (isinstance(t, torch.Tensor) and t.is_cuda) or torch.cuda.is_current_stream_capturing():
-            return None
-        pool = self.__dict__.setdefault('_side_streams', {})
-        if id(f) not in pool:
-            pool[id(f)] = torch.cuda.Stream()
-        return pool[id(f)]
 
     def draw_samples(self, F, variables, num_samples=1, targets=None):
         """factor_graph.py:240-297."""

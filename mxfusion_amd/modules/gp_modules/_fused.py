@@ -110,7 +110,7 @@ class Float32Guard(object):
         used = {g.slot for g in cls._instances}
         free = [k for k in range(1, _lib.COND_SLOTS) if k not in used]
         self.shared_slot = not free
-        self.slot = free[0] if free else _lib.COND_SLOTS - 1
+        self.slot = free[0] if free else 0          # surplus guards publish into slot 0 (the un-configured calls' slot, which no guard polls)
         self.name = name
         self.tier = self.EXPLICIT
         self.cond_max = 0.0         # largest condition number this owner has seen
@@ -147,8 +147,9 @@ class Float32Guard(object):
         """What the guards have seen.  dev given: fold in what the finished calls have published first (the caller has synchronised)."""
         if dev is not None:
             for g in cls.instances():
-                with _lib.handle_slot(getattr(g, '_hslot', 0)):
-                    last, mx = _lib.svgp_cond_slot(ops._device_index(dev), g.slot, reset=False)
+                if g.shared_slot:             # a surplus guard reads nobody's slot (pinned to float64; ADVICE r05)
+                    continue
+                last, mx = _lib.svgp_cond_slot(ops._device_index(dev), g.slot, reset=False)
                 if mx > 0 and not getattr(g, '_stale', False):
                     g.cond_max, g.cond_last = max(g.cond_max, mx), last
         gs = [g for g in cls.instances() if g.cond_max > 0]
@@ -189,9 +190,10 @@ class Float32Guard(object):
 
     def poll(self, dev):
         """Before a call: fold in what this owner's finished calls have published since the last poll (no synchronisation)."""
+        if self.shared_slot:                      # more live guards than slots: this one runs float64 and never consumes an owner's readings
+            return
         idx = ops._device_index(dev)
-        with _lib.handle_slot(getattr(self, '_hslot', getattr(_lib._slot, 'k', 0))):
-            last, mx = _lib.svgp_cond_slot(idx, self.slot, reset=True)
+        last, mx = _lib.svgp_cond_slot(idx, self.slot, reset=True)
         if getattr(self, '_stale', False):          # after reset(): whatever was published before does not count
             self._stale = False
             return
@@ -248,7 +250,6 @@ class Float32Guard(object):
         return self.tier
 
     def configure(self, dev, tier):
-        self._hslot = getattr(_lib._slot, 'k', 0)        # (the library handle this owner's calls run on: polls and reports read ITS condition slots)
         _lib.svgp_configure(ops._device_index(dev), _lib.FORM_WHITENED if tier == self.WHITENED else _lib.FORM_EXPLICIT, self.slot)
 
     def first_call_needs_rerun(self, dev, ran_at, whitened_ok):

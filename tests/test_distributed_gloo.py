@@ -21,6 +21,18 @@ def _free_port():
     return p
 
 
+def _count_all_reduces():
+    """Wrap torch.distributed.all_reduce: SURVEY 8(e) asks for ONE collective per step ('flat gradient + scalar loss')."""
+    calls = []
+    orig = dist.all_reduce
+
+    def counted(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    dist.all_reduce = counted
+    return calls
+
+
 class _Params(object):
     """Minimal stand-in for InferenceParameters: one flat autograd leaf."""
 
@@ -123,7 +135,9 @@ def _worker8(rank, world, port, q):
     shard = eps[rank * (S // world):(rank + 1) * (S // world)]          # 4 MC samples per rank
     params = _Params(flat + (0.25 * rank))                              # replicas must start from rank 0's parameters (the loop broadcasts)
     loop = _batch_loop_cls()()
+    calls = _count_all_reduces()
     loop.run(_executor(Y, shard, sizes, params), [None], params, None, learning_rate=0.05, max_iter=3)
+    assert len(calls) == 3 and loop.collectives == 3, (len(calls), loop.collectives)        # one all-reduce per step: gradient + loss together
     q.put((rank, params.flat.detach().clone().numpy()))
     dist.destroy_process_group()
 
@@ -228,8 +242,10 @@ def _mb_worker(rank, world, port, q):
     params = _Params(flat + (0.5 if rank == 1 else 0.0))
     loop = _mb_loop_cls()(batch_size=B)
     my_perms = perms if rank == 0 else [p[::-1].copy() for p in perms]
+    calls = _count_all_reduces()
     loop.run(_mb_executor(shard, sizes, params, X.shape[0] / B, 1.0), [O.T(X), O.T(Y)], params, None, learning_rate=0.05, max_iter=3,
              permutations=my_perms)
+    assert len(calls) == 9 and loop.collectives == 9, (len(calls), loop.collectives)        # 3 epochs x 3 minibatches, one all-reduce each
     q.put((rank, params.flat.detach().clone().numpy()))
     dist.destroy_process_group()
 
@@ -347,10 +363,13 @@ def _run_rows(loop_kind, world_rank=None):
         losses.append(float(out.detach()))
         return out
     loop.step = step
+    calls = _count_all_reduces()
     if 'minibatch' in loop_kind:
         infr.run(X=X, Y=Y, learning_rate=0.05, max_iter=2, permutations=perms if not world_rank else [p[::-1].copy() for p in perms])
     else:
         infr.run(X=X, Y=Y, learning_rate=0.05, max_iter=3)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        assert len(calls) == len(losses) == loop.collectives, (len(calls), len(losses))     # ONE collective per step (gradient + loss)
     return infr.params.flat.detach().clone().numpy(), losses
 
 

@@ -153,8 +153,9 @@ def test_svi_with_samples_matches_oracle_trajectory(golden_dir):
     losses, grads = [], []
 
     class Rec(BatchInferenceLoop):
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
 
         def run(self, infr_executor, data, **kw):
             def wrapped(*a):

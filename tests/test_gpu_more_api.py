@@ -86,8 +86,9 @@ def test_combination_kernel_gp_logpdf_and_gradients():
     grads = []
 
     class Rec(BatchInferenceLoop):
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
     infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=Rec(), dtype=DT)
     infr.run(X=_t(X), Y=_t(Y), max_iter=1, learning_rate=0.01)
     ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
@@ -215,8 +216,9 @@ def test_svgp_with_add_kernel_through_the_api(latent):
     grads, losses = [], []
 
     class Rec(BatchInferenceLoop):
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
 
         def run(self, infr_executor, data, **kw):
             def wrapped(*a):
@@ -276,14 +278,10 @@ def test_svgp_with_add_kernel_through_the_api(latent):
         assert np.allclose(grads[0][o:o + n].cpu().numpy(), ref.grad.numpy().reshape(-1), rtol=1e-7, atol=1e-8), var
 
 
-@pytest.mark.parametrize('concurrent', [False, True])
-def test_two_layer_deep_gp_svi_step_matches_oracle(concurrent, monkeypatch):
+def test_two_layer_deep_gp_svi_step_matches_oracle():
     """SURVEY 8f rank 1 (BASELINE config 5 in miniature): two chained SVGPRegression modules, first layer AddKernel(Matern52, RBF),
     hidden layer H with a mean-field q(H) (inference/meanfield.py:24-44), StochasticVariationalInference with injected noise.
-    Loss and flat gradient of the first step vs the oracle.  concurrent (r05): the two modules' log-pdfs enqueued on streams and library
-    handles of their own (FactorGraph.concurrent_modules, what bench.py --workload deepgp runs)."""
-    from mxfusion_amd.models.factor_graph import FactorGraph
-    monkeypatch.setattr(FactorGraph, 'concurrent_modules', concurrent)
+    Loss and flat gradient of the first step vs the oracle."""
     from mxfusion_amd import Model, Variable
     from mxfusion_amd.components.variables import PositiveTransformation
     from mxfusion_amd.components.distributions.random_gen import MockRandomGenerator
@@ -319,8 +317,9 @@ def test_two_layer_deep_gp_svi_step_matches_oracle(concurrent, monkeypatch):
     grads, losses = [], []
 
     class Rec(BatchInferenceLoop):
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
 
         def run(self, infr_executor, data, **kw):
             def wrapped(*a):
@@ -506,8 +505,9 @@ def test_with_samples_gp_and_sparse_gp(module, golden_dir):
     grads, losses = [], []
 
     class Rec(BatchInferenceLoop):
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
 
         def run(self, infr_executor, data, **kw):
             def wrapped(*a):

@@ -113,8 +113,9 @@ def test_sgp_with_a_combination_kernel_runs_the_materialised_path():
             losses.append(float(loss.detach()))
             return loss
 
-        def _exchange(self, param_dict):
+        def _exchange(self, param_dict, loss):
             grads.append(param_dict.flat.grad.clone())
+            return loss
     infr = GradBasedInference(MAP(model=m, observed=[m.X, m.Y]), grad_loop=Rec(), dtype='float64')
     infr.run(X=t64(X), Y=t64(Y), max_iter=1, learning_rate=1e-9)
     ok = O.AddKernel([O.Matern52(Q), O.RBF(Q)])
