@@ -190,6 +190,13 @@ int mxf_gemm_f16x2(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, 
 int mxf_f16x2_split(mxf_handle h, int64_t R, int64_t K, const void* X, int64_t ld, void* planes, void* maxword, void* stream);
 int mxf_gemm_f16x2_planes(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
                           const void* B_planes, const void* B_maxword, double beta, void* C, int64_t ldc, int lower_only, void* stream);
+/* The same product with the second operand stored the OTHER way round (r06): C (M x N) = alpha * A (M x K) * Bt (K x N), Bt_planes =
+ * mxf_f16x2_split of the (K x N) matrix Bt itself (rows = contraction index).  The SVGP training step uses it for T = H0 Kuf on the SAME
+ * planes of Kuf that Psi2 = Kuf Kuf^T reads (svgp_regression.py:85-90 needs Kuf in both roles; until r05 it was written twice).
+ * M % 256 == 0, N % 256 == 0, K % 16 == 0, K >= 48.  blocked != 0: C in 16-column blocks (layout of lower_only = 2 above), else row-major
+ * with ldc == N.  w (K floats) and U (N floats), both or neither: the same launch forms U[n] = sum_k w[k] Bt[k][n] (K <= 2048).          */
+int mxf_gemm_f16x2_planes_kmajor(mxf_handle h, int64_t M, int64_t N, int64_t K, double alpha, const void* A_planes, const void* A_maxword,
+                                 const void* Bt_planes, const void* Bt_maxword, void* C, int blocked, const void* w, void* U, void* stream);
 /* Chained split products (the whitened SVGP tier, svgp_regression.py:83-92 in factorised float32 form):
  * mxf_gemm_f16x2_planes_out writes alpha * A B^T DIRECTLY as the two f16 planes (hi + lo, UNSCALED: the caller picks alpha so that the
  * largest magnitude sits near 2^13..2^14; as an operand of the next product its maxword is a word holding 8192.0f = scale 1) of the (M x N) operand whose contraction

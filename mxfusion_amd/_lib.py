@@ -53,6 +53,7 @@ SIGNATURES = {
     'mxf_gemm_f16x2': [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i, _vp],
     'mxf_f16x2_split': [_i64, _i64, _vp, _i64, _vp, _vp, _vp],
     'mxf_gemm_f16x2_planes': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _d, _vp, _i64, _i, _vp],
+    'mxf_gemm_f16x2_planes_kmajor': [_i64, _i64, _i64, _d, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     'mxf_svgp_logpdf_het': [_i, _i, _i, _i64, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                             _d, _d, _d, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_svgp_logpdf_mat': [_i, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _i,

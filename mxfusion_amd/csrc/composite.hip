@@ -793,6 +793,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (use_split) { acc(3 * pl_big, 2); acc(3 * pl_h0, 2); acc(3 * pl_big, 2); acc(gp_scr, 1); acc(gp_scr, 1); }
     else { acc((size_t)M * SB, sizeof(T)); if (want_grad) acc((size_t)M * SB, sizeof(T)); }      // Kuf, Kfu in the streaming dtype
     if (whiten) { acc(2 * pl_h0, 2); acc(MP, 8); acc(MP, sizeof(T)); acc(4, sizeof(float)); acc((size_t)(M / 128) * SB, sizeof(float)); }
+    // r06: ONE set of Kuf planes.  T = H0 Kuf reads the planes Psi2 reads (operand (m, k = n)) through gemm_bt.hip's transposing LDS read, and
+    // forms the row U = w^T Kuf on the way: the second planes pass (8.6 GB written between the two products, 1.8 ms of the 24 ms step with the
+    // matrix pipe idle) and its 8.6 GB buffer are gone.  Needs the explicit float32 form, one output column, whole 256 x 256 tiles.
+    static const int bt_env = (int)MXF_KNOB("MXF_SVGP_BT", 1);
+    const bool bt_path = bt_env && use_split && !whiten && !het_stream && P == 1 && split_mode == MXF_SPLIT_F16X2 && M <= 2048 && mxf_gemm_bt_ok(M, SB, M);
+    if (bt_path) acc(2 * (size_t)M + 8, 2);
     if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
@@ -814,6 +820,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     unsigned short* plLi = nullptr; D* ad = nullptr; T* aT = nullptr; float* sigf = nullptr;
     float* upart = nullptr;
     if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); upart = cv.take<float>((size_t)(M / 128) * SB); }
+    unsigned short* wpl = nullptr;
+    if (bt_path) wpl = cv.take<unsigned short>(2 * (size_t)M + 8);
     // whitened tier: the planes of V^T (operand (n, k = m) of T = Hh V) go into the THIRD plane slots of the two big buffers (sized for the
     // three-plane bf16 format; the whitened tier runs two-plane f16x2 only) -- the V product writes them next to V's own planes while other
     // workgroups still read the Kfu planes, so they cannot share that buffer's first two slots
@@ -941,6 +949,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
         MXF_T1(h, MXF_T_PLANES_A, sd_);
         MXF_STAGE(h, "Kuf planes (sd)", sd_);
+        if (bt_path) MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));     // the T product reads THESE planes
         // (the Kfu planes -- operand (n, k = m) of the T GEMM -- are written later, on the second side stream, once w = Kuu^-1 mu exists:
         //  the same pass then also forms the row U = w^T Kuf)
     } else {
@@ -1087,7 +1096,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     MXF_STAGE(h, "Su^-1 (s2)", s2_);
     MXF_HIP(h, hipEventRecord(h->ev_join, s2_));
-    if (use_split && !whiten) {
+    if (use_split && !whiten && !bt_path) {
         // Kfu planes (operand (n, k = m) of the T GEMM) + the row U = w^T Kuf in ONE pass, behind the Su chain on the second side stream:
         // HBM-write bound.  (r03, tests/probes/svgp_stages.py: the pass starts when w = Kuu^-1 mu exists, and the Kuu chain -- potrf, trtri,
         // Ki -- shares the chip with the Kuf planes pass and Psi2 and finishes just after Psi2: 0.9 / 1.4 / 1.6 ms at 4 samples against 0.6
@@ -1137,7 +1146,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     MXF_T0(h, MXF_T_TGEMM, st);
     // r05: the reverse pass as the EPILOGUE of the T product (gemm_split.hip wide_body<..., FUSE>): T is never written
-    const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 &&
+    const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 && !bt_path &&
                           mxf_svgp_bwd_fuse_ok(kind, dtype, M, SB, B, Q, P) != 0;
     mxf_fuse_args fza;
     if (fuse_bwd) {
@@ -1155,6 +1164,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plVt, pVt, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
+    else if (bt_path)     // T = H0 Kuf straight from the Kuf planes, U = w^T Kuf from the same fragments (gemm_bt.hip)
+        rc = mxf_gemm_bt_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKuf, (int64_t)pl_big, M, (float*)Text, SB, t_blocked, st, 0,
+                                  split_var, (const unsigned*)(info2 + 2), (unsigned*)(info2 + 3), (const float*)wT, (float*)(Text + M * SB),
+                                  1.0 / 16384.0, wpl);
     else if (use_split)   // T = H0 Kuf = H0 Kfu^T on the 16-bit matrix pipe (f32-equivalent splitting, gemm_split.hip)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr, nullptr, t_blocked,

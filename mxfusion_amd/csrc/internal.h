@@ -81,6 +81,14 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
 // (Cplanes != nullptr: the product is written as two f16 planes (hi + lo of alpha * A B^T, plane stride pC) in the layout of an (M x K' = N)
 //  operand, ((n / 16) * M + m) * 16 + n % 16 -- C / ldc are ignored; a_lower: A is lower triangular, the k loop of a row tile stops at its last row)
 // (maxout: the wide kernel's plain products raise this word (atomicMax) to the bit pattern of max |C|; every other path leaves it untouched)
+// gemm_bt.hip (r06): the same product with the second operand stored K-MAJOR -- C (M x N) = alpha * ad0[0] / scale(maxbits) * A (M x K) Bt (K x N),
+// Bt = the planes of the (btR >= K rows, k' = N) operand, element (k, n) at ((n / 16) * btR + k) * 16 + n % 16: the T product of the SVGP step
+// reads the SAME Kuf planes as Psi2.  w / U / wscratch (2 K halves + one word): optional row U[n] = uscale * ad0[0] * sum_k w[k] Bt[k][n].
+bool mxf_gemm_bt_ok(int64_t M, int64_t N, int64_t K);
+int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA, const unsigned short* Bt,
+                         int64_t pB, int64_t btR, float* C, int64_t ldc, int c_blocked, hipStream_t st, int reserve_cus = 0, const float* ad0 = nullptr,
+                         const unsigned* maxbits = nullptr, unsigned* maxout = nullptr, const float* w = nullptr, float* U = nullptr,
+                         double uscale = 1.0, void* wscratch = nullptr, const unsigned* maxbits2 = nullptr);
 size_t mxf_gram_planes_scratch_bytes(int64_t R, int64_t Kn, int Q);
 int mxf_gram_planes_internal(mxf_ctx* h, int kind, int64_t R, int64_t Kn, int Q, const float* Xmin, const float* Xmaj, const float* ls,
                              int ard, const float* var, unsigned short* planes, int64_t pstride, float* scratch, hipStream_t st,

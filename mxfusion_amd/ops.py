@@ -154,6 +154,20 @@ def gemm_f16x2_planes(A_split, B_split, M, N, K, alpha=1.0, beta=0.0, out=None, 
     return out
 
 
+def gemm_f16x2_planes_kmajor(A_split, Bt_split, M, N, K, alpha=1.0, out=None, blocked=False, w=None):
+    """C (M x N) = alpha A (M x K) Bt (K x N) from split operands, Bt_split = f16x2_split of the (K x N) matrix itself -- the product that lets
+    the SVGP step form T = H0 Kuf from the planes of Kuf that Psi2 reads (mxf_gemm_f16x2_planes_kmajor).  w (K,) float32: also returns
+    U[n] = sum_k w[k] Bt[k][n] from the same launch."""
+    (pa, wa), (pb, wb) = A_split, Bt_split
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=pa.device)
+    U = torch.empty(N, dtype=torch.float32, device=pa.device) if w is not None else None
+    wc = _c(w) if w is not None else None
+    _lib.call('mxf_gemm_f16x2_planes_kmajor', _h(pa), M, N, K, float(alpha), _p(pa), _p(wa), _p(pb), _p(wb), _p(out), int(bool(blocked)),
+              _p(wc) if wc is not None else None, _p(U) if U is not None else None, _stream())
+    return (out, U) if w is not None else out
+
+
 def gemm_f16x2_planes_out(A_split, B_split, M, N, K, alpha=1.0, a_lower=False, transposed=False, a=None):
     """alpha A B^T written directly as the two f16 planes (unscaled hi + lo) of the (M x N) operand whose contraction index is its column
     (mxf_gemm_f16x2_planes_out: chained split products; M % 128 == 0, N % 256 == 0).  Returns the int16 planes tensor; transposed=True: also

@@ -175,3 +175,35 @@ def test_wide_split_gemm_variants(xt, sync, pp):
     env = dict(os.environ, MXF_GP_LIB=probe, MXF_SPLIT_XT=str(xt), MXF_SPLIT_SYNC=str(sync), MXF_SPLIT_PP=str(pp))
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize('M,N,K,blocked,with_u', [(256, 256, 48, False, False), (256, 512, 64, True, True), (1024, 8192, 1024, True, True),
+                                                   (512, 2048, 1040, False, True), (1024, 65536, 1024, True, True), (256, 1024, 2048, False, True)])
+def test_gemm_f16x2_kmajor_second_operand(M, N, K, blocked, with_u):
+    """mxf_gemm_f16x2_planes_kmajor (gemm_bt.hip, r06): C = A Bt with Bt (K x N) split AS STORED -- its 16 x 16 tiles [k][n] are turned into
+    MFMA fragments by LDS-DMA + ds_read_b64_tr_b16 -- against float64 and against the row-operand product on the explicitly transposed copy
+    (same arithmetic: three f16 products per k block, f32 accumulation); the fused row U = w^T Bt against float64.  Shapes: one k trip with
+    clamped look-ahead (48), remainders 1 and 2 of the three-slot ring (64, 1040), several persistent rounds per workgroup, the T shape of
+    BASELINE configs[3] (1024 x 65536 x 1024), K = 2048 (the largest the fused U row takes)."""
+    from mxfusion_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    A = torch.randn(M, K, device='cuda', generator=g) * torch.exp(torch.randn(M, 1, device='cuda', generator=g))
+    Bt = torch.rand(K, N, device='cuda', generator=g) - 0.3
+    w = torch.randn(K, device='cuda', generator=g) * 3.0 if with_u else None
+    pa, pbt = ops.f16x2_split(A), ops.f16x2_split(Bt)
+    out = torch.full((M * N,), float('nan'), device='cuda')
+    r = ops.gemm_f16x2_planes_kmajor(pa, pbt, M, N, K, alpha=0.75, out=out.view(M, N), blocked=blocked, w=w)
+    C = out.view(N // 16, M, 16).permute(1, 0, 2).reshape(M, N) if blocked else out.view(M, N)
+    assert not torch.isnan(C).any()
+    idx = torch.randint(0, N, (1024,), device='cuda', generator=g)
+    ref = 0.75 * (A.double() @ Bt[:, idx].double())
+    scale = A.double().abs() @ Bt[:, idx].double().abs()
+    assert float(((C[:, idx].double() - ref).abs() / scale).max()) < 6e-7
+    # the row-operand kernel on the transposed copy forms the same products in the same order
+    C2 = ops.gemm_f16x2_planes(pa, ops.f16x2_split(Bt.T.contiguous()), M, N, K, alpha=0.75)
+    assert float(((C - C2).abs() / (A.abs() @ Bt.abs())).max()) < 3e-7
+    if with_u:
+        U = r[1]
+        uref = w.double() @ Bt.double()
+        uscale = w.double().abs() @ Bt.double().abs()
+        assert float(((U.double() - uref).abs() / uscale).max()) < 6e-7
