@@ -967,7 +967,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // (few samples per GPU: the whole product runs in the reduced-occupancy form -- the core chains are the critical path there and
         //  Psi2 is short; same-box at 4 samples: 5.46 -> 5.20 ms per step; at 32 samples a longer first phase costs 0.1-0.4 ms)
         const int64_t ka_dflt = (use_split ? 192 : 128) * M;
-        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split && SB <= 2 * ka_dflt ? SB : ka_dflt);
+        // r06, one set of planes (bt_path): nothing but the core chains runs next to Psi2 any more (the second planes pass used to take the
+        // CUs Psi2 left free and starve the chain behind it), so the whole product leaves them 32 CUs and there is no reduced first phase --
+        // the chains finish under Psi2 and T starts when Psi2 ends (same box, 32 samples: 23.5 -> 22.85 ms per step; 24 CUs: 23.8; 40: 22.9)
+        const int64_t ka_req = psi2_ka >= 0 ? psi2_ka : (use_split && SB <= 2 * ka_dflt ? SB : (bt_path ? 0 : ka_dflt));
+        const int rb_phase_b = (bt_path && !MXF_KNOB_SET("MXF_SVGP_PSI2_RB")) ? 32 : psi2_rb;
         const int64_t KA = (ka_req > 0 && ka_req < SB) ? ka_req / 32 * 32 : (ka_req > 0 ? SB : 0);
         MXF_T0(h, MXF_T_PSI2, sd_);
         if (use_split) {
@@ -981,7 +985,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             if (KA < SB) {
                 const unsigned short* pk = plKuf + (KA / 16) * M * 16;
                 rc = mxf_gemm_split_internal(h, M, M, SB - KA, (double)split_ga * split_ga, pk, (int64_t)pl_big, pk, (int64_t)pl_big, KA > 0 ? 1.0 : 0.0, (float*)Psi2, M, 1, sd_,
-                                             psi2_rb, split_mode, split_var, 2, nullptr);
+                                             rb_phase_b, split_mode, split_var, 2, nullptr);
                 if (rc) return rc;
             }
         } else {

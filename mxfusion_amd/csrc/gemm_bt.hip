@@ -80,8 +80,9 @@ __device__ __forceinline__ void bt_rendezvous(unsigned* ctr, unsigned n, int& pa
 }
 
 // one LDS-DMA request: 64 lanes x 16 bytes from per-lane global addresses to the 1 KB at LDS byte address `lds` (wave-uniform, in M0)
-__device__ __forceinline__ void bt_dma16(const void* gptr, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds) : "memory", "m0");
+// (wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset: two address registers per thread for the whole kernel)
+__device__ __forceinline__ void bt_dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 
 // acc + sum of the eight f16 products of two 16-byte fragments (four v_dot2_f32_f16)
@@ -100,8 +101,8 @@ constexpr int BT_KMAX16 = 128;           // U row: w planes of up to 2048 k live
 template <bool WU>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     constexpr int NU = 512;                          // 16-byte units of one plane's (256 x 16) slab
-    __shared__ u32x4 sA[3][2][NU];                   // [ring slot][plane][unit]: A rows, gemm_split.hip's swizzled image
-    __shared__ u32x4 sB[3][2][NU];                   // Bt: chunk c = ((wq * 2 + y) * 2 + h) * 4 + grp of 128 bytes [4 k][16 n]
+    __shared__ u32x4 sA[4][2][NU];                   // [ring slot][plane][unit]: A rows, gemm_split.hip's swizzled image
+    __shared__ u32x4 sB[4][2][NU];                   // Bt: chunk c = ((wq * 2 + y) * 2 + h) * 4 + grp of 128 bytes [4 k][16 n]
     __shared__ u32x4 sW[WU ? 2 * BT_KMAX16 * 2 : 1]; // w planes [plane][16 K16 halves]
     __shared__ float sU[WU ? 512 : 1];               // the two row halves' shares of U for the item's 256 columns
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wq = wave & 3, wh = wave >> 2;
@@ -129,115 +130,135 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     const int bc = tid >> 3, bs = tid & 7;
     const int b_nb = 4 * (bc >> 4) + 2 * ((bc >> 3) & 1) + (bc & 1);              // n16 block inside the strip: 4 wq' + 2 y + (grp & 1)
     const int b_kl = 8 * ((bc >> 1) & 1) + 4 * ((bc >> 2) & 1) + (bs >> 1);       // k inside the block: 8 (grp >> 1) + 4 h + j
-    const int64_t b_off = ((int64_t)b_nb * g.btR + b_kl) * 16 + 8 * (bs & 1);
+    const unsigned voff_b = (unsigned)((((int64_t)b_nb * g.btR + b_kl) * 16 + 8 * (bs & 1)) * 2);      // bytes (host checks 16 btR * 32 < 2^31)
+    const unsigned voff_a = (unsigned)((drow * 16 + dkh * 8) * 2);
     // fragment reads: A units; Bt byte offset of this lane inside a plane image (instruction (y, h) adds (2 y + h) * 512)
-    int ua[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) ua[x] = bt_lds_unit(128 * wh + 32 * x + li, lk);
+    // (row = 128 wh + 32 x + li: the swizzle bit (row >> 3) & 1 does not depend on x, so fragment x sits 64 units behind fragment 0 -- one
+    //  address register and immediate offsets)
+    const int ua0_ = bt_lds_unit(128 * wh + li, lk);
+#define ua_(x) (ua0_ + 64 * (x))
     const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sA[0][0][wave * 64]);
     const unsigned ldsB = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sB[0][0][wave * 64]);
+    const unsigned toff_blk = (unsigned)((((int64_t)(4 * wq) * g.M + 128 * wh + li) * 16 + 4 * lk) * 4);      // bytes (host: 16 M * 64 < 2^31)
     const int rb_h = (wq * 2048 + (lane >> 4) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8) / 2;      // in halves
 
-    for (int64_t wid0 = blockIdx.x; wid0 < g.nwg; wid0 += gridDim.x) {
-        int64_t wid = wid0;
-        {   // XCD-aware mapping: every XCD owns a contiguous run of items (gemm_split.hip)
-            const int64_t q = g.nwg / 8, r = g.nwg % 8, xcd = wid % 8, j = wid / 8;
-            wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        }
-        const int64_t tile_m = wid % g.tm, tile_n = wid / g.tm;      // the row tiles of one column strip are neighbours
-        const int64_t m0 = tile_m * 256, n0 = tile_n * 256;
-        const int64_t nk = g.K16;
-        // the U row of this strip: one of its row-tile workgroups, rotating with the strip so that no persistent workgroup keeps the duty
-        const bool uitem = WU && g.uout != nullptr && ((tile_n + tile_n / 8 + tile_n / 64) % g.tm) == tile_m;
-        if (g.sync) bt_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);
-
-        f32x16 c[4][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;
-        float ua0 = 0.f, ua1 = 0.f;
-
-        const unsigned short* da = g.A + (m0 + drow) * 16 + dkh * 8;
-        const unsigned short* db = g.Bt + (n0 / 16) * g.btR * 16 + b_off;
-        // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin the compiler tracks the LDS-DMA writes itself and puts an
-        //  s_waitcnt vmcnt(0) in front of the fragment reads at the loop header -- it cannot see the counted waits below --, i.e. one full
-        //  memory latency per trip with nothing in flight)
-#define BT_ISSUE(kb, SLOT)                                                                                                          \
-        do {                                                                                                                        \
-            bt_dma16(da + (kb) * g.M * 16, ldsA + (SLOT) * 16384);                                                                  \
-            bt_dma16(da + g.pA + (kb) * g.M * 16, ldsA + (SLOT) * 16384 + 8192);                                                    \
-            bt_dma16(db + (kb) * 256, ldsB + (SLOT) * 16384);                                                                       \
-            bt_dma16(db + g.pB + (kb) * 256, ldsB + (SLOT) * 16384 + 8192);                                                         \
-        } while (0)
-        // all but the block issued last (4 requests) have landed -- this wave's share; the barrier extends it to the workgroup
+    // One STREAM of k blocks over all of this workgroup's items (blockIdx.x, + gridDim.x, ...): the requests run two blocks ahead of the
+    // multiplies ACROSS item boundaries, so an item's first blocks arrive under the previous item's last multiplies and its epilogue -- a
+    // per-item pipeline fill (two memory latencies with nothing in flight, ~3 % of a K = 1024 item) never happens.  Ring slot = stream
+    // position modulo 3 (the fragments are read from LDS, so nothing here needs a compile-time ring index).
+    // (32-bit index arithmetic throughout: the 64-bit divisions of a first form expanded to branchy software routines in the per-item paths,
+    //  with spill reloads whose compiler-inserted s_waitcnt vmcnt(0) drained the request stream once per item)
+    const int nk = (int)g.K16;
+    const unsigned nwg = (unsigned)g.nwg, tmu = (unsigned)g.tm;
+    const int nit = (int)((nwg - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int nsteps = nit * nk;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7;
+    auto item_of = [&](int i) -> unsigned {         // XCD-aware mapping: every XCD owns a contiguous run of items (gemm_split.hip)
+        const unsigned wid = blockIdx.x + (unsigned)i * gridDim.x;
+        const unsigned xcd = wid & 7, jx = wid >> 3;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + jx;
+    };
+    // request side
+    int q_it = 0, q_kb = 0;
+    unsigned q_slot = 0;
+    const unsigned short* qa = nullptr;
+    const unsigned short* qb = nullptr;
+    auto q_enter = [&]() {
+        const unsigned wid = item_of(q_it);
+        const unsigned tn_ = wid / tmu, tm_ = wid - tn_ * tmu;      // the row tiles of one column strip are neighbours
+        qa = g.A + (int64_t)tm_ * 256 * 16;           // wave-uniform bases: SGPRs
+        qb = g.Bt + ((int64_t)tn_ * 16) * g.btR * 16;
+    };
+    // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin the compiler tracks the LDS-DMA writes itself and puts an
+    //  s_waitcnt vmcnt(0) in front of the fragment reads at the loop header -- it cannot see the counted waits below --, i.e. one full
+    //  memory latency per trip with nothing in flight)
+    auto q_issue = [&]() {
+        bt_dma16(qa + (int64_t)q_kb * g.M * 16, voff_a, ldsA + q_slot * 16384);
+        bt_dma16(qa + g.pA + (int64_t)q_kb * g.M * 16, voff_a, ldsA + q_slot * 16384 + 8192);
+        bt_dma16(qb + (int64_t)q_kb * 256, voff_b, ldsB + q_slot * 16384);
+        bt_dma16(qb + g.pB + (int64_t)q_kb * 256, voff_b, ldsB + q_slot * 16384 + 8192);
+        q_slot = (q_slot + 1) & 3;
+        if (++q_kb == nk) { q_kb = 0; ++q_it; if (q_it < nit) q_enter(); }
+    };
+    // all but the block requested last (4 requests) have landed -- this wave's share; the barrier extends it to the workgroup.  (vmcnt
+    // retires in order and counts the epilogue's stores too: a wait behind an epilogue also drains that item's stores -- conservative.)
 #define BT_WAIT(NSTR) do { asm volatile("s_waitcnt vmcnt(" NSTR ")" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define HF(v) __builtin_bit_cast(f16x8, v)
 #define BT_TR(ptr) __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr)))
-#define BT_COMPUTE(kk, SLOT)                                                                                                        \
-        do {                                                                                                                        \
-            u32x4 a_[4][2], b_[2][2];                                                                                               \
-            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                         \
-                const unsigned short* sb_ = reinterpret_cast<const unsigned short*>(&sB[SLOT][p][0]) + rb_h;                        \
-                _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                     \
-                    const u32x2 v0_ = BT_TR(sb_ + (2 * y) * 256), v1_ = BT_TR(sb_ + (2 * y + 1) * 256);                             \
-                    b_[y][p] = u32x4{v0_[0], v0_[1], v1_[0], v1_[1]};                                                               \
-                }                                                                                                                   \
+    f32x16 c[4][2];
+    float ua0 = 0.f, ua1 = 0.f;
+    int c_kb = 0, c_it = 0;
+    int64_t m0 = 0, n0 = 0;
+    unsigned c_slot = 0;
+    bool uitem = false;
+    // Fragment registers, two sets: while the MFMAs of block s run from one set, the Bt fragments and the first A fragment of block s + 1
+    // are read into the other -- the first six MFMAs behind a barrier then find their operands in registers and the remaining A
+    // fragments arrive under them.  (r06 PMC of the form that read all sixteen fragments behind the barrier: matrix pipe 0.54 busy at
+    // 1.80 GHz -- stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56.)  Hence FOUR ring
+    // slots: block s + 1 must have landed one step earlier than it is multiplied.
+    u32x4 fb0[2][2], fa0[2], fb1[2][2], fa1[2];
+#define BT_READ_B(FB, SLOTV)                                                                                                        \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                             \
+            const unsigned short* sb_ = reinterpret_cast<const unsigned short*>(&sB[SLOTV][p][0]) + rb_h;                           \
+            _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                         \
+                const u32x2 v0_ = BT_TR(sb_ + (2 * y) * 256), v1_ = BT_TR(sb_ + (2 * y + 1) * 256);                                 \
+                FB[y][p] = u32x4{v0_[0], v0_[1], v1_[0], v1_[1]};                                                                   \
             }                                                                                                                       \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x) { a_[x][0] = sA[SLOT][0][ua[x]]; a_[x][1] = sA[SLOT][1][ua[x]]; }         \
+        }                                                                                                                           \
+    } while (0)
+#define BT_READ_A0(FA, SLOTV) do { FA[0] = sA[SLOTV][0][ua_(0)]; FA[1] = sA[SLOTV][1][ua_(0)]; } while (0)
+#define BT_MM(x, AH, AL, FB)                                                                                                        \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                             \
+            c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AL), c[x][y], 0, 0, 0);          /* hi' lo */         \
+            c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][1]), HF(AH), c[x][y], 0, 0, 0);          /* lo' hi */         \
+            c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AH), c[x][y], 0, 0, 0);          /* hi' hi */         \
+        }                                                                                                                           \
+    } while (0)
+    // one stream position: CUR holds block s_ (its Bt fragments and A fragment 0), NXT receives block s_ + 1
+#define BT_STEP(FB, FA, NFB, NFA)                                                                                                   \
+    do {                                                                                                                            \
+        if (c_kb == 0) {                             /* a new item (workgroup-uniform) */                                           \
+            const unsigned wid = item_of(c_it);                                                                                     \
+            const unsigned tile_n = wid / tmu, tile_m = wid - tile_n * tmu;                                                         \
+            m0 = (int64_t)tile_m * 256; n0 = (int64_t)tile_n * 256;                                                                 \
+            uitem = WU && g.uout != nullptr && ((tile_n + (tile_n >> 3) + (tile_n >> 6)) % tmu) == tile_m;                          \
+            if (g.sync) bt_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);                                       \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
                 _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
-                    c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(b_[y][0]), HF(a_[x][1]), c[x][y], 0, 0, 0);   /* hi' lo */  \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
-                _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
-                    c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(b_[y][1]), HF(a_[x][0]), c[x][y], 0, 0, 0);   /* lo' hi */  \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
-                _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
-                    c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(b_[y][0]), HF(a_[x][0]), c[x][y], 0, 0, 0);   /* hi' hi */  \
-            if constexpr (WU) {                                                                                                     \
-                if (uitem && (((int)(kk) & 1) == wh)) {       /* wave-uniform: this half's k blocks of the U row */                  \
-                    const u32x4 wh_ = sW[2 * (int)(kk) + lk], wl_ = sW[BT_KMAX16 * 2 + 2 * (int)(kk) + lk];                         \
-                    ua0 = bt_dot8(b_[0][1], wh_, ua0); ua0 = bt_dot8(b_[0][0], wl_, ua0); ua0 = bt_dot8(b_[0][0], wh_, ua0);        \
-                    ua1 = bt_dot8(b_[1][1], wh_, ua1); ua1 = bt_dot8(b_[1][0], wl_, ua1); ua1 = bt_dot8(b_[1][0], wh_, ua1);        \
-                }                                                                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;                                                \
+            ua0 = 0.f; ua1 = 0.f;                                                                                                   \
+        }                                                                                                                           \
+        const bool more = s_ + 3 < nsteps;                                                                                          \
+        if (more) q_issue();                         /* block s_ + 3 into the slot block s_ - 1 left */                             \
+        asm volatile("" ::: "memory");               /* the fragment reads stay behind the requests */                              \
+        const unsigned nslot = (c_slot + 1) & 3;                                                                                    \
+        if constexpr (WU) {                                                                                                         \
+            if (uitem && (((int)c_kb & 1) == wh)) {      /* wave-uniform; FIRST: few registers are live here */                        \
+                const u32x4 wh_ = sW[2 * (int)c_kb + lk], wl_ = sW[BT_KMAX16 * 2 + 2 * (int)c_kb + lk];                             \
+                ua0 = bt_dot8(FB[0][1], wh_, ua0); ua0 = bt_dot8(FB[0][0], wl_, ua0); ua0 = bt_dot8(FB[0][0], wh_, ua0);            \
+                ua1 = bt_dot8(FB[1][1], wh_, ua1); ua1 = bt_dot8(FB[1][0], wl_, ua1); ua1 = bt_dot8(FB[1][0], wh_, ua1);            \
             }                                                                                                                       \
-        } while (0)
-        // one k block: request block kk + 2 (clamped: the surplus requests of the last two steps re-read the last block into a slot nobody
-        // reads again) into the slot that block kk - 1 left at the last barrier, multiply block kk, wait for block kk + 1
-#define BT_STEP(kk, SLOT, SLOT2)                                                                                                    \
-        do {                                                                                                                        \
-            const int64_t k2_ = (kk) + 2 < nk ? (kk) + 2 : nk - 1;                                                                  \
-            BT_ISSUE(k2_, SLOT2);                                                                                                   \
-            asm volatile("" ::: "memory");      /* the fragment reads stay behind the requests */                                     \
-            BT_COMPUTE(kk, SLOT);                                                                                                   \
-            BT_WAIT("4");                                                                                                           \
-        } while (0)
-        int64_t kb = 0;
-        for (int i = (int)(nk % 3); i > 0; --i, ++kb) {      // the block count modulo 3 first, unpipelined
-            BT_ISSUE(kb, 0);
-            BT_WAIT("0");
-            BT_COMPUTE(kb, 0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (kb < nk) {
-            BT_ISSUE(kb, 0);
-            BT_ISSUE(kb + 1, 1);
-            BT_WAIT("4");
-            for (; kb < nk; kb += 3) {                       // three k blocks per trip: the ring indices are compile-time constants
-                BT_STEP(kb, 0, 2);
-                BT_STEP(kb + 1, 1, 0);
-                BT_STEP(kb + 2, 2, 1);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus requests must have landed before the ring is reused
-        }
-#undef BT_STEP
-#undef BT_COMPUTE
-#undef BT_TR
-#undef HF
-#undef BT_WAIT
-#undef BT_ISSUE
+        }                                                                                                                           \
+        u32x4 a1h = sA[c_slot][0][ua_(1)], a1l = sA[c_slot][1][ua_(1)];                                                               \
+        BT_MM(0, FA[0], FA[1], FB);                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);           /* (keeps the live fragment sets at two: the scheduler otherwise hoists every read) */ \
+        u32x4 a2h = sA[c_slot][0][ua_(2)], a2l = sA[c_slot][1][ua_(2)];                                                               \
+        BT_MM(1, a1h, a1l, FB);                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        u32x4 a3h = sA[c_slot][0][ua_(3)], a3l = sA[c_slot][1][ua_(3)];                                                               \
+        BT_MM(2, a2h, a2l, FB);                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        if (s_ + 1 < nsteps) { BT_READ_B(NFB, nslot); BT_READ_A0(NFA, nslot); }     /* block s_ + 1 landed at the last barrier */    \
+        BT_MM(3, a3h, a3l, FB);                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        if (more) BT_WAIT("4"); else BT_WAIT("0");   /* block s_ + 2 has landed (workgroup-uniform branch) */                       \
+        c_slot = nslot;                                                                                                             \
+        if (++c_kb == nk) { c_kb = 0; ++c_it; finish_item(); }                                                                      \
+        ++s_;                                                                                                                       \
+    } while (0)
+    auto finish_item = [&]() {
         if constexpr (WU) {
             if (uitem) {          // workgroup-uniform
                 ua0 += __shfl_xor(ua0, 32, 64);              // the two k halves of the fragment
@@ -252,23 +273,61 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
             }
         }
         // D = Bt^T A^T: accumulator register r of tile (x, y) is C[m0 + 128 wh + 32 x + li][n0 + 64 wq + 32 y + 8 (r >> 2) + 4 lk + (r & 3)]
+        if (g.c_blk) {
+            // blocked layout, element (row, col) at ((col / 16) * M + row) * 16 + col % 16: one 32-bit per-thread byte offset (toff_blk) + a
+            // wave-uniform base per (x, y, q) -- the 32 store addresses cost one register, not 64
+            char* const cb = reinterpret_cast<char*>(g.C) + ((n0 >> 4) * g.M + m0) * 64;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int64_t row = m0 + 128 * wh + 32 * x + li;
+            for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+                for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t col = n0 + 64 * wq + 32 * y + 8 * q + 4 * lk;
-                    float* p = g.c_blk ? g.C + ((col >> 4) * g.M + row) * 16 + (col & 15) : g.C + row * g.ldc + col;
-                    const f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(p) = v;
-                    if (g.maxout) cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        char* const sb = cb + ((int64_t)(2 * y + (q >> 1)) * g.M + 32 * x) * 64 + 32 * (q & 1);      // wave-uniform
+                        const f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(sb + toff_blk) = v;
+                        if (g.maxout) cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int64_t row = m0 + 128 * wh + 32 * x + li;
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t col = n0 + 64 * wq + 32 * y + 8 * q + 4 * lk;
+                        float* p = g.C + row * g.ldc + col;
+                        const f32x4 v = {alpha * c[x][y][4 * q], alpha * c[x][y][4 * q + 1], alpha * c[x][y][4 * q + 2], alpha * c[x][y][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(p) = v;
+                        if (g.maxout) cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    }
+            }
         }
-        // the next item's first requests overwrite ring slots 0 / 1: every wave has left the k loop (barrier of its last step) -- and the
-        // sU exchange above sits behind a __syncthreads of its own
+    };
+    if (nsteps > 0) {
+        q_enter();
+        q_issue();
+        q_issue();
+        q_issue();                                   // (K >= 48: every item has at least three blocks)
+        BT_WAIT("8");                                // block 0 landed
+        BT_READ_B(fb0, 0); BT_READ_A0(fa0, 0);
+        BT_WAIT("4");                                // block 1 landed
     }
+    int s_ = 0;
+    while (s_ + 1 < nsteps) {                        // two positions per trip: the fragment sets alternate at compile time
+        BT_STEP(fb0, fa0, fb1, fa1);
+        BT_STEP(fb1, fa1, fb0, fa0);
+    }
+    if (s_ < nsteps) BT_STEP(fb0, fa0, fb1, fa1);
+#undef ua_
+#undef BT_STEP
+#undef BT_MM
+#undef BT_READ_A0
+#undef BT_READ_B
+#undef BT_TR
+#undef HF
+#undef BT_WAIT
     if (g.maxout) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
@@ -308,6 +367,8 @@ bool mxf_gemm_bt_ok(int64_t M, int64_t N, int64_t K) { return M > 0 && N > 0 && 
 int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alpha, const unsigned short* A, int64_t pA, const unsigned short* Bt,
                          int64_t pB, int64_t btR, float* C, int64_t ldc, int c_blocked, hipStream_t st, int reserve_cus, const float* ad0,
                          const unsigned* maxbits, unsigned* maxout, const float* w, float* U, double uscale, void* wscratch, const unsigned* maxbits2) {
+    if (c_blocked && M * 16 * 64 >= (1ll << 31)) MXF_FAIL(h, -3, "mxf_gemm_bt: too many rows for the blocked output");
+    if (btR * 16 * 32 >= (1ll << 31)) MXF_FAIL(h, -3, "mxf_gemm_bt: the K-major operand has too many rows");
     if (!mxf_gemm_bt_ok(M, N, K) || btR < K) MXF_FAIL(h, -2, "mxf_gemm_bt: needs M %% 256 == 0, N %% 256 == 0, K %% 16 == 0, K >= 48");
     if (c_blocked && ldc != N) MXF_FAIL(h, -2, "mxf_gemm_bt: the blocked output layout needs ldc == N");
     if ((ldc % 4) != 0 || (((uintptr_t)C) % 16) != 0) MXF_FAIL(h, -2, "mxf_gemm_bt: C must be 16-byte aligned with ldc %% 4 == 0");
@@ -326,8 +387,10 @@ int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alp
     int64_t grid = (int64_t)(256 - (reserve_cus > 0 ? reserve_cus : 0)) / 8 * 8;
     if (grid < 8) grid = 8;
     if (g.nwg <= grid) grid = g.nwg;
-    // the tm row tiles of a column strip start together (bounded rendezvous): they share the strip's Bt lines in their XCD's L2
-    static const int sync_env = (int)MXF_KNOB("MXF_BT_SYNC", 1);
+    // (the tm row tiles of a column strip CAN start together -- bounded rendezvous, as in gemm_split.hip -- so that they share the strip's Bt
+    //  lines in their XCD's L2.  Measured with the request stream running across items (r06, same box, 32 samples): 22.6-22.8 ms per step
+    //  with it, 22.4-22.5 without -- the requests of an item are in flight before its rendezvous anyway.  Off; probe knob MXF_BT_SYNC=1.)
+    static const int sync_env = (int)MXF_KNOB("MXF_BT_SYNC", 0);
     const int64_t q = g.nwg / 8, per_xcd = grid / 8;
     if (sync_env && g.tm >= 2 && g.nwg % 8 == 0 && g.nwg >= 16 && q % g.tm == 0 && per_xcd % g.tm == 0 && (g.nwg <= grid || g.nwg % grid == 0)) {
         g.sync = mxf_gsync(h, (unsigned)(g.nwg / g.tm));

@@ -1,4 +1,5 @@
-"""One-kernel workloads for the PMC passes of the split GEMMs.  usage: split_pmc.py t|tzero|psi2|v|vp|tr [SB]
+"""One-kernel workloads for the PMC passes of the split GEMMs.  usage: split_pmc.py t|tbt|tbt0|tzero|psi2|v|vp|tr [SB]
+tbt (r06): the T shape through the K-MAJOR second operand (gemm_bt.hip: the Kuf planes Psi2 reads, LDS-DMA + transposing LDS reads) with the fused U row; tbt0: without U;
 tzero: the T shape with an ALL-ZERO B operand (no operand toggling: the schedule's own ceiling, clock from GRBM_GUI_ACTIVE -- VERDICT r03 2a);
 v: V = L^-1 Kuf of the whitened tier as the step runs it (triangular A; planes of V and of V^T and the partial sums of U from one launch);
 vp: the same product writing the planes of V only; tr: the stand-alone planes transposition + U pass (mxf_f16x2_planes_transpose).
@@ -25,6 +26,15 @@ if which in ('v', 'vp', 'tr'):
         sc = torch.ones(1, device='cuda')
         for _ in range(3):
             ops.f16x2_planes_transpose(pl, M, SB, a=a, scale=sc)
+elif which in ('tbt', 'tbt0'):
+    pa = ops.f16x2_split(torch.randn(M, M, device='cuda'))
+    Bt = torch.rand(M, SB, device='cuda')
+    pb = ops.f16x2_split(Bt)
+    del Bt
+    out = torch.empty(M, SB, device='cuda')
+    w = torch.randn(M, device='cuda') if which == 'tbt' else None
+    for _ in range(3):
+        ops.gemm_f16x2_planes_kmajor(pa, pb, M, SB, M, out=out, blocked=True, w=w)
 elif which in ('t', 'tzero'):
     pa = ops.f16x2_split(torch.randn(M, M, device='cuda'))
     B = torch.zeros(SB, M, device='cuda') if which == 'tzero' else torch.rand(SB, M, device='cuda')
