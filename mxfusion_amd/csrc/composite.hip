@@ -798,7 +798,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // matrix pipe idle) and its 8.6 GB buffer are gone.  Needs the explicit float32 form, one output column, whole 256 x 256 tiles.
     static const int bt_env = (int)MXF_KNOB("MXF_SVGP_BT", 1);
     const bool bt_path = bt_env && use_split && !whiten && !het_stream && P == 1 && split_mode == MXF_SPLIT_F16X2 && M <= 2048 && mxf_gemm_bt_ok(M, SB, M);
-    if (bt_path) acc(2 * (size_t)M + 8, 2);
+    // the whitened tier likewise: T = Hh V reads the planes of V that Phi = V V^T reads (the V product's planes output IS the K-major layout),
+    // and forms U = a^T V on the way -- the V product no longer writes the planes of V^T (8.6 GB, its "second output") nor the partial sums of U
+    const bool bt_wh = bt_env && whiten && P == 1 && M <= 2048 && mxf_gemm_bt_ok(M, SB, M);
+    if (bt_path || bt_wh) acc(2 * (size_t)M + 8, 2);
     if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
@@ -821,7 +824,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     float* upart = nullptr;
     if (whiten) { plLi = cv.take<unsigned short>(2 * pl_h0); ad = cv.take<D>(MP); aT = cv.take<T>(MP); sigf = cv.take<float>(4); upart = cv.take<float>((size_t)(M / 128) * SB); }
     unsigned short* wpl = nullptr;
-    if (bt_path) wpl = cv.take<unsigned short>(2 * (size_t)M + 8);
+    if (bt_path || bt_wh) wpl = cv.take<unsigned short>(2 * (size_t)M + 8);
     // whitened tier: the planes of V^T (operand (n, k = m) of T = Hh V) go into the THIRD plane slots of the two big buffers (sized for the
     // three-plane bf16 format; the whitened tier runs two-plane f16x2 only) -- the V product writes them next to V's own planes while other
     // workgroups still read the Kfu planes, so they cannot share that buffer's first two slots
@@ -1049,6 +1052,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_T0(h, MXF_T_VGEMM, sd_);
         // (few samples per GPU: the Kuu chain on the caller's stream is the critical path -- both side-stream products leave it 40 CUs)
         const bool few = SB <= 2 * 192 * M;
+        if (bt_wh)      // planes of V only: T and U come from them (gemm_bt.hip)
+            rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, few ? 40 : 0, split_mode, sigf, 1,
+                                         (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1);
+        else
         rc = mxf_gemm_split_internal(h, M, SB, M, 1.0, plLi, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, nullptr, SB, 0, sd_, few ? 40 : 0, split_mode, sigf, 1,
                                      (const unsigned*)limax, nullptr, 0, nullptr, plKuf, (int64_t)pl_big, 1, plVt, pVt, P == 1 ? (const float*)aT : nullptr,
                                      P == 1 ? upart : nullptr);
@@ -1056,7 +1063,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_T1(h, MXF_T_VGEMM, sd_);
         MXF_STAGE(h, "V = Linv Kuf (sd)", sd_);
         MXF_T0(h, MXF_T_PLANES_B, sd_);
-        if (P == 1) rc = mxf_upart_reduce_internal(h, SB, (int)(M / 128), upart, sigf, 1.f / 16384.f, (float*)(Text + M * SB), sd_);
+        if (bt_wh) rc = 0;
+        else if (P == 1) rc = mxf_upart_reduce_internal(h, SB, (int)(M / 128), upart, sigf, 1.f / 16384.f, (float*)(Text + M * SB), sd_);
         else hipLaunchKernelGGL((wt_planes_kernel<8, 2>), dim3((unsigned)((SB + 255) / 256)), dim3(256), 0, sd_, M, SB, P, (const unsigned short*)plVt,
                                 pVt, (const float*)aT, (float*)(Text + M * SB), (const float*)sigf);
         if (rc) return rc;
@@ -1150,7 +1158,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     MXF_T0(h, MXF_T_TGEMM, st);
     // r05: the reverse pass as the EPILOGUE of the T product (gemm_split.hip wide_body<..., FUSE>): T is never written
-    const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 && !bt_path &&
+    const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 && !bt_path && !bt_wh &&
                           mxf_svgp_bwd_fuse_ok(kind, dtype, M, SB, B, Q, P) != 0;
     mxf_fuse_args fza;
     if (fuse_bwd) {
@@ -1165,6 +1173,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     else if (fuse_bwd)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      split_var, 1, (const unsigned*)(info2 + 2), nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, &fza);
+    else if (bt_wh)       // T = Hh V from the planes of V (scaled from max |Hh|; V / sigma 2^14), U = a^T V from the same fragments
+        rc = mxf_gemm_bt_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKuf, (int64_t)pl_big, M, (float*)Text, SB, t_blocked, st, 0,
+                                  sigf, (const unsigned*)(info2 + 2), (unsigned*)(info2 + 3), (const float*)aT, (float*)(Text + M * SB),
+                                  1.0 / 16384.0, wpl);
     else if (whiten)      // T = Hh V: planes of Hh (scaled from max |Hh|) x planes of V^T (V / sigma 2^14)
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plVt, pVt, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      sigf, 1, (const unsigned*)(info2 + 2), nullptr, t_blocked, (unsigned*)(info2 + 3));
