@@ -632,13 +632,15 @@ def mfma_roofline(M, SB, dtype, reps=12):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if dtype == 'float32':
         A = torch.randn(M, M, device='cuda')
-        B = torch.rand(SB, M, device='cuda')
-        pa, pb = ops.f16x2_split(A), ops.f16x2_split(B)
-        del B
+        Bt = torch.rand(M, SB, device='cuda')                 # the K-major operand AS STORED: the planes of Kuf that Psi2 reads
+        pa, pb = ops.f16x2_split(A), ops.f16x2_split(Bt)
+        del Bt
+        w = torch.randn(M, device='cuda')
         out = torch.empty(M, SB, device='cuda')
-        # as the training step runs it: T written in 16-column blocks (what the reverse pass reads), which puts it on the 128 x 256 kernel
-        run = lambda: ops.gemm_f16x2_planes(pa, pb, M, SB, M, out=out, blocked=True)
-        name, peak, extra = "gemm_f16x2_wide_kernel_256 (f32 = 2 scaled f16 terms, 3 MFMA products; C in 16-column blocks) %dx%dx%d" % (M, SB, M), 2500.0 / 3.0, \
+        # as the training step runs it (r06): second operand K-major through LDS-DMA + transposing LDS reads, T written in 16-column blocks
+        # (what the reverse pass reads), the row U = w^T Kuf formed from the same fragments
+        run = lambda: ops.gemm_f16x2_planes_kmajor(pa, pb, M, SB, M, out=out, blocked=True, w=w)
+        name, peak, extra = "gemm_f16x2_bt_kernel<true> (f32 = 2 scaled f16 terms, 3 MFMA products; K-major second operand via ds_read_b64_tr_b16; C in 16-column blocks; fused U row) %dx%dx%d" % (M, SB, M), 2500.0 / 3.0, \
             {"peak_note": "dense f16 MFMA peak 2500 TFLOP/s / 3 products; the f32 MFMA peak is 157.3", "f32_mfma_peak": 157.3}
     else:
         A = torch.randn(1, M, M, device='cuda', dtype=torch.float64)
@@ -655,7 +657,7 @@ def mfma_roofline(M, SB, dtype, reps=12):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     torch.cuda.empty_cache()
-    traffic, traffic_src = _pmc_traffic('gemm_t_pmc') if (dtype == 'float32' and M == 1024 and SB == 2097152) else (None, None)
+    traffic, traffic_src = _pmc_traffic('gemm_tbt_pmc') if (dtype == 'float32' and M == 1024 and SB == 2097152) else (None, None)
     r = {"bound": "mfma", "kernel": name, "achieved": fl / ms / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / peak,
          "traffic": traffic, "traffic_source": traffic_src, "ms_per_launch": ms, "algorithmic_flops": fl}
     r.update(extra)

@@ -1156,6 +1156,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_STAGE(h, "H0 planes", st);
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
+    // (in-step timing only: the T product is held until Psi2 has finished, so that `t_gemm` is the product's own duration -- untimed, its
+    //  first workgroups take the CUs Psi2's last work items free, and the event pair would count that queueing)
+    if (h->tm.on && bt_path && want_grad && !het) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));
     MXF_T0(h, MXF_T_TGEMM, st);
     // r05: the reverse pass as the EPILOGUE of the T product (gemm_split.hip wide_body<..., FUSE>): T is never written
     const bool fuse_bwd = use_split && want_grad && !het && !het_stream && split_mode == MXF_SPLIT_F16X2 && !bt_path && !bt_wh &&

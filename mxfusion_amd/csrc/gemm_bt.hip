@@ -98,7 +98,7 @@ __device__ __forceinline__ float bt_dot8(u32x4 a, u32x4 b, float acc) {
 constexpr int BT_KMAX16 = 128;           // U row: w planes of up to 2048 k live in LDS
 
 // 256 x 256 tile, 512 threads: wave = 4 h + w owns rows [128 h, + 128) x columns [64 w, + 64) = 4 x 2 MFMA tiles (128 accumulators).
-template <bool WU>
+template <bool WU, bool RA = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     constexpr int NU = 512;                          // 16-byte units of one plane's (256 x 16) slab
     __shared__ u32x4 sA[4][2][NU];                   // [ring slot][plane][unit]: A rows, gemm_split.hip's swizzled image
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     int64_t m0 = 0, n0 = 0;
     unsigned c_slot = 0;
     bool uitem = false;
-    // Fragment registers, two sets: while the MFMAs of block s run from one set, the Bt fragments and the first A fragment of block s + 1
-    // are read into the other -- the first six MFMAs behind a barrier then find their operands in registers and the remaining A
-    // fragments arrive under them.  (r06 PMC of the form that read all sixteen fragments behind the barrier: matrix pipe 0.54 busy at
-    // 1.80 GHz -- stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56.)  Hence FOUR ring
-    // slots: block s + 1 must have landed one step earlier than it is multiplied.
+    // FOUR ring slots.  Default (RA = false): the requests run THREE blocks ahead, a step reads its own fragments (Bt + A fragment 0 at the
+    // top, the other A fragments two multiplies ahead of their use).  RA = true (probe builds): requests two blocks ahead and the NEXT
+    // block's Bt fragments + first A fragment are read into a second register set under this block's MFMAs -- measured 0.15 ms slower per
+    // 32-sample step.  (r06 PMC of the first form -- three slots, all sixteen fragments read behind the barrier: matrix pipe 0.54 busy at
+    // 1.80 GHz, i.e. stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56; this form: 0.60 at 1.61.)
     u32x4 fb0[2][2], fa0[2], fb1[2][2], fa1[2];
 #define BT_READ_B(FB, SLOTV)                                                                                                        \
     do {                                                                                                                            \
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
         if (more) q_issue();                         /* block s_ + 3 into the slot block s_ - 1 left */                             \
         asm volatile("" ::: "memory");               /* the fragment reads stay behind the requests */                              \
         const unsigned nslot = (c_slot + 1) & 3;                                                                                    \
+        if constexpr (!RA) { BT_READ_B(FB, c_slot); BT_READ_A0(FA, c_slot); }      /* (measured alternative: no register read-ahead, requests three blocks ahead) */ \
         if constexpr (WU) {                                                                                                         \
             if (uitem && (((int)c_kb & 1) == wh)) {      /* wave-uniform; FIRST: few registers are live here */                        \
                 const u32x4 wh_ = sW[2 * (int)c_kb + lk], wl_ = sW[BT_KMAX16 * 2 + 2 * (int)c_kb + lk];                             \
@@ -241,19 +242,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
                 ua1 = bt_dot8(FB[1][1], wh_, ua1); ua1 = bt_dot8(FB[1][0], wl_, ua1); ua1 = bt_dot8(FB[1][0], wh_, ua1);            \
             }                                                                                                                       \
         }                                                                                                                           \
+        /* the A fragments run TWO multiplies ahead of their use (LDS pipe ~55 % busy in this kernel: one multiply of cover was not enough) */ \
         u32x4 a1h = sA[c_slot][0][ua_(1)], a1l = sA[c_slot][1][ua_(1)];                                                               \
-        BT_MM(0, FA[0], FA[1], FB);                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);           /* (keeps the live fragment sets at two: the scheduler otherwise hoists every read) */ \
         u32x4 a2h = sA[c_slot][0][ua_(2)], a2l = sA[c_slot][1][ua_(2)];                                                               \
+        BT_MM(0, FA[0], FA[1], FB);                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);           /* (pins the order: the scheduler otherwise hoists every read to the top) */    \
+        u32x4 a3h = sA[c_slot][0][ua_(3)], a3l = sA[c_slot][1][ua_(3)];                                                               \
         BT_MM(1, a1h, a1l, FB);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        u32x4 a3h = sA[c_slot][0][ua_(3)], a3l = sA[c_slot][1][ua_(3)];                                                               \
+        if constexpr (RA) { if (s_ + 1 < nsteps) { BT_READ_B(NFB, nslot); BT_READ_A0(NFA, nslot); } }     /* block s_ + 1 landed at the last barrier */    \
         BT_MM(2, a2h, a2l, FB);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        if (s_ + 1 < nsteps) { BT_READ_B(NFB, nslot); BT_READ_A0(NFA, nslot); }     /* block s_ + 1 landed at the last barrier */    \
         BT_MM(3, a3h, a3l, FB);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        if (more) BT_WAIT("4"); else BT_WAIT("0");   /* block s_ + 2 has landed (workgroup-uniform branch) */                       \
+        if constexpr (RA) { if (more) BT_WAIT("4"); else BT_WAIT("0"); }   /* block s_ + 2 has landed (workgroup-uniform branch) */  \
+        else { if (more) BT_WAIT("8"); else if (s_ + 2 < nsteps) BT_WAIT("4"); else BT_WAIT("0"); }      /* block s_ + 1 */            \
         c_slot = nslot;                                                                                                             \
         if (++c_kb == nk) { c_kb = 0; ++c_it; finish_item(); }                                                                      \
         ++s_;                                                                                                                       \
@@ -311,15 +314,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
         q_issue();
         q_issue();                                   // (K >= 48: every item has at least three blocks)
         BT_WAIT("8");                                // block 0 landed
-        BT_READ_B(fb0, 0); BT_READ_A0(fa0, 0);
-        BT_WAIT("4");                                // block 1 landed
+        if constexpr (RA) {
+            BT_READ_B(fb0, 0); BT_READ_A0(fa0, 0);
+            BT_WAIT("4");                            // block 1 landed
+        }
     }
     int s_ = 0;
-    while (s_ + 1 < nsteps) {                        // two positions per trip: the fragment sets alternate at compile time
-        BT_STEP(fb0, fa0, fb1, fa1);
-        BT_STEP(fb1, fa1, fb0, fa0);
+    if constexpr (RA) {
+        while (s_ + 1 < nsteps) {                    // two positions per trip: the fragment sets alternate at compile time
+            BT_STEP(fb0, fa0, fb1, fa1);
+            BT_STEP(fb1, fa1, fb0, fa0);
+        }
+        if (s_ < nsteps) BT_STEP(fb0, fa0, fb1, fa1);
+    } else {
+        while (s_ < nsteps) BT_STEP(fb0, fa0, fb1, fa1);
     }
-    if (s_ < nsteps) BT_STEP(fb0, fa0, fb1, fa1);
 #undef ua_
 #undef BT_STEP
 #undef BT_MM
@@ -396,8 +405,19 @@ int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alp
         g.sync = mxf_gsync(h, (unsigned)(g.nwg / g.tm));
         g.sync_n = (int)g.tm;
     }
-    if (U) hipLaunchKernelGGL(gemm_f16x2_bt_kernel<true>, dim3((unsigned)grid), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL(gemm_f16x2_bt_kernel<false>, dim3((unsigned)grid), dim3(512), 0, st, g);
+#ifdef MXF_PROBES
+    // RA (register read-ahead of the next block's Bt fragments + first A fragment, requests two blocks ahead) against the default (fragments
+    // read at the top of their own step, requests THREE blocks ahead): same box, 32-sample step 22.69-22.80 ms with it, 22.57 without
+    static const int ra_env = (int)MXF_KNOB("MXF_BT_RA", 0);
+    if (ra_env) {
+        if (U) hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f16x2_bt_kernel<false, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
+#endif
+    if (U) hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f16x2_bt_kernel<false>), dim3((unsigned)grid), dim3(512), 0, st, g);
     MXF_LAUNCH_CHECK(h);
     return 0;
 }
