@@ -98,6 +98,17 @@ int mxf_uniform_sum(mxf_handle h, int dtype, int64_t n, const void* g, void* out
 int mxf_sgd_step(mxf_handle h, int dtype, int64_t n, void* w, const void* g, void* mom, double lr, double momentum, double wd,
                  double rescale_grad, void* stream);
 
+/* The other update rules gluon.Trainer is driven with by name through the same seam (batch_loop.py:46-49, minibatch_loop.py:71-74): MXNet 1.x
+ * 'rmsprop' (non-centred), 'adagrad', 'adadelta', 'nag' on a flat buffer -- s1 / s2 are the optimiser's state buffers (n elements each,
+ * zero-initialised by the caller; s2 only for adadelta), p1 = gamma1 / rho / momentum.  Rules in csrc/elementwise.hip (API knowledge of
+ * MXNet; the reference holds no vector for them).                                                                                      */
+#define MXF_OPT_RMSPROP 1
+#define MXF_OPT_ADAGRAD 2
+#define MXF_OPT_ADADELTA 3
+#define MXF_OPT_NAG 4
+int mxf_opt_step(mxf_handle h, int kind, int dtype, int64_t n, void* w, const void* g, void* s1, void* s2, double lr, double p1, double epsilon,
+                 double wd, double rescale_grad, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU gradient exchange (RCCL over xGMI), SURVEY.md section 8(b)/(e).  The reference has no multi-device path (one MXNet context
  * per Inference object); north_star shards the Monte-Carlo samples of StochasticVariationalInference.compute

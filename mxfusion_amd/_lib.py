@@ -38,6 +38,7 @@ SIGNATURES = {
     'mxf_normal_reparam_bwd': [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'mxf_adam_step': [_i, _i64, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _i, _vp],
     'mxf_sgd_step': [_i, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _vp],
+    'mxf_opt_step': [_i, _i, _i64, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _d, _vp],
     'mxf_uniform_sum': [_i, _i64, _vp, _vp, _vp],
     'mxf_gp_logpdf': [_i, _i, _i, _i64, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _d,
                       _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],

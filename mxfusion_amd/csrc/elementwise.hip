@@ -281,6 +281,64 @@ extern "C" int mxf_sgd_step(mxf_handle h, int dtype, int64_t n, void* w, const v
              hipLaunchKernelGGL((sgd_kernel<double>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)mom, lr, momentum, wd, rescale_grad));
 }
 
+// The other optimisers gluon.Trainer is commonly driven with by name (batch_loop.py:46-49 hands `optimizer` to the Trainer): MXNet's
+// update rules as documented for its 1.x python optimisers (API knowledge -- there is no reference-held vector for them: parity unpinned).
+//   g = rescale * grad (+ wd * w where the rule folds weight decay into the gradient)
+//   RMSPROP (non-centred): n = (1 - gamma1) g^2 + gamma1 n;  w -= lr g / sqrt(n + eps)                      [s1 = n;  p1 = gamma1]
+//   ADAGRAD: h += g^2;  w -= lr (g / sqrt(h + eps) + wd w)                                                   [s1 = h]
+//   ADADELTA: a = rho a + (1 - rho) g^2;  d = sqrt(b + eps) / sqrt(a + eps) g;  b = rho b + (1 - rho) d^2;  w -= d + wd w   [s1 = a, s2 = b; p1 = rho]
+//   NAG: m = momentum m + g;  w -= lr (g + momentum m)                                                       [s1 = m;  p1 = momentum]
+template <typename T, int KIND>
+__global__ void opt_kernel(int64_t n, T* __restrict__ w, const T* __restrict__ g, T* __restrict__ s1, T* __restrict__ s2, T lr, T p1, T eps, T wd,
+                           T rescale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T wi = w[i];
+        if (KIND == MXF_OPT_RMSPROP) {
+            const T gi = g[i] * rescale + wd * wi;
+            const T ni = ((T)1 - p1) * gi * gi + p1 * s1[i];
+            s1[i] = ni;
+            w[i] = wi - lr * gi / sqrt(ni + eps);
+        } else if (KIND == MXF_OPT_ADAGRAD) {
+            const T gi = g[i] * rescale;
+            const T hi = s1[i] + gi * gi;
+            s1[i] = hi;
+            w[i] = wi - lr * (gi / sqrt(hi + eps) + wd * wi);
+        } else if (KIND == MXF_OPT_ADADELTA) {
+            const T gi = g[i] * rescale;
+            const T ai = p1 * s1[i] + ((T)1 - p1) * gi * gi;
+            const T di = sqrt(s2[i] + eps) / sqrt(ai + eps) * gi;
+            s1[i] = ai;
+            s2[i] = p1 * s2[i] + ((T)1 - p1) * di * di;
+            w[i] = wi - (di + wd * wi);
+        } else {
+            const T gi = g[i] * rescale + wd * wi;
+            const T mi = p1 * s1[i] + gi;
+            s1[i] = mi;
+            w[i] = wi - lr * (gi + p1 * mi);
+        }
+    }
+}
+
+extern "C" int mxf_opt_step(mxf_handle h, int kind, int dtype, int64_t n, void* w, const void* g, void* s1, void* s2, double lr, double p1, double epsilon,
+                            double wd, double rescale_grad, void* stream) {
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    if (!w || !g || !s1 || (kind == MXF_OPT_ADADELTA && !s2)) MXF_FAIL(h, -2, "mxf_opt_step: null argument");
+    hipStream_t st = (hipStream_t)stream;
+#define OPT_GO(K)                                                                                                                              \
+    DISPATCH(h, dtype, "mxf_opt_step",                                                                                                          \
+             hipLaunchKernelGGL((opt_kernel<float, K>), dim3(grid_for(n)), dim3(256), 0, st, n, (float*)w, (const float*)g, (float*)s1, (float*)s2, (float)lr, (float)p1, (float)epsilon, (float)wd, (float)rescale_grad), \
+             hipLaunchKernelGGL((opt_kernel<double, K>), dim3(grid_for(n)), dim3(256), 0, st, n, (double*)w, (const double*)g, (double*)s1, (double*)s2, lr, p1, epsilon, wd, rescale_grad))
+    switch (kind) {
+        case MXF_OPT_RMSPROP: OPT_GO(MXF_OPT_RMSPROP);
+        case MXF_OPT_ADAGRAD: OPT_GO(MXF_OPT_ADAGRAD);
+        case MXF_OPT_ADADELTA: OPT_GO(MXF_OPT_ADADELTA);
+        case MXF_OPT_NAG: OPT_GO(MXF_OPT_NAG);
+    }
+#undef OPT_GO
+    MXF_FAIL(h, -2, "mxf_opt_step: unknown optimiser kind %d", kind);
+}
+
 extern "C" int mxf_coldot(mxf_handle h, int dtype, int S, int64_t M, int64_t N, const void* A, int64_t lda, int64_t strideS_A,
                           const void* B, int64_t ldb, int64_t strideS_B, void* out, void* stream) {
     if (!h) return -1;

@@ -11,22 +11,34 @@ from .grad_loop import GradLoop
 
 class _Adam(object):
     """gluon.Trainer.step(batch_size) for the optimizers the reference's loops are called with by name (batch_loop.py:29-44 passes
-    `optimizer` and {'learning_rate': lr} to the Trainer): MXNet 'adam' (the default) and 'sgd' (plain, or
-    optimizer=('sgd', {'momentum': 0.9, 'wd': 0.0})); rescale_grad = 1/batch_size.  One fused kernel over the flat parameter buffer."""
+    `optimizer` and {'learning_rate': lr} to the Trainer): MXNet 'adam' (the default), 'sgd' (plain, or
+    optimizer=('sgd', {'momentum': 0.9, 'wd': 0.0})), 'nag', 'rmsprop' (non-centred), 'adagrad', 'adadelta' -- options as a
+    (name, {...}) pair with MXNet's keyword names; rescale_grad = 1/batch_size.  One fused kernel over the flat parameter buffer."""
+
+    # MXNet 1.x defaults of the rules served by mxf_opt_step: (first parameter, its keyword, epsilon)
+    _RULES = {'rmsprop': (0.9, 'gamma1', 1e-8), 'adagrad': (0.0, None, 1e-7), 'adadelta': (0.9, 'rho', 1e-5), 'nag': (0.0, 'momentum', 0.0)}
 
     def __init__(self, params, learning_rate, optimizer='adam'):
         opts = {}
         if isinstance(optimizer, (tuple, list)):
             optimizer, opts = optimizer[0], dict(optimizer[1])
-        if optimizer not in ('adam', 'sgd'):
-            raise NotImplementedError("optimizer %r: 'adam' (the reference default) and 'sgd' are implemented" % (optimizer,))
+        if optimizer not in ('adam', 'sgd') and optimizer not in self._RULES:
+            raise NotImplementedError("optimizer %r: 'adam' (the reference default), 'sgd', 'nag', 'rmsprop', 'adagrad' and 'adadelta' are implemented"
+                                      % (optimizer,))
+        if optimizer == 'rmsprop' and opts.get('centered', False):
+            raise NotImplementedError("optimizer 'rmsprop': the centred variant is not implemented")
         self.kind, self.opts = optimizer, opts
         self.params, self.lr, self.t = params, learning_rate, 0
         flat = params.flat.detach()
+        self.v = None
         if optimizer == 'adam':
             self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
-        else:
+        elif optimizer == 'sgd':
             self.m = torch.zeros_like(flat) if opts.get('momentum', 0.0) != 0.0 else None
+        else:
+            self.m = torch.zeros_like(flat)
+            if optimizer == 'adadelta':
+                self.v = torch.zeros_like(flat)
 
     def step(self, batch_size=1):
         self.t += 1
@@ -34,9 +46,13 @@ class _Adam(object):
         if self.kind == 'adam':
             ops.adam_step_(flat.detach(), flat.grad, self.m, self.v, self.lr, self.t, beta1=self.opts.get('beta1', 0.9),
                            beta2=self.opts.get('beta2', 0.999), epsilon=self.opts.get('epsilon', 1e-8), rescale_grad=1.0 / batch_size)
-        else:
+        elif self.kind == 'sgd':
             ops.sgd_step_(flat.detach(), flat.grad, self.m, self.lr, momentum=self.opts.get('momentum', 0.0), wd=self.opts.get('wd', 0.0),
                           rescale_grad=1.0 / batch_size)
+        else:
+            p1, key, eps = self._RULES[self.kind]
+            ops.opt_step_(self.kind, flat.detach(), flat.grad, self.m, self.v, self.lr, self.opts.get(key, p1) if key else 0.0,
+                          self.opts.get('epsilon', self.opts.get('eps', eps)), wd=self.opts.get('wd', 0.0), rescale_grad=1.0 / batch_size)
         self.params.zero_grad()
 
 

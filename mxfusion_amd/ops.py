@@ -372,6 +372,15 @@ def sgd_step_(w, g, mom, lr, momentum=0.0, wd=0.0, rescale_grad=1.0):
               float(rescale_grad), _stream())
 
 
+OPT_KIND = {'rmsprop': 1, 'adagrad': 2, 'adadelta': 3, 'nag': 4}
+
+
+def opt_step_(kind, w, g, s1, s2, lr, p1, epsilon, wd=0.0, rescale_grad=1.0):
+    """MXNet 'rmsprop' / 'adagrad' / 'adadelta' / 'nag' on a flat buffer (mxf_opt_step); s1, s2: the rule's state buffers (s2: adadelta only)."""
+    _lib.call('mxf_opt_step', _h(w), OPT_KIND[kind], _dt(w), w.numel(), _p(w), _p(g), _p(s1), None if s2 is None else _p(s2), float(lr), float(p1),
+              float(epsilon), float(wd), float(rescale_grad), _stream())
+
+
 def gp_logpdf(kind, X, Y, noise_var, lengthscale, variance, ard, jitter=0.0, want_grad=False):
     """GPRegressionLogPdf.compute (gp_regression.py:42-76).  X (S|1,N,Q), Y (S|1,N,P) [minus mean], noise_var (S|1,1),
     lengthscale (S|1,Q|1), variance (S|1,1).  Returns dict(logL (S,), L (S,N,N), LinvY (S,N,P), info, grads...)."""

@@ -841,6 +841,38 @@ class MXNetAdam(object):
         return params
 
 
+class MXNetRule(object):
+    """MXNet 1.x 'rmsprop' (non-centred) / 'adagrad' / 'adadelta' / 'nag' update rules on one tensor (API knowledge of MXNet's python
+    optimisers; no reference-held vector: parity unpinned).  Checker of mxf_opt_step."""
+
+    def __init__(self, kind, lr, p1=None, epsilon=None, wd=0.0):
+        d = {'rmsprop': (0.9, 1e-8), 'adagrad': (0.0, 1e-7), 'adadelta': (0.9, 1e-5), 'nag': (0.0, 0.0)}[kind]
+        self.kind, self.lr, self.wd = kind, lr, wd
+        self.p1 = d[0] if p1 is None else p1
+        self.eps = d[1] if epsilon is None else epsilon
+        self.s1 = self.s2 = None
+
+    def step(self, w, grad, batch_size=1):
+        g = grad * (1.0 / batch_size)
+        if self.s1 is None:
+            self.s1, self.s2 = torch.zeros_like(w), torch.zeros_like(w)
+        if self.kind == 'rmsprop':
+            g = g + self.wd * w
+            self.s1 = (1 - self.p1) * g * g + self.p1 * self.s1
+            return w - self.lr * g / torch.sqrt(self.s1 + self.eps)
+        if self.kind == 'adagrad':
+            self.s1 = self.s1 + g * g
+            return w - self.lr * (g / torch.sqrt(self.s1 + self.eps) + self.wd * w)
+        if self.kind == 'adadelta':
+            self.s1 = self.p1 * self.s1 + (1 - self.p1) * g * g
+            d = torch.sqrt(self.s2 + self.eps) / torch.sqrt(self.s1 + self.eps) * g
+            self.s2 = self.p1 * self.s2 + (1 - self.p1) * d * d
+            return w - (d + self.wd * w)
+        g = g + self.wd * w
+        self.s1 = self.p1 * self.s1 + g
+        return w - self.lr * (g + self.p1 * self.s1)
+
+
 def run_map_gp_notebook(X, Y, max_iter=100, lr=0.05, record=(10, 20, 30, 40, 50, 60, 70, 80, 90, 100)):
     """Replays examples/notebooks/gp_regression.ipynb cells 10-14 through the oracle:
     RBF(1), variance=1, lengthscale=1, noise=0.01, Adam lr 0.05, 100 iterations.

@@ -300,3 +300,49 @@ def test_change_default_dtype():
         assert infr.params[m.mu].dtype == torch.float64 and infr.params[m.s].dtype == torch.float64
     finally:
         config.DEFAULT_DTYPE = old
+
+
+@pytest.mark.parametrize('name,opts', [('rmsprop', {}), ('adagrad', {}), ('adadelta', {'rho': 0.95}), ('nag', {'momentum': 0.9})])
+def test_trainer_seam_takes_the_other_mxnet_optimisers_by_name(name, opts):
+    """batch_loop.py:46-49 hands any optimiser NAME to gluon.Trainer; here 'rmsprop' / 'adagrad' / 'adadelta' / 'nag' drive the same fused
+    flat-buffer update (mxf_opt_step).  The GP notebook model, 5 MAP iterations through GradBasedInference.run: raw parameters against the oracle's
+    objective + the oracle's restatement of MXNet's rule (the reference holds no vector for these rules: API knowledge, parity unpinned)."""
+    from mxfusion_amd import Model, Variable
+    from mxfusion_amd.components.variables import PositiveTransformation
+    from mxfusion_amd.components.distributions.gp.kernels import RBF
+    from mxfusion_amd.modules.gp_modules import GPRegression
+    from mxfusion_amd.inference import GradBasedInference, MAP
+    from oracle import gp_oracle as O
+    rng = np.random.RandomState(0)
+    X = rng.uniform(-3., 3., (20, 1))
+    Y = np.sin(X) + rng.randn(20, 1) * 0.05
+    m = Model()
+    m.N = Variable()
+    m.X = Variable(shape=(m.N, 1))
+    m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=_t([0.01]))
+    m.kernel = RBF(input_dim=1, variance=_t([1.0]), lengthscale=_t([1.0]), dtype=DT)
+    m.Y = GPRegression.define_variable(X=m.X, kernel=m.kernel, noise_var=m.noise_var, shape=(m.N, 1), dtype=DT)
+    infr = GradBasedInference(inference_algorithm=MAP(model=m, observed=[m.X, m.Y]), dtype=DT)
+    infr.run(X=_t(X), Y=_t(Y), max_iter=5, learning_rate=0.05, optimizer=(name, opts) if opts else name)
+    kern = O.RBF(1, ARD=False)
+    raw = {'lengthscale': O.inv_softplus(O.T([1.0])), 'variance': O.inv_softplus(O.T([1.0])), 'noise_var': O.inv_softplus(O.T([0.01]))}
+    p1 = list(opts.values())[0] if opts else None
+    rules = {k: O.MXNetRule(name, 0.05, p1=p1) for k in raw}
+    for _ in range(5):
+        lv = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        O.map_gp_loss(kern, O.T(X), O.T(Y), lv).backward()
+        raw = {k: rules[k].step(lv[k].detach(), lv[k].grad) for k in lv}
+    sp = O.softplus
+    assert abs(float(infr.params[m.kernel.lengthscale]) - float(sp(raw['lengthscale']))) < 1e-9
+    assert abs(float(infr.params[m.kernel.variance]) - float(sp(raw['variance']))) < 1e-9
+    assert abs(float(infr.params[m.noise_var]) - float(sp(raw['noise_var']))) < 1e-9
+    assert abs(float(sp(raw['lengthscale'])) - 1.0) > 1e-3           # the rule moved the parameters
+
+
+def test_unknown_optimiser_name_is_refused():
+    from mxfusion_amd.inference.batch_loop import _Adam
+
+    class P(object):
+        flat = torch.zeros(3, device='cuda')
+    with pytest.raises(NotImplementedError):
+        _Adam(P(), 0.1, 'ftrl')

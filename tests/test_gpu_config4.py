@@ -21,7 +21,7 @@ def _t(a, dt=torch.float64):
     return torch.as_tensor(np.asarray(a), dtype=dt).cuda()
 
 
-def build_uncertain_input_svgp(N, Q, M, B, S, dtype, Z, loop=None, prior_var=1e-2):
+def build_uncertain_input_svgp(N, Q, M, B, S, dtype, Z, loop=None, prior_var=1e-2, lengthscale=1.0, kernel_cls=None):
     from mxfusion_amd import Model, Variable
     from mxfusion_amd.models.posterior import Posterior
     from mxfusion_amd.components.variables import PositiveTransformation
@@ -35,7 +35,7 @@ def build_uncertain_input_svgp(N, Q, M, B, S, dtype, Z, loop=None, prior_var=1e-
     m.X = Normal.define_variable(mean=m.Xobs, variance=prior_var, shape=(m.N, Q), dtype=dtype)
     m.Z = Variable(shape=(M, Q), initial_value=Z)
     m.noise_var = Variable(shape=(1,), transformation=PositiveTransformation(), initial_value=0.01)
-    kernel = RBF(input_dim=Q, ARD=True, variance=1., lengthscale=np.ones(Q), dtype=dtype)
+    kernel = (kernel_cls or RBF)(input_dim=Q, ARD=True, variance=1., lengthscale=np.full(Q, float(lengthscale)), dtype=dtype)
     m.Y = SVGPRegression.define_variable(X=m.X, kernel=kernel, noise_var=m.noise_var, inducing_inputs=m.Z, shape=(m.N, 1), dtype=dtype)
     m.Y.factor.svgp_log_pdf.jitter = 1e-6
     q = Posterior(m)

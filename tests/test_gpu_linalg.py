@@ -253,6 +253,18 @@ def test_elementwise_kernels(dtype, tol):
                 wr = wr - 0.05 * gi
             ops.sgd_step_(wdev, _dev(g, dtype), mdev, 0.05, momentum=momentum, wd=wdecay, rescale_grad=0.25)
         assert np.allclose(wdev.cpu().numpy(), wr, rtol=tol * 10, atol=tol * 10)
+    # the other rules the Trainer seam takes by name (mxf_opt_step): MXNet 'rmsprop' / 'adagrad' / 'adadelta' / 'nag' vs the oracle's restatement,
+    # 4 steps with weight decay and rescale_grad = 1 / batch_size
+    for kind, p1 in (('rmsprop', 0.9), ('adagrad', 0.0), ('adadelta', 0.9), ('nag', 0.8)):
+        w0 = rng.randn(300)
+        rule = O.MXNetRule(kind, 0.05, p1=p1, wd=1e-2)
+        wr = O.T(w0)
+        wdev, s1, s2 = _dev(w0, dtype), torch.zeros(300, dtype=dtype).cuda(), torch.zeros(300, dtype=dtype).cuda()
+        for t in range(4):
+            g = rng.randn(300)
+            wr = rule.step(wr, O.T(g), batch_size=4)
+            ops.opt_step_(kind, wdev, _dev(g, dtype), s1, s2 if kind == 'adadelta' else None, 0.05, p1, rule.eps, wd=1e-2, rescale_grad=0.25)
+        assert np.allclose(wdev.cpu().numpy(), wr.numpy(), rtol=tol * 20, atol=tol * 20), kind
 
 
 def test_potrf_is_race_free_under_cu_contention():

@@ -23,14 +23,15 @@ class _SharedNoise(object):
         return torch.randn(tuple(shape), dtype=torch.float64, device='cuda', generator=self.gen).to(config.torch_dtype(dtype))
 
 
-def _train(dtype, X, Y, Z, B, S, steps, lr):
+def _train(dtype, X, Y, Z, B, S, steps, lr, lengthscale=1.0, kernel_cls=None):
     from tests.test_gpu_config4 import build_uncertain_input_svgp
     from mxfusion_amd.inference.batch_loop import _Adam
     from mxfusion_amd.modules.gp_modules._fused import Float32Guard
     N, Q = X.shape
     M = Z.shape[0]
     td = torch.float32 if dtype == 'float32' else torch.float64
-    m, q, infr, loop, kernel = build_uncertain_input_svgp(N, Q, M, B, S, dtype, torch.as_tensor(Z, dtype=td).cuda())
+    m, q, infr, loop, kernel = build_uncertain_input_svgp(N, Q, M, B, S, dtype, torch.as_tensor(Z, dtype=td).cuda(), lengthscale=lengthscale,
+                                                          kernel_cls=kernel_cls)
     post = m.Y.factor._extra_graphs[0]
     infr.params[post.qU_mean] = torch.zeros(M, 1, dtype=td).cuda()
     infr.params[post.qU_cov_W] = torch.zeros(M, M, dtype=td).cuda()
@@ -123,6 +124,95 @@ def test_full_batch_latent_input_model_100_steps_float32_tracks_float64():
     prel = {k: float(np.abs(np.asarray(r32[k]) - np.asarray(r64[k])).max() / np.abs(np.asarray(r64[k])).max()) for k in ('ls', 'var', 'noise', 'xm')}
     print('\nfull batch: loss f64 first / last %.6e / %.6e; trajectory max rel diff %.2e; parameters %s; float32 ended on %s (cond max %.2e)'
           % (r64['loss'][0], r64['loss'][-1], rel.max(), {k: '%.1e' % v for k, v in prel.items()}, r32['tier'], r32['cond']))
+    assert r64['loss'][-1] < r64['loss'][0]
+    assert rel.max() <= 1e-4, rel.max()
+    assert max(prel.values()) <= 1e-3, prel
+
+
+# ---- the same comparison where the other float32 forms / kernels / compositions run from the first step ---------------
+def _compare(r32, r64, keys, what):
+    rel = np.abs(r32['loss'] - r64['loss']) / np.abs(r64['loss'])
+    prel = {k: float(np.abs(np.asarray(r32[k]) - np.asarray(r64[k])).max() / np.abs(np.asarray(r64[k])).max()) for k in keys}
+    print('\n%s: loss f64 first / last %.6e / %.6e; trajectory max rel diff %.2e (step %d); learned parameters %s; float32 ended on %s (cond max %.2e)'
+          % (what, r64['loss'][0], r64['loss'][-1], rel.max(), int(rel.argmax()), {k: '%.1e' % v for k, v in prel.items()}, r32.get('tier'), r32.get('cond', 0.0)))
+    return rel, prel
+
+
+def test_training_that_starts_in_the_whitened_regime_tracks_float64():
+    """Length-scale 2.2 from the first step (where a trained model of this family ends: cond_1(Kuu) ~ 2e4): the guard's synchronous first-call
+    check moves the module to the WHITENED float32 form at step 0 and the whole run stays there -- V = L^-1 Kuf, Phi = V V^T and T = Hh V on
+    the f16x2 matrix-pipe kernels (r06: T and U from the planes of V, gemm_bt.hip).  100 Adam steps against float64, same bars as above."""
+    import bench
+    N, Q, M, B, S, steps, lr = 65536, 8, 1024, 8192, 4, 100, 1e-2
+    X, Y, Z = bench.synth(N, Q, M)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r32 = _train('float32', X, Y, Z, B, S, steps, lr, lengthscale=2.2)
+        r64 = _train('float64', X, Y, Z, B, S, steps, lr, lengthscale=2.2)
+    assert r32['info'] == 0 and r64['info'] == 0
+    rel, prel = _compare(r32, r64, ('ls', 'var', 'noise', 'qx', 'mu'), 'whitened from step 0')
+    assert r32['tier'] == 'whitened float32' and r32['cond'] > 1e3, (r32['tier'], r32['cond'])
+    assert r64['loss'][-1] < r64['loss'][0]
+    assert rel.max() <= 1e-4, rel.max()
+    assert max(prel['ls'], prel['var'], prel['noise'], prel['qx']) <= 1e-3, prel
+    assert prel['mu'] <= 5e-3, prel
+
+
+def test_matern52_training_in_float32_tracks_float64():
+    """Matern52 (difference-form reverse pass, clip 1e-14: matern.py:84-88): 100 Adam steps of the same model, float32 against float64."""
+    import bench
+    from mxfusion_amd.components.distributions.gp.kernels import Matern52
+    N, Q, M, B, S, steps, lr = 65536, 8, 1024, 8192, 4, 100, 1e-2
+    X, Y, Z = bench.synth(N, Q, M)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r32 = _train('float32', X, Y, Z, B, S, steps, lr, lengthscale=1.5, kernel_cls=Matern52)
+        r64 = _train('float64', X, Y, Z, B, S, steps, lr, lengthscale=1.5, kernel_cls=Matern52)
+    assert r32['info'] == 0 and r64['info'] == 0
+    rel, prel = _compare(r32, r64, ('ls', 'var', 'noise', 'qx', 'mu'), 'Matern52')
+    assert r64['loss'][-1] < r64['loss'][0]
+    assert rel.max() <= 1e-4, rel.max()
+    assert max(prel['ls'], prel['var'], prel['noise'], prel['qx']) <= 1e-3, prel
+    assert prel['mu'] <= 5e-3, prel
+
+
+def _train_deepgp(dtype, N, Q, M, Dh, S, steps, lr):
+    import bench
+    from mxfusion_amd.inference.batch_loop import _Adam
+    from mxfusion_amd.modules.gp_modules._fused import Float32Guard
+    td = torch.float32 if dtype == 'float32' else torch.float64
+    X, Y, _ = bench.synth(N, Q, M)
+    infr, loop = bench.build_deepgp(N, Q, M, Dh, S, dtype, X, Y, False)
+    m = infr._inference_algorithm.model
+    q = infr._inference_algorithm.posterior
+    q[m.H].factor._rand_gen = _SharedNoise(79)
+    data = [torch.as_tensor(X, dtype=td).cuda(), torch.as_tensor(Y, dtype=td).cuda()]
+    ex = infr.create_executor()
+    opt = _Adam(infr.params, lr)
+    losses = []
+    for _ in range(steps):
+        losses.append(loop.step(ex, data, infr.params).detach().double())
+        opt.step()
+    torch.cuda.synchronize()
+    rep = Float32Guard.report(torch.device('cuda', torch.cuda.current_device()))
+    k1 = m.Y.factor.kernel
+    out = dict(loss=torch.stack(losses).cpu().numpy(), ls_top=infr.params[k1.lengthscale].double().cpu().numpy(), var_top=float(infr.params[k1.variance]),
+               noise0=float(infr.params[m.noise0]), noise1=float(infr.params[m.noise1]), hm=infr.params[q[m.H].factor.mean].double().cpu().numpy(),
+               tier=str(rep.get('float32_tiers')), cond=rep.get('kuu_cond_max', 0.0))
+    del infr, ex, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_two_layer_deep_gp_training_in_float32_tracks_float64():
+    """BASELINE configs[4]'s composition at reduced size (N = 16 384, Q = 16, M = 256 per layer, 2 hidden columns, 4 samples): Matern52 + RBF first
+    layer (materialised combination-kernel path), RBF-ARD second layer on the sampled hidden layer, mean-field q(H); 60 Adam steps."""
+    N, Q, M, Dh, S, steps, lr = 16384, 16, 256, 2, 4, 60, 1e-2
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        r32 = _train_deepgp('float32', N, Q, M, Dh, S, steps, lr)
+        r64 = _train_deepgp('float64', N, Q, M, Dh, S, steps, lr)
+    rel, prel = _compare(r32, r64, ('ls_top', 'var_top', 'noise0', 'noise1', 'hm'), 'two-layer deep GP')
     assert r64['loss'][-1] < r64['loss'][0]
     assert rel.max() <= 1e-4, rel.max()
     assert max(prel.values()) <= 1e-3, prel
