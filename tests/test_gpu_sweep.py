@@ -38,7 +38,7 @@ def _case(rng, large=False):
 def test_svgp_module_call_random_case(seed):
     """seeds 0-23: the r04 slice (small problems -- since r05 evaluated in float64 inside, SVGPRegressionLogPdf.SMALL_F64_ELEMS); seeds 100-115:
     problems large enough to run the float32 forms.  The FLOAT32 call is held to north_star's 1e-5 on the bound against the ORACLE (the
-    host evaluates every case here); r06: its gradients are compared with the ORACLE's autograd, normwise per parameter (5e-3; the float64
+    host evaluates every case here); r06: its gradients are compared with the ORACLE's autograd, normwise per parameter (2e-4; the float64
     call's to 1e-7), and every case's figures are recorded."""
     from mxfusion_amd.components.distributions.gp.kernels import RBF, Matern12, Matern32, Matern52
     from mxfusion_amd.modules.gp_modules.svgp_regression import SVGPRegressionLogPdf
@@ -92,7 +92,9 @@ def test_svgp_module_call_random_case(seed):
     e32 = {k: nrm(a, b) for k, a, b in zip(names, g32, gref)}
     _record(seed, tag, e32, e64)
     assert max(e64.values()) <= max(1e-7, 1e-11 * cond), (tag, e64)                   # the float64 call's gradients ARE the oracle's
-    assert max(e32.values()) <= 5e-3, (tag, e32)                                      # float32 gradients against the oracle, normwise per parameter
+    # float32 gradients against the oracle, normwise per parameter (measured worst over the slice: 1.1e-5, profiles/r06_sweep_gradient_errors.json;
+    # until r05 this line compared with the HIP float64 call at 5e-3)
+    assert max(e32.values()) <= 2e-4, (tag, e32)
 
 
 def _record(seed, tag, e32, e64):
