@@ -942,7 +942,15 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     (void)hipStreamIsCapturing(st, &cap);
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
     hipStream_t ax = look ? h->potrf_aux : st;
-    bool pending_b = false, pending_h = false;
+    bool pending_b = false, pending_h = false, pending_r = false;
+    // r06, measured and NOT kept -- probe knob MXF_POTRF_ROWS2=1: only the NEXT panel's eight block rows of the rows below
+    // an outer panel are on the serial path (its diagonal block's head update reads them), so the rows further down are solved on a stream
+    // of their own next to that head update and the next chain, and the auxiliary stream's products -- the only readers of those rows --
+    // wait for them.  Correct (tests/test_gpu_linalg.py passes either way), but same box, alternating: potrf(8192) 6.65 / 6.67 ms with it,
+    // 6.57 / 6.60 without; exact-GP MAP step 14.64-14.67 against 14.52-14.53 ms -- the hundred far-row workgroups now run NEXT TO the next
+    // panel's latency-bound chain and head update instead of before them, and the chain pays more than the shorter path saves (the same
+    // outcome as r03's rows kernel following the chain's progress counters and r05's per-panel eager inverse).
+    static const int rows2_env = MXF_KNOB("MXF_POTRF_ROWS2", 0);
     // row blocks of FOUR outer panels (2048 rows), from four row blocks on.  Measured at n = 8192 (MAP step of the exact GP, two alternating rounds,
     // profiles/r05_potrf_eager_inverse_ab.txt): off 15.0 ms; every panel 18.1 (208 more launches, and products of a few tiles each that hold CUs the
     // chain's tile workgroups are waiting for); every second 14.6-14.7; every fourth 14.5; two halves 15.0; leaving the products 64 / 128 CUs less changes nothing
@@ -981,8 +989,20 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 hipLaunchKernelGGL(potrf_tiles_kernel, dim3(na, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, 0, 0);
                 const int rows_env = rows_env_g;
                 // (the rows below this panel's diagonal block were updated on the auxiliary stream, next to the chain above)
+                const bool had_h = pending_h;
                 if (pending_h) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0)); pending_h = false; }
                 if (split && rows_env) {       // r03: the rows below right-looking from registers (potrf_rows_kernel)
+                    const unsigned nbel = nbr - npt, nfirst = (unsigned)(NBO / NB) < nbel ? (unsigned)(NBO / NB) : nbel;
+                    if (rows2_env && look && head_split_env && nbel >= nfirst + 16 && pe + NBO < n) {
+                        if (had_h) MXF_HIP(h, hipStreamWaitEvent(h->potrf_rows, h->ev_ph, 0));      // (their columns' head update, auxiliary stream)
+                        MXF_HIP(h, hipEventRecord(h->ev_pc, st));                                   // the chain of this panel (and all before it)
+                        MXF_HIP(h, hipStreamWaitEvent(h->potrf_rows, h->ev_pc, 0));
+                        hipLaunchKernelGGL(potrf_rows_kernel, dim3(nfirst, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
+                        hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbel - nfirst, (unsigned)S), dim3(512), 0, h->potrf_rows, A, lda, sA, c0, (int)npt,
+                                           (int)(npt + nfirst), (const double*)pinv);
+                        MXF_HIP(h, hipEventRecord(h->ev_rb, h->potrf_rows));
+                        pending_r = true;
+                    } else
                     hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbr - npt, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
                 } else if (split)
                     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr - npt, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, (int)npt, 1);
@@ -1016,7 +1036,12 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         if (pe < n) {   // trailing update, lower blocks only: A22 -= L21 L21^T with K = panel width
             const int64_t pe2 = (pe + NBO < n) ? pe + NBO : n, K = pe - c0;
             if (pending_b) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0)); pending_b = false; }   // the previous rest-update touched these columns
+            // the far rows of this panel (potrf_rows stream): every product below except the next diagonal block's head update reads them
+            const bool far_rows = pending_r;
+            if (far_rows) MXF_HIP(h, hipStreamWaitEvent(ax, h->ev_rb, 0));
+            pending_r = false;
             if (!look || pe2 >= n) {
+                if (far_rows) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_rb, 0));
                 int rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe, n - pe, K, -1.0, A + pe * lda + c0, lda, sA,
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe * lda + pe, lda, sA, S, 1, st);
                 if (rc) return rc;
@@ -1038,6 +1063,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                     MXF_HIP(h, hipEventRecord(h->ev_ph, ax));
                     pending_h = true;
                 } else {
+                    if (far_rows) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_rb, 0));
                     rc = mxf_gemm_internal(h, dtype, 0, 1, n - pe2, pe2 - pe, K, -1.0, A + pe2 * lda + c0, lda, sA,
                                            A + pe * lda + c0, lda, sA, 1.0, A + pe2 * lda + pe, lda, sA, S, 0, st);
                     if (rc) return rc;
@@ -1058,6 +1084,7 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pj, 0));
         if (eager_done) *eager_done = true;
     }
+    if (pending_r) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_rb, 0));
     if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
     if (pending_h) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0));      // (never pending here today: the last panel has no successor; kept so that the caller's stream always joins the auxiliary one)
     if (n > 1 && zero_upper) {      // (internal callers that only ever read the lower triangle skip this pass)

@@ -78,6 +78,8 @@ struct mxf_ctx {
     hipEvent_t ev_pa = nullptr, ev_pb = nullptr, ev_ph = nullptr;
     hipStream_t potrf_inv = nullptr;                        // r05: the inverse of the factor, row block by row block NEXT TO the factorisation (chol.hip)
     hipEvent_t ev_pi = nullptr, ev_pj = nullptr;
+    hipStream_t potrf_rows = nullptr;                       // r06: the rows FAR below an outer panel are solved here, next to the next panel's chain
+    hipEvent_t ev_pc = nullptr, ev_rb = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
@@ -203,11 +205,14 @@ static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
     if (!ok) h->potrf_aux = nullptr;
     ok = ok && hipStreamCreateWithFlags(&h->potrf_inv, hipStreamNonBlocking) == hipSuccess;
     if (!ok) h->potrf_inv = nullptr;
-    hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj};
+    ok = ok && hipStreamCreateWithFlags(&h->potrf_rows, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) h->potrf_rows = nullptr;
+    hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj, &h->ev_pc, &h->ev_rb};
     for (hipEvent_t* e : evs)
         if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; ok = false; }
     if (!ok) {
         for (hipEvent_t* e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        if (h->potrf_rows) { (void)hipStreamDestroy(h->potrf_rows); h->potrf_rows = nullptr; }
         if (h->potrf_inv) { (void)hipStreamDestroy(h->potrf_inv); h->potrf_inv = nullptr; }
         if (h->potrf_aux) { (void)hipStreamDestroy(h->potrf_aux); h->potrf_aux = nullptr; }
         return false;

@@ -43,6 +43,9 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->potrf_inv) (void)hipStreamDestroy(h->potrf_inv);
     if (h->ev_pi) (void)hipEventDestroy(h->ev_pi);
     if (h->ev_pj) (void)hipEventDestroy(h->ev_pj);
+    if (h->potrf_rows) (void)hipStreamDestroy(h->potrf_rows);
+    if (h->ev_pc) (void)hipEventDestroy(h->ev_pc);
+    if (h->ev_rb) (void)hipEventDestroy(h->ev_rb);
     delete h;
     return 0;
 }
