@@ -1011,8 +1011,15 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         // row block [rb0, pe) of L is final once the panel ending at pe has been factored (the rows above it in these columns are zero).  Row blocks
         // of eager_rb outer panels (probe knob MXF_POTRF_EAGER_INV: 1 = every panel, 2 = every second, ..., 100 = two halves)
         const int64_t rbw = eager_env >= 100 ? n / 2 : (int64_t)eager_env * NBO;
-        if (eager && (pe % rbw == 0 || pe == n)) {
-            const int64_t rb0 = (pe - 1) / rbw * rbw;
+        // r06 probe knob MXF_POTRF_EAGER_TAIL = t > 0: behind the first 3/4 of the rows the row blocks shrink to t outer panels -- the last
+        // block is what stays exposed behind the factorisation (2.5 ms of the 14.6 ms MAP step at n = 8192 with blocks of four panels), and
+        // the late panels are chain-bound, i.e. the chip is mostly idle next to them
+        static const int tail_env = MXF_KNOB("MXF_POTRF_EAGER_TAIL", 0);
+        const int64_t tail0 = (n * 3 / 4) / rbw * rbw, tbw = (int64_t)tail_env * NBO;
+        const bool in_tail = tail_env > 0 && eager_env < 100 && tbw < rbw && pe > tail0;
+        const bool fire = in_tail ? ((pe - tail0) % tbw == 0 || pe == n) : (pe % rbw == 0 || pe == n);
+        if (eager && fire) {
+            const int64_t rb0 = in_tail ? tail0 + (pe - tail0 - 1) / tbw * tbw : (pe - 1) / rbw * rbw;
             MXF_HIP(h, hipEventRecord(h->ev_pi, st));
             MXF_HIP(h, hipStreamWaitEvent(h->potrf_inv, h->ev_pi, 0));
             if constexpr (sizeof(T) == 8) {

@@ -1085,16 +1085,17 @@ __device__ __forceinline__ void wide_body(const SplitArgs& g) {
 // halves;  _256w4: 256 x 256 by four 512-register waves;  _256pp: eight waves, ping-pong phases.  (The last two are measured alternatives
 // kept for the probe build)
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128(SplitArgs g) { wide_body<4, 1, false>(g); }
-__global__ __launch_bounds__(256, 1) void gemm_f16x2_wide_kernel_256w4(SplitArgs g) { wide_body<8, 1, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256(SplitArgs g) { wide_body<4, 2, false>(g); }
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256lo(SplitArgs g) { wide_body<4, 2, false, true, true>(g); }
 #ifdef MXF_PROBES
+// measured alternatives and killed experiments: in the PROBE library only (r06; until r05 they were compiled into the shipped one)
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_wide_kernel_256w4(SplitArgs g) { wide_body<8, 1, false>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pp(SplitArgs g) { wide_body<4, 2, true>(g); }
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256b1(SplitArgs g) { wide_body<4, 2, false, false>(g); }
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256bf(SplitArgs g) { wide_body<4, 2, false, true, false, false, true>(g); }
-#endif
-// the T product of the SVGP training call with the reverse pass as its epilogue (r05)
+// the T product of the SVGP training call with the reverse pass as its epilogue (r05: correct, twice as slow -- 309 spilled registers)
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256fz(SplitArgs g) { wide_body<4, 2, false, true, false, false, false, true>(g); }
+#endif
 // planes-output forms (c_blk == 2; the whitened SVGP tier's V = L^-1 Kuf)
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_wide_kernel_256pl(SplitArgs g) { wide_body<4, 2, false, true, false, true>(g); }
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_wide_kernel_128pl(SplitArgs g) { wide_body<4, 1, false, true, false, true>(g); }
@@ -1181,7 +1182,11 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
     // rows per tile of the wide kernel: 256 when the shape allows, else 128 (four waves, two workgroups per CU).  MXF_SPLIT_XT: 4 = always
     // 128; 8 = 256 rows by four 512-register waves (one per SIMD); 16 (default) = 256 rows by eight waves, two row halves (two per SIMD)
     static const int xt_env = (int)MXF_KNOB("MXF_SPLIT_XT", 16);
+#ifdef MXF_PROBES
     const int XT = (wide && !Cplanes && !fuse && xt_env == 8 && (M % 256) == 0) ? 8 : 4;
+#else
+    const int XT = 4;
+#endif
     const int NH = (wide && (xt_env == 16 || Cplanes || fuse) && (M % 256) == 0) ? 2 : 1;
     const int64_t WBMh = 32 * XT * NH;
     int64_t tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
@@ -1278,14 +1283,19 @@ int mxf_gemm_split_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double 
         static const int bfi_env = (int)MXF_KNOB("MXF_SPLIT_BF16MFMA", 0);
         if (bfi_env && NH == 2 && !Cplanes && !lower_only) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256bf, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
 #endif
-        if (fuse) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256fz, dim3((unsigned)grid), dim3(512), 0, st, g);
-        else if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
+#ifdef MXF_PROBES
+        if (fuse) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256fz, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
+        if (!Cplanes && NH == 2 && bhi_env && c_blocked) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
+        if (!Cplanes && NH == 2 && pp_env) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
+        if (!Cplanes && NH != 2 && XT == 8) { hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256w4, dim3((unsigned)grid), dim3(256), 0, st, g); MXF_LAUNCH_CHECK(h); return 0; }
+#else
+        if (fuse) MXF_FAIL(h, -3, "mxf_gemm_split: the fused reverse pass exists in the probe build only");
+        (void)bhi_env; (void)pp_env;
+#endif
+        if (Cplanes && NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pl, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (Cplanes) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128pl, dim3((unsigned)grid), dim3(256), 0, st, g);
-        else if (NH == 2 && bhi_env && c_blocked) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256b1, dim3((unsigned)grid), dim3(512), 0, st, g);
-        else if (NH == 2 && pp_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256pp, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2 && lower_only && lskip_env) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256lo, dim3((unsigned)grid), dim3(512), 0, st, g);
         else if (NH == 2) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256, dim3((unsigned)grid), dim3(512), 0, st, g);
-        else if (XT == 8) hipLaunchKernelGGL(gemm_f16x2_wide_kernel_256w4, dim3((unsigned)grid), dim3(256), 0, st, g);
         else hipLaunchKernelGGL(gemm_f16x2_wide_kernel_128, dim3((unsigned)grid), dim3(256), 0, st, g);
         MXF_LAUNCH_CHECK(h);
         return 0;
