@@ -45,6 +45,7 @@ struct BtArgs {
     const unsigned* maxbits2;            // the same for the Bt planes (nullptr: Gram planes, whose scale is known: alpha / ad0 carry it)
     unsigned* maxout;                    // atomicMax of the bit pattern of max |C| (nullptr: none)
     unsigned* sync; int sync_n;          // rendezvous of the tm row tiles of a column strip (gemm_split.hip: wg_rendezvous)
+    int sync_every;                      // ... in every sync_every-th persistent round only: bounds the drift of the tiles that share a strip's lines in L2
     // U row: w as two f16 planes [2][16 K16] (hi, lo of w * scale_from_maxbits(uwmax[0])), U[n] = uscale * ad0[0] / that scale * sum
     const unsigned short* uw; const unsigned* uwmax; float* uout; float uscale;
 };
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
             const unsigned tile_n = wid / tmu, tile_m = wid - tile_n * tmu;                                                         \
             m0 = (int64_t)tile_m * 256; n0 = (int64_t)tile_n * 256;                                                                 \
             uitem = WU && g.uout != nullptr && ((tile_n + (tile_n >> 3) + (tile_n >> 6)) % tmu) == tile_m;                          \
-            if (g.sync) bt_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);                                       \
+            if (g.sync && (c_it % g.sync_every) == 0) bt_rendezvous(g.sync + wid / g.sync_n, (unsigned)g.sync_n, patience);         \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                           \
                 _Pragma("unroll") for (int y = 0; y < 2; ++y)                                                                       \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) c[x][y][r] = 0.f;                                                \
@@ -396,14 +397,19 @@ int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alp
     int64_t grid = (int64_t)(256 - (reserve_cus > 0 ? reserve_cus : 0)) / 8 * 8;
     if (grid < 8) grid = 8;
     if (g.nwg <= grid) grid = g.nwg;
-    // (the tm row tiles of a column strip CAN start together -- bounded rendezvous, as in gemm_split.hip -- so that they share the strip's Bt
-    //  lines in their XCD's L2.  Measured with the request stream running across items (r06, same box, 32 samples): 22.6-22.8 ms per step
-    //  with it, 22.4-22.5 without -- the requests of an item are in flight before its rendezvous anyway.  Off; probe knob MXF_BT_SYNC=1.)
-    static const int sync_env = (int)MXF_KNOB("MXF_BT_SYNC", 0);
+    // The tm row tiles of a column strip (tm consecutive items of one XCD's run, taken in the same persistent round by tm different
+    // workgroups) share the strip's Bt lines in their XCD's L2 -- as long as they run in step.  Nothing keeps them there: with no pacing
+    // at all they drift apart and every one fetches the strip from HBM itself (r06 PMC: 50 GB of traffic per launch against 26 GB of
+    // operands + output).  A bounded rendezvous (gemm_split.hip) at the start of an item re-aligns them.  Same box, T shape, traffic per
+    // launch | 32-sample step: never 49.9 GB | 22.04-22.09 ms; every item 23.1 GB | 22.31; every 4th round 32.1 GB | 22.07; 8th 33.0 | 22.02-22.06;
+    // 16th 34.1 | 22.06 (tests/probes/r06_bt_sync.sh).  Every fourth round: two thirds of the avoidable traffic gone at no cost in time.
+    // (MXF_BT_SYNC = rounds between two rendezvous, 0 = never; probe builds.)
+    static const int sync_env = (int)MXF_KNOB("MXF_BT_SYNC", 4);
     const int64_t q = g.nwg / 8, per_xcd = grid / 8;
     if (sync_env && g.tm >= 2 && g.nwg % 8 == 0 && g.nwg >= 16 && q % g.tm == 0 && per_xcd % g.tm == 0 && (g.nwg <= grid || g.nwg % grid == 0)) {
         g.sync = mxf_gsync(h, (unsigned)(g.nwg / g.tm));
         g.sync_n = (int)g.tm;
+        g.sync_every = sync_env > 0 ? sync_env : 1;
     }
 #ifdef MXF_PROBES
     // RA (register read-ahead of the next block's Bt fragments + first A fragment, requests two blocks ahead) against the default (fragments
