@@ -931,6 +931,16 @@ def main():
         run_s = time_minibatch_run(infr, {'Xobs': Xd_, 'Y': Yd_}, max(2, args.steps // (N // B)), args.lr, distributed)
         rep = dist_report(world, args.steps, infr.params.flat.numel(), td)          # collective: every rank
         rep["ms_per_step_through_run"] = run_s * 1e3
+        if world == 1 and not args.no_extras and args.samples % 8 == 0 and args.samples >= 8:
+            # one rank's share of an 8-GPU run of this config on THIS GPU (samples / 8, no collective): the projection the scaling curve will be
+            # read against -- the sample-independent M x M chain is the floor of a rank's step
+            del infr, m, loop
+            torch.cuda.empty_cache()
+            m8, infr8, loop8 = build_minibatch(N, Q, M, B, args.samples // 8, args.dtype, Z)
+            dt8, _ = time_minibatch_steps(infr8, loop8, Xd_, Yd_, B, args.steps, args.warmup, args.lr, False)
+            rep["per_rank_proxy"] = {"samples": args.samples // 8, "ms_per_step": dt8 / args.steps * 1e3,
+                                     "projected_speedup_8gpu": dt / dt8, "note": "one GPU evaluating one rank's share; before the all-reduce"}
+            m = m8
         if rank == 0:
             emit(dict({"metric": "ELBO-steps/sec (minibatch steps), SVGP N=65k D=8 M=1024 minibatch=%d (BASELINE.json configs[3])" % B,
                   "value": args.steps / dt, "unit": "ELBO-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -992,6 +1002,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         del infr, m, q
         torch.cuda.empty_cache()
+        if args.samples % 8 == 0 and args.samples >= 8 and not args.trained_like:
+            # one rank's share of an 8-GPU run (samples / 8) on THIS GPU, no collective: what the 1 -> 8 curve will be read against
+            m8, q8, infr8, loop8, _ = build(N, Q, M, args.samples // 8, args.dtype, X, Y, Z, False)
+            dt8, _ = time_steps(infr8, loop8, Yd, max(args.steps, 10), max(args.warmup, 3), args.lr, False)
+            out["per_rank_proxy"] = {"samples": args.samples // 8, "ms_per_step": dt8 / max(args.steps, 10) * 1e3,
+                                     "projected_speedup_8gpu": (dt / args.steps) / (dt8 / max(args.steps, 10)),
+                                     "note": "one GPU evaluating one rank's share; before the all-reduce (allreduce of the 8.4 MB flat gradient: ~0.1 ms on a ring over xGMI)"}
+            del infr8, m8, q8
+            torch.cuda.empty_cache()
         out["other_boxes"] = box_spread()
         out["roofline"] = gram_roofline(N, Q, args.dtype)
         out["roofline_mfma"] = mfma_roofline(M, N * S_local, args.dtype)
