@@ -1011,6 +1011,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     // ---- main stream: Kuu -> L -> L^-1 -> Ki, w (the critical path up to the T GEMM) --------------------------------------------
     // condition number of Kuu + jitter I (1-norm), for the float32 validity check of mxf_svgp_last_cond: |Kuu|_1 here, |Ki|_1 below
+    // r06 probe knob MXF_SVGP_CHAIN_LATE (one-planes path, many samples): the Kuu chain (2: the Su chain too) starts only when the planes pass is
+    // done.  A profiler timeline shows the planes pass at 2.17 instead of 1.7 ms next to the chains -- without the profiler it takes 1.79 ms
+    // either way and the step does not move (same box: 22.60-22.69 / 22.66-22.77 / 22.60-22.70 ms for 0 / 1 / 2).  Off.
+    static const int chain_late = (int)MXF_KNOB("MXF_SVGP_CHAIN_LATE", 0);
+    const bool late = chain_late && bt_path && want_grad && SB > 2 * 192 * M;
+    if (late) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
@@ -1094,6 +1100,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
     // (a plain kernel, not hipMemcpyAsync: the runtime's copy path sat idle for ~1 ms before it started next to busy queues -- r02 timeline:
     //  the Su chain did not begin until 1.66 ms although nothing in the Kuu chain feeds it)
+    if (late && chain_late >= 2) MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_aux, 0));
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, s2_, (int64_t)1, MM, (const D*)Su, MM, tmp, MM);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, tmp, M, MM, info2, s2_, false, false);                  // Ls = chol(Su) :84
     if (rc) return rc;

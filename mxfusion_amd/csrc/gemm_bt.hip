@@ -99,7 +99,7 @@ __device__ __forceinline__ float bt_dot8(u32x4 a, u32x4 b, float acc) {
 constexpr int BT_KMAX16 = 128;           // U row: w planes of up to 2048 k live in LDS
 
 // 256 x 256 tile, 512 threads: wave = 4 h + w owns rows [128 h, + 128) x columns [64 w, + 64) = 4 x 2 MFMA tiles (128 accumulators).
-template <bool WU, bool RA = false>
+template <bool WU, bool RA = false, bool PM = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     constexpr int NU = 512;                          // 16-byte units of one plane's (256 x 16) slab
     __shared__ u32x4 sA[4][2][NU];                   // [ring slot][plane][unit]: A rows, gemm_split.hip's swizzled image
@@ -217,6 +217,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
             c[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AH), c[x][y], 0, 0, 0);          /* hi' hi */         \
         }                                                                                                                           \
     } while (0)
+#define BT_MM2(x0, AH0, AL0, x1, AH1, AL1, FB)                                                                                      \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                             \
+            c[x0][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AL0), c[x0][y], 0, 0, 0);                            \
+            c[x1][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AL1), c[x1][y], 0, 0, 0);                            \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                             \
+            c[x0][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][1]), HF(AH0), c[x0][y], 0, 0, 0);                            \
+            c[x1][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][1]), HF(AH1), c[x1][y], 0, 0, 0);                            \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int y = 0; y < 2; ++y) {                                                                             \
+            c[x0][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AH0), c[x0][y], 0, 0, 0);                            \
+            c[x1][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(FB[y][0]), HF(AH1), c[x1][y], 0, 0, 0);                            \
+        }                                                                                                                           \
+    } while (0)
     // one stream position: CUR holds block s_ (its Bt fragments and A fragment 0), NXT receives block s_ + 1
 #define BT_STEP(FB, FA, NFB, NFA)                                                                                                   \
     do {                                                                                                                            \
@@ -243,6 +258,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
                 ua1 = bt_dot8(FB[1][1], wh_, ua1); ua1 = bt_dot8(FB[1][0], wl_, ua1); ua1 = bt_dot8(FB[1][0], wh_, ua1);            \
             }                                                                                                                       \
         }                                                                                                                           \
+        if constexpr (PM) {                                                                                                         \
+            /* (measured alternative, probe knob MXF_BT_PM) product-major in PAIRS of row fragments: four independent MFMAs between two that share an */ \
+            /* accumulator -- same box, 32-sample step 22.38-22.46 ms against 22.31-22.35: back-to-back accumulation is not what stalls the pipe    */ \
+            u32x4 a1h = sA[c_slot][0][ua_(1)], a1l = sA[c_slot][1][ua_(1)];                                                           \
+            u32x4 a2h = sA[c_slot][0][ua_(2)], a2l = sA[c_slot][1][ua_(2)];                                                           \
+            u32x4 a3h = sA[c_slot][0][ua_(3)], a3l = sA[c_slot][1][ua_(3)];                                                           \
+            BT_MM2(0, FA[0], FA[1], 1, a1h, a1l, FB);                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            if constexpr (RA) { if (s_ + 1 < nsteps) { BT_READ_B(NFB, nslot); BT_READ_A0(NFA, nslot); } }                           \
+            BT_MM2(2, a2h, a2l, 3, a3h, a3l, FB);                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        } else {                                                                                                                    \
         /* the A fragments run TWO multiplies ahead of their use (LDS pipe ~55 % busy in this kernel: one multiply of cover was not enough) */ \
         u32x4 a1h = sA[c_slot][0][ua_(1)], a1l = sA[c_slot][1][ua_(1)];                                                               \
         u32x4 a2h = sA[c_slot][0][ua_(2)], a2l = sA[c_slot][1][ua_(2)];                                                               \
@@ -256,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
         BT_MM(3, a3h, a3l, FB);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        }                                                                                                                           \
         if constexpr (RA) { if (more) BT_WAIT("4"); else BT_WAIT("0"); }   /* block s_ + 2 has landed (workgroup-uniform branch) */  \
         else { if (more) BT_WAIT("8"); else if (s_ + 2 < nsteps) BT_WAIT("4"); else BT_WAIT("0"); }      /* block s_ + 1 */            \
         c_slot = nslot;                                                                                                             \
@@ -332,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     }
 #undef ua_
 #undef BT_STEP
+#undef BT_MM2
 #undef BT_MM
 #undef BT_READ_A0
 #undef BT_READ_B
@@ -414,7 +443,14 @@ int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alp
 #ifdef MXF_PROBES
     // RA (register read-ahead of the next block's Bt fragments + first A fragment, requests two blocks ahead) against the default (fragments
     // read at the top of their own step, requests THREE blocks ahead): same box, 32-sample step 22.69-22.80 ms with it, 22.57 without
+    static const int pm_env = (int)MXF_KNOB("MXF_BT_PM", 0);
     static const int ra_env = (int)MXF_KNOB("MXF_BT_RA", 0);
+    if (pm_env) {
+        if (U) hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true, false, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f16x2_bt_kernel<false, false, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (ra_env) {
         if (U) hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_f16x2_bt_kernel<false, true>), dim3((unsigned)grid), dim3(512), 0, st, g);
