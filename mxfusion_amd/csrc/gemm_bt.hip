@@ -99,7 +99,7 @@ __device__ __forceinline__ float bt_dot8(u32x4 a, u32x4 b, float acc) {
 constexpr int BT_KMAX16 = 128;           // U row: w planes of up to 2048 k live in LDS
 
 // 256 x 256 tile, 512 threads: wave = 4 h + w owns rows [128 h, + 128) x columns [64 w, + 64) = 4 x 2 MFMA tiles (128 accumulators).
-template <bool WU, bool RA = false, bool PM = false>
+template <bool WU, bool RA = false, bool PM = false, int DG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     constexpr int NU = 512;                          // 16-byte units of one plane's (256 x 16) slab
     __shared__ u32x4 sA[4][2][NU];                   // [ring slot][plane][unit]: A rows, gemm_split.hip's swizzled image
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     // 32-sample step.  (r06 PMC of the first form -- three slots, all sixteen fragments read behind the barrier: matrix pipe 0.54 busy at
     // 1.80 GHz, i.e. stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56; this form: 0.60 at 1.61.)
     u32x4 fb0[2][2], fa0[2], fb1[2][2], fa1[2];
+    u32x4 dga[6];      // (the A fragments 1-3 of the current block; a named array only so that the DG diagnostics can keep them)
 #define BT_READ_B(FB, SLOTV)                                                                                                        \
     do {                                                                                                                            \
         _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                             \
@@ -250,7 +251,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
         if (more) q_issue();                         /* block s_ + 3 into the slot block s_ - 1 left */                             \
         asm volatile("" ::: "memory");               /* the fragment reads stay behind the requests */                              \
         const unsigned nslot = (c_slot + 1) & 3;                                                                                    \
-        if constexpr (!RA) { BT_READ_B(FB, c_slot); BT_READ_A0(FA, c_slot); }      /* (measured alternative: no register read-ahead, requests three blocks ahead) */ \
+        if constexpr (!RA) {                                                                                                        \
+            if (DG != 2 || c_kb == 0) BT_READ_B(FB, c_slot);      /* DG (probe builds): timing diagnostics with WRONG results -- 1: the A fragments, */ \
+            if (DG != 1 || c_kb == 0) BT_READ_A0(FA, c_slot);     /* 2: the Bt fragments are read for an item's first k block only                   */ \
+        }                                                                                                                           \
         if constexpr (WU) {                                                                                                         \
             if (uitem && (((int)c_kb & 1) == wh)) {      /* wave-uniform; FIRST: few registers are live here */                        \
                 const u32x4 wh_ = sW[2 * (int)c_kb + lk], wl_ = sW[BT_KMAX16 * 2 + 2 * (int)c_kb + lk];                             \
@@ -271,11 +275,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
         } else {                                                                                                                    \
         /* the A fragments run TWO multiplies ahead of their use (LDS pipe ~55 % busy in this kernel: one multiply of cover was not enough) */ \
-        u32x4 a1h = sA[c_slot][0][ua_(1)], a1l = sA[c_slot][1][ua_(1)];                                                               \
-        u32x4 a2h = sA[c_slot][0][ua_(2)], a2l = sA[c_slot][1][ua_(2)];                                                               \
+        if (DG != 1 || c_kb == 0) { dga[0] = sA[c_slot][0][ua_(1)]; dga[1] = sA[c_slot][1][ua_(1)]; dga[2] = sA[c_slot][0][ua_(2)]; dga[3] = sA[c_slot][1][ua_(2)]; } \
+        u32x4 a1h = dga[0], a1l = dga[1];                                                                                           \
+        u32x4 a2h = dga[2], a2l = dga[3];                                                                                           \
         BT_MM(0, FA[0], FA[1], FB);                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);           /* (pins the order: the scheduler otherwise hoists every read to the top) */    \
-        u32x4 a3h = sA[c_slot][0][ua_(3)], a3l = sA[c_slot][1][ua_(3)];                                                               \
+        if (DG != 1 || c_kb == 0) { dga[4] = sA[c_slot][0][ua_(3)]; dga[5] = sA[c_slot][1][ua_(3)]; }                               \
+        u32x4 a3h = dga[4], a3l = dga[5];                                                                                           \
         BT_MM(1, a1h, a1l, FB);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
         if constexpr (RA) { if (s_ + 1 < nsteps) { BT_READ_B(NFB, nslot); BT_READ_A0(NFA, nslot); } }     /* block s_ + 1 landed at the last barrier */    \
@@ -443,6 +449,13 @@ int mxf_gemm_bt_internal(mxf_ctx* h, int64_t M, int64_t N, int64_t K, double alp
 #ifdef MXF_PROBES
     // RA (register read-ahead of the next block's Bt fragments + first A fragment, requests two blocks ahead) against the default (fragments
     // read at the top of their own step, requests THREE blocks ahead): same box, 32-sample step 22.69-22.80 ms with it, 22.57 without
+    static const int dg_env = (int)MXF_KNOB("MXF_BT_DIAG", 0);
+    if (dg_env == 1 || dg_env == 2) {      // timing diagnostics, WRONG results
+        if (dg_env == 1) hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true, false, false, 1>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f16x2_bt_kernel<true, false, false, 2>), dim3((unsigned)grid), dim3(512), 0, st, g);
+        MXF_LAUNCH_CHECK(h);
+        return 0;
+    }
     static const int pm_env = (int)MXF_KNOB("MXF_BT_PM", 0);
     static const int ra_env = (int)MXF_KNOB("MXF_BT_RA", 0);
     if (pm_env) {
