@@ -11,8 +11,9 @@
 //     its four rows -- two reads give the lane its eight k.  The chunks of one instruction's four lane groups are consecutive (512
 //     contiguous bytes per instruction: conflict free).
 // A (shared by the workgroup's eight waves) goes through LDS exactly as in gemm_split.hip's 256 x 256 kernel; so does Bt now, which ends
-// that kernel's per-wave register ring of B fragments (48 registers) and its eight-fold redundant fragment fetch.  Three-slot ring of
-// (A 16 KB + Bt 16 KB), one barrier per k block, every load is an LDS-DMA request (4 per thread and k block).
+// that kernel's per-wave register ring of B fragments (48 registers) and its eight-fold redundant fragment fetch.  Four-slot ring of
+// (A 16 KB + Bt 16 KB), requests three k blocks ahead as one stream ACROSS work items, one barrier per k block, every load an LDS-DMA
+// request (4 per thread and k block).  What bounds it, and the alternatives that were measured: DESIGN.md section 4.2.
 //
 // U (optional, P = 1 of the SVGP call): the row  U[n] = uscale * sum_k w[k] Bt[k][n]  rides on the fragments that are in registers anyway:
 // for every column strip ONE of its tm row-tile workgroups (rotating) also forms v_dot2_f32_f16 sums of its Bt fragments with the f16
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     const unsigned toff_blk = (unsigned)((((int64_t)(4 * wq) * g.M + 128 * wh + li) * 16 + 4 * lk) * 4);      // bytes (host: 16 M * 64 < 2^31)
     const int rb_h = (wq * 2048 + (lane >> 4) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8) / 2;      // in halves
 
-    // One STREAM of k blocks over all of this workgroup's items (blockIdx.x, + gridDim.x, ...): the requests run two blocks ahead of the
+    // One STREAM of k blocks over all of this workgroup's items (blockIdx.x, + gridDim.x, ...): the requests run three blocks ahead of the
     // multiplies ACROSS item boundaries, so an item's first blocks arrive under the previous item's last multiplies and its epilogue -- a
     // per-item pipeline fill (two memory latencies with nothing in flight, ~3 % of a K = 1024 item) never happens.  Ring slot = stream
-    // position modulo 3 (the fragments are read from LDS, so nothing here needs a compile-time ring index).
+    // position modulo 4 (the fragments are read from LDS, so nothing here needs a compile-time ring index).
     // (32-bit index arithmetic throughout: the 64-bit divisions of a first form expanded to branchy software routines in the per-item paths,
     //  with spill reloads whose compiler-inserted s_waitcnt vmcnt(0) drained the request stream once per item)
     const int nk = (int)g.K16;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
     // top, the other A fragments two multiplies ahead of their use).  RA = true (probe builds): requests two blocks ahead and the NEXT
     // block's Bt fragments + first A fragment are read into a second register set under this block's MFMAs -- measured 0.15 ms slower per
     // 32-sample step.  (r06 PMC of the first form -- three slots, all sixteen fragments read behind the barrier: matrix pipe 0.54 busy at
-    // 1.80 GHz, i.e. stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56; this form: 0.60 at 1.61.)
+    // 1.80 GHz, i.e. stalled, not power-bound; the r05 kernel, whose B fragments sat in a register ring: 0.69 at 1.56; this form: 0.64 at 1.62.)
     u32x4 fb0[2][2], fa0[2], fb1[2][2], fa1[2];
     u32x4 dga[6];      // (the A fragments 1-3 of the current block; a named array only so that the DG diagnostics can keep them)
 #define BT_READ_B(FB, SLOTV)                                                                                                        \
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_bt_kernel(BtArgs g) {
             BT_MM2(2, a2h, a2l, 3, a3h, a3l, FB);                                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
         } else {                                                                                                                    \
-        /* the A fragments run TWO multiplies ahead of their use (LDS pipe ~55 % busy in this kernel: one multiply of cover was not enough) */ \
+        /* the A fragments are requested two multiplies ahead of their use                                                           */ \
         if (DG != 1 || c_kb == 0) { dga[0] = sA[c_slot][0][ua_(1)]; dga[1] = sA[c_slot][1][ua_(1)]; dga[2] = sA[c_slot][0][ua_(2)]; dga[3] = sA[c_slot][1][ua_(2)]; } \
         u32x4 a1h = dga[0], a1l = dga[1];                                                                                           \
         u32x4 a2h = dga[2], a2l = dga[3];                                                                                           \
