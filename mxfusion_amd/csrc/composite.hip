@@ -980,9 +980,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (use_split) {
             if (KA > 0) {
                 // 3 workgroups of the three-term kernel fit a CU: (256 - 184) * 3 = 216 workgroups = one per CU on 216 CUs; the two-term
-                // kernel fits 4: (256 - 202) * 4 = 216
+                // kernel fits 4: (256 - 202) * 4 = 216.  r06, one-planes path: (256 - 214) * 4 = 168 workgroups -- with the second planes pass
+                // gone the chains are alone on what Psi2 leaves, and 88 CUs serve the few-sample step better than 40 (same box, 4 samples:
+                // 4.30 -> 4.21 ms; 210: 4.25-4.32, 218: 4.22-4.26, 224: 4.27; configs[3] at 4 samples 2.41 -> 2.37)
                 rc = mxf_gemm_split_internal(h, M, M, KA, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                             psi2_ra_env ? psi2_ra : (split_mode == MXF_SPLIT_F16X2 ? 202 : 184), split_mode, split_var, 2, nullptr);
+                                             psi2_ra_env ? psi2_ra : (split_mode == MXF_SPLIT_F16X2 ? (bt_path ? 214 : 202) : 184), split_mode, split_var, 2, nullptr);
                 if (rc) return rc;
             }
             if (KA < SB) {
