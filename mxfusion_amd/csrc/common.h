@@ -81,6 +81,7 @@ struct mxf_ctx {
     hipStream_t potrf_rows = nullptr;                       // r06: the rows FAR below an outer panel are solved here, next to the next panel's chain
     hipEvent_t ev_pc = nullptr, ev_rb = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
+    hipEvent_t ev_tg = nullptr;       // the T product has been enqueued / finished (whitened few-sample form: Phi runs behind it)
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
     int64_t ws_generation = 0; // bumped whenever `ws` / `gram_ws` is freed and re-allocated: device pointers baked into a captured hipGraph are stale after that
@@ -241,6 +242,7 @@ static inline bool mxf_side_init(mxf_ctx* h) {
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tg, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }

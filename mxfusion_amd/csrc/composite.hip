@@ -1038,6 +1038,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     MXF_STAGE(h, "trtri Kuu", st);
     if (whiten && wh_defer2 == 2) { rc = deferred_planes(); if (rc) return rc; }
+    static const int phi_late_env = (int)MXF_KNOB("MXF_SVGP_WH_PHI_LATE", 0);
+    const bool phi_late = phi_late_env && whiten && bt_wh && want_grad && !het && SB <= 2 * 192 * M;
+    auto launch_phi = [&](bool few_) -> int {
+        MXF_T0(h, MXF_T_PSI2, sd_);
+        int r_ = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
+                                         few_ ? 202 : psi2_rb, split_mode, split_var, 1, nullptr);
+        if (r_) return r_;
+        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
+        MXF_T1(h, MXF_T_PSI2, sd_);
+        MXF_STAGE(h, "Phi (sd)", sd_);
+        return 0;
+    };
     unsigned* limax = (unsigned*)(info2 + 4);           // bit pattern of max |L^-1| (whitened tier; word cleared by svgp_init_kernel)
     if (whiten) {
         // L^-1 as f16x2 planes (the A operand of V = L^-1 Kuf); Aext is free until Hh is formed
@@ -1079,13 +1091,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_T1(h, MXF_T_PLANES_B, sd_);
         MXF_HIP(h, hipEventRecord(h->ev_aux, sd_));      // V^T planes and U ready: the T GEMM / the reverse pass wait for it
         // Phi = V V^T (lower tiles, split-K) = sigma^2 2^-28 (planes)(planes)^T
-        MXF_T0(h, MXF_T_PSI2, sd_);
-        rc = mxf_gemm_split_internal(h, M, M, SB, (double)split_ga * split_ga, plKuf, (int64_t)pl_big, plKuf, (int64_t)pl_big, 0.0, (float*)Psi2, M, 1, sd_,
-                                     few ? 202 : psi2_rb, split_mode, split_var, 1, nullptr);
-        if (rc) return rc;
-        hipLaunchKernelGGL((symmetrize_kernel<T>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Psi2, M, M, MM);
-        MXF_T1(h, MXF_T_PSI2, sd_);
-        MXF_STAGE(h, "Phi (sd)", sd_);
+        // r06 probe knob MXF_SVGP_WH_PHI_LATE, few samples per GPU: Phi is enqueued BEHIND the T product (launch_phi above) -- T is on the
+        // critical path (the reverse pass needs it), Phi only feeds the core's reverse mode in the tail.  Measured, same box, 4 samples at
+        // trained-like parameters: 6.14-6.17 ms with it against 6.04 -- Phi then runs next to the latency-bound reverse pass and the tail waits
+        // for it; whitened parity tests pass either way.  Off.
+        if (!phi_late) { rc = launch_phi(few); if (rc) return rc; }
     }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
@@ -1205,6 +1215,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     if (rc) return rc;
     MXF_T1(h, MXF_T_TGEMM, st);
     MXF_STAGE(h, "T", st);
+    if (phi_late) {      // Phi behind T: next to the reverse pass instead of next to T
+        MXF_HIP(h, hipEventRecord(h->ev_tg, st));
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_tg, 0));
+        rc = launch_phi(true);
+        if (rc) return rc;
+    }
     if (use_split) {
         // (U = w^T Kuf was written by the Kfu planes pass)
     } else {

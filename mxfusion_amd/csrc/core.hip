@@ -33,6 +33,7 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_aux) (void)hipEventDestroy(h->ev_aux);
     if (h->ev_aux2) (void)hipEventDestroy(h->ev_aux2);
+    if (h->ev_tg) (void)hipEventDestroy(h->ev_tg);
     if (h->ev_su) (void)hipEventDestroy(h->ev_su);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
