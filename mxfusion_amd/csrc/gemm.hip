@@ -589,6 +589,11 @@ bool gemm_small_launch<double>(mxf_ctx* h, GemmArgs<double>& g, int ta, int tb, 
     static const int small_env = MXF_KNOB("MXF_GEMM_SMALL", 1);
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
     if (!small_env || t128 > 64 || M > 65535) return false;       // the big kernel fills at least a quarter of the chip: keep it
+    // r06: a LONG contraction over a small output (the float64 step's Psi2 = Kuf Kuf^T: 1024 x 1024 x 2.1 M) is throughput-bound, not
+    // latency-bound -- it belongs on the 128 x 128 LDS-DMA kernel with split-K (probe knob MXF_GEMM_SMALL_KMAX: contraction length above
+    // which the small-tile kernel steps aside)
+    static const int64_t kmax_env = MXF_KNOB("MXF_GEMM_SMALL_KMAX", 16384);
+    if (K > kmax_env && !g.k_from_m && M >= 512 && N >= 512) return false;      // (skinny outputs -- K^T y, M x P -- stay: the 128 x 128 tiles would idle)
     const int64_t tm = (M + SBM_ - 1) / SBM_, tn = (N + SBM_ - 1) / SBM_;
     if (lower_only && tm != tn) return false;
     const int64_t tiles = (lower_only ? tm * (tm + 1) / 2 : tm * tn) * batch;
