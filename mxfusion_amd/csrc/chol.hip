@@ -777,23 +777,28 @@ __global__ __launch_bounds__(256) void sumlogdiag_kernel(const T* __restrict__ L
 //  and tile reads share its L2) and 120 mostly waiting workgroups hold CUs the look-ahead GEMM wants: potrf(8192) 7.18 vs 6.72 ms.)
 // MFMA conventions as potrf_tiles_kernel: A operand lane (li, lq) = P[m = li][k = lq], B operand = Q[n = li][k = lq], accumulator register r of
 // lane (li, lq) = element (row lq + 4 r, column li).
+// RH (r06): rows per workgroup.  A block row's critical chain is npt x (solve + ONE wave's tile update): at RH = 64 that update is 256 float64
+// MFMAs of 64 cycles each, 7.8 us, i.e. >= 62 us per outer panel on <= 120 of the 256 CUs.  RH = 32 / 16 halve / quarter the chain and
+// double / quadruple the workgroup count (each re-reads the L2-resident diagonal block L11: 1.2 MB per workgroup).
 static_assert(NBO / NB <= 8, "potrf_rows_kernel: one wave per tile of the panel, eight waves");
+template <int RH>
 __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A, int64_t lda, int64_t sA, int64_t c0, int npt, int row0,
                                                          const double* __restrict__ inv_all) {
-    __shared__ double Tb[2][NB][NB + 1];
+    constexpr int XR = RH / 16;
+    __shared__ double Tb[2][RH][NB + 1];
     __shared__ double a[NB][NB + 1];          // L[k][k]
     __shared__ double minv[4][16][17];        // the inverses of its four 16 x 16 diagonal blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    const int i = row0 + (int)blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
     double* Ab = A + (int64_t)b * sA;
     const double* invs = inv_all + (int64_t)b * npt * 1024;
-    const int64_t ri = c0 + (int64_t)i * NB;
+    const int64_t ri = c0 + (int64_t)row0 * NB + (int64_t)blockIdx.x * RH;      // (row0 in units of NB rows)
     const bool own = wave < npt;
     const int64_t rjw = c0 + (int64_t)wave * NB;
-    pt_f64x4 acc[4][4];
+    pt_f64x4 acc[XR][4];
     if (own) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < XR; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A,
         if (upd) { lgroup(0, b0); lgroup(1, b1); lgroup(2, b2); }
         if (wave == k) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < XR; ++x)
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -833,7 +838,7 @@ __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A,
         minv[tid >> 8][(tid >> 4) & 15][tid & 15] = mv0;
         minv[2 + (tid >> 8)][(tid >> 4) & 15][tid & 15] = mv1;
         __syncthreads();
-        if (wave < 4) {
+        if (wave < XR) {
             // X L[k][k]^T = T, 16 rows per wave, in registers (accumulator layout of the TRANSPOSED tile: lane (li, lq), register r = element
             // (row li, column lq + 4 r) of a 16 x 16 block): X_b = Y_b M_b^T with the published inverse M_b (4 MFMAs), then
             // Y_b'' -= X_b L_b''b^T for the blocks to the right -- as potrf_tiles_kernel
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A,
         __syncthreads();
         {   // L[i][k] = X to global memory, coalesced
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = tid + 512 * u, rr = e >> 6, cc = e & 63; Ab[(ri + rr) * lda + rk + cc] = T[rr][cc]; }
+            for (int u = 0; u < RH / 8; ++u) { const int e = tid + 512 * u, rr = e >> 6, cc = e & 63; Ab[(ri + rr) * lda + rk + cc] = T[rr][cc]; }
         }
         if (upd) {
 #pragma unroll
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(512) void potrf_rows_kernel(double* __restrict__ A,
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int x = 0; x < 4; ++x)
+                        for (int x = 0; x < XR; ++x)
                             acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[16 * x + li][16 * qq + 4 * t + lq], b0[t], acc[x][y], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { b0[t] = b1[t]; b1[t] = b2[t]; b2[t] = b3[t]; }
@@ -899,6 +904,23 @@ int trtri_row_block(mxf_ctx* h, int dtype, int64_t c0, int64_t pe, const T* L, i
     rc = mxf_gemm_internal(h, dtype, 1, 1, c0, b2, c0, 1.0, Li, ldi, 0, L + c0 * ldl, ldl, 0, 0.0, Li + c0, ldi, 0, 1, 0, st, res, 1);
     if (rc) return rc;
     rc = mxf_gemm_internal(h, dtype, 0, 1, b2, c0, b2, -1.0, Li + c0 * (ldi + 1), ldi, 0, Li + c0, ldi, 0, 0.0, Li + c0 * ldi, ldi, 0, 1, 0, st, res, 2);
+    if (rc) return rc;
+    hipLaunchKernelGGL((zero_block_kernel<T>), dim3((unsigned)((c0 * b2 + 255) / 256 > 1024 ? 1024 : (c0 * b2 + 255) / 256), 1), dim3(256), 0, st, Li + c0, c0, b2, ldi, (int64_t)0);
+    return 0;
+}
+// The same row block in its three dependent pieces (r06), so that each starts as soon as ITS inputs exist:
+//   p1: (L[i, :c0] I[:c0, :c0])^T into the upper mirror block -- needs the rows below the panel ending at c0 and the finished leading inverse,
+//       NOT the block's own panels (the bulk of the row block's work: 2 b2 c0^2 / 2 flops);
+//   the inverse of the diagonal block L[i, i] -- needs the block's own panels only (latency-bound small launches: a stream of its own);
+//   p2: X = -I_ii p1^T, then the mirror block zeroed again.
+template <typename T>
+int trtri_row_block_p1(mxf_ctx* h, int dtype, int64_t c0, int64_t pe, const T* L, int64_t ldl, T* Li, int64_t ldi, hipStream_t st) {
+    return mxf_gemm_internal(h, dtype, 1, 1, c0, pe - c0, c0, 1.0, Li, ldi, 0, L + c0 * ldl, ldl, 0, 0.0, Li + c0, ldi, 0, 1, 0, st, 0, 1);
+}
+template <typename T>
+int trtri_row_block_p2(mxf_ctx* h, int dtype, int64_t c0, int64_t pe, T* Li, int64_t ldi, hipStream_t st) {
+    const int64_t b2 = pe - c0;
+    int rc = mxf_gemm_internal(h, dtype, 0, 1, b2, c0, b2, -1.0, Li + c0 * (ldi + 1), ldi, 0, Li + c0, ldi, 0, 0.0, Li + c0 * ldi, ldi, 0, 1, 0, st, 0, 2);
     if (rc) return rc;
     hipLaunchKernelGGL((zero_block_kernel<T>), dim3((unsigned)((c0 * b2 + 255) / 256 > 1024 ? 1024 : (c0 * b2 + 255) / 256), 1), dim3(256), 0, st, Li + c0, c0, b2, ldi, (int64_t)0);
     return 0;
@@ -954,8 +976,10 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // row blocks of FOUR outer panels (2048 rows), from four row blocks on.  Measured at n = 8192 (MAP step of the exact GP, two alternating rounds,
     // profiles/r05_potrf_eager_inverse_ab.txt): off 15.0 ms; every panel 18.1 (208 more launches, and products of a few tiles each that hold CUs the
     // chain's tile workgroups are waiting for); every second 14.6-14.7; every fourth 14.5; two halves 15.0; leaving the products 64 / 128 CUs less changes nothing
-    static const int eager_env = MXF_KNOB("MXF_POTRF_EAGER_INV", 4);
-    const bool eager = Ie != nullptr && eager_env && sizeof(T) == 8 && S == 1 && panel_tiles && look && n % NBO == 0 &&
+    // r06: with the row blocks in split pieces (MXF_POTRF_EAGER_SPLIT below) blocks of TWO panels are best: 14.10-14.15 ms against 14.42-14.44
+    // (four), 15.0 (three: ragged last block), 14.72 for the r05 form
+    static const int eager_env = MXF_KNOB("MXF_POTRF_EAGER_INV", 2);
+    const bool eager = Ie != nullptr && eager_env && sizeof(T) == 8 && S == 1 && panel_tiles && look && n % NBO == 0 && n >= 16 * NBO &&
                        n >= 4 * (eager_env >= 100 ? n / 8 : (int64_t)eager_env * NBO);
     static const int split_rows_g = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
     static const int rows_env_g = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
@@ -991,19 +1015,25 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                 // (the rows below this panel's diagonal block were updated on the auxiliary stream, next to the chain above)
                 const bool had_h = pending_h;
                 if (pending_h) { MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0)); pending_h = false; }
+                // nblk block rows of NB rows from block row row0 of the panel on: workgroups of RH rows each (MXF_POTRF_ROWS_RH, see the kernel)
+                auto launch_rows = [&](unsigned nblk, unsigned row0, hipStream_t s_) {
+                    static const int rh_env = MXF_KNOB("MXF_POTRF_ROWS_RH", 32);
+                    if (rh_env == 16) hipLaunchKernelGGL(potrf_rows_kernel<16>, dim3(nblk * 4, (unsigned)S), dim3(512), 0, s_, A, lda, sA, c0, (int)npt, (int)row0, (const double*)pinv);
+                    else if (rh_env == 32) hipLaunchKernelGGL(potrf_rows_kernel<32>, dim3(nblk * 2, (unsigned)S), dim3(512), 0, s_, A, lda, sA, c0, (int)npt, (int)row0, (const double*)pinv);
+                    else hipLaunchKernelGGL(potrf_rows_kernel<64>, dim3(nblk, (unsigned)S), dim3(512), 0, s_, A, lda, sA, c0, (int)npt, (int)row0, (const double*)pinv);
+                };
                 if (split && rows_env) {       // r03: the rows below right-looking from registers (potrf_rows_kernel)
                     const unsigned nbel = nbr - npt, nfirst = (unsigned)(NBO / NB) < nbel ? (unsigned)(NBO / NB) : nbel;
                     if (rows2_env && look && head_split_env && nbel >= nfirst + 16 && pe + NBO < n) {
                         if (had_h) MXF_HIP(h, hipStreamWaitEvent(h->potrf_rows, h->ev_ph, 0));      // (their columns' head update, auxiliary stream)
                         MXF_HIP(h, hipEventRecord(h->ev_pc, st));                                   // the chain of this panel (and all before it)
                         MXF_HIP(h, hipStreamWaitEvent(h->potrf_rows, h->ev_pc, 0));
-                        hipLaunchKernelGGL(potrf_rows_kernel, dim3(nfirst, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
-                        hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbel - nfirst, (unsigned)S), dim3(512), 0, h->potrf_rows, A, lda, sA, c0, (int)npt,
-                                           (int)(npt + nfirst), (const double*)pinv);
+                        launch_rows(nfirst, npt, st);
+                        launch_rows(nbel - nfirst, npt + nfirst, h->potrf_rows);
                         MXF_HIP(h, hipEventRecord(h->ev_rb, h->potrf_rows));
                         pending_r = true;
                     } else
-                    hipLaunchKernelGGL(potrf_rows_kernel, dim3(nbr - npt, (unsigned)S), dim3(512), 0, st, A, lda, sA, c0, (int)npt, (int)npt, (const double*)pinv);
+                    launch_rows(nbr - npt, npt, st);
                 } else if (split)
                     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(nbr - npt, (unsigned)S), dim3(256), 0, st, A, lda, sA, c0, (int)npt, info, progress, pinv, (int)npt, 1);
             }
@@ -1015,16 +1045,44 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         // block is what stays exposed behind the factorisation (2.5 ms of the 14.6 ms MAP step at n = 8192 with blocks of four panels), and
         // the late panels are chain-bound, i.e. the chip is mostly idle next to them
         static const int tail_env = MXF_KNOB("MXF_POTRF_EAGER_TAIL", 0);
-        const int64_t tail0 = (n * 3 / 4) / rbw * rbw, tbw = (int64_t)tail_env * NBO;
+        const int64_t tail0 = (n * 3 / 4) / rbw * rbw, tbw = (int64_t)(tail_env > 0 ? tail_env : 1) * NBO;
         const bool in_tail = tail_env > 0 && eager_env < 100 && tbw < rbw && pe > tail0;
         const bool fire = in_tail ? ((pe - tail0) % tbw == 0 || pe == n) : (pe % rbw == 0 || pe == n);
+        // r06, MXF_POTRF_EAGER_SPLIT (default 1): the row block's pieces separately (trtri_row_block_p1 / _p2).  When block b's panels end, its
+        // diagonal inverse goes to the third auxiliary stream, its p2 follows on the inverse stream, and p1 of block b + 1 -- whose inputs are
+        // complete at this point, four panels before that block is factored -- is queued right behind.  What is left behind the factorisation
+        // is the last block's diagonal inverse and p2 instead of its whole row block.
+        static const int esplit_env = MXF_KNOB("MXF_POTRF_EAGER_SPLIT", 1);
+        const bool esplit = esplit_env && !rows2_env;
+        auto fires_at = [&](int64_t pe_) {
+            const bool it_ = tail_env > 0 && eager_env < 100 && tbw < rbw && pe_ > tail0;
+            return it_ ? ((pe_ - tail0) % tbw == 0 || pe_ == n) : (pe_ % rbw == 0 || pe_ == n);
+        };
         if (eager && fire) {
             const int64_t rb0 = in_tail ? tail0 + (pe - tail0 - 1) / tbw * tbw : (pe - 1) / rbw * rbw;
             MXF_HIP(h, hipEventRecord(h->ev_pi, st));
-            MXF_HIP(h, hipStreamWaitEvent(h->potrf_inv, h->ev_pi, 0));
             if constexpr (sizeof(T) == 8) {
-                int rc = trtri_row_block<T>(h, dtype, rb0, pe, A, lda, Ie, ldie, h->potrf_inv);
-                if (rc) return rc;
+                if (esplit) {
+                    hipStream_t qd = h->potrf_rows, qp = h->potrf_inv;
+                    MXF_HIP(h, hipStreamWaitEvent(qd, h->ev_pi, 0));
+                    int rc = trtri_typed<T>(h, dtype, 1, pe - rb0, A + rb0 * (lda + 1), lda, 0, Ie + rb0 * (ldie + 1), ldie, 0, qd);
+                    if (rc) return rc;
+                    MXF_HIP(h, hipEventRecord(h->ev_pc, qd));
+                    MXF_HIP(h, hipStreamWaitEvent(qp, h->ev_pc, 0));       // (block 0: p1 of block 1 reads this inverse)
+                    if (rb0 > 0) { rc = trtri_row_block_p2<T>(h, dtype, rb0, pe, Ie, ldie, qp); if (rc) return rc; }
+                    if (pe < n) {
+                        MXF_HIP(h, hipStreamWaitEvent(qp, h->ev_pi, 0));   // the rows below the panel that just ended
+                        int64_t ne = pe + NBO;                           // the end of the next row block = the next firing point
+                        while (ne < n && !fires_at(ne)) ne += NBO;
+                        if (ne > n) ne = n;
+                        rc = trtri_row_block_p1<T>(h, dtype, pe, ne, A, lda, Ie, ldie, qp);
+                        if (rc) return rc;
+                    }
+                } else {
+                    MXF_HIP(h, hipStreamWaitEvent(h->potrf_inv, h->ev_pi, 0));
+                    int rc = trtri_row_block<T>(h, dtype, rb0, pe, A, lda, Ie, ldie, h->potrf_inv);
+                    if (rc) return rc;
+                }
             }
         }
         for (int64_t j0 = c0; j0 < pe && !panel_tiles; j0 += NB) {
