@@ -461,9 +461,35 @@ __device__ __forceinline__ void split4(const float (&x)[4], bw_f16x4& hi, bw_f16
     lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bw_f16x4);
 }
 
-template <int KIND, bool FULL, bool F16>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks); F16: RBF only
+// LDS-DMA requests of the DMAT form below (inline asm: the compiler neither tracks nor waits for them -- the waits are counted by hand)
+//   bw_dma16: 64 lanes x 16 bytes from sbase + voff (wave-uniform base in SGPRs, per-lane byte offset) to the KB at LDS byte address lds
+//   bw_dma4 / bw_dma4v: 64 lanes x 4 bytes to the 256 bytes at lds; the v form takes a full per-lane address
+__device__ __forceinline__ void bw_dma16(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void bw_dma4(const void* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void bw_dma4v(const float* p, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(lds) : "memory", "m0");
+}
+
+// DMAT (r06; RBF, FULL, F16, T in 16-column blocks): the T tiles and the column-side values reach the wave through LDS-DMA instead of
+// registers.  The register form keeps PD = 4 tiles (64 bytes) per lane in flight -- at two waves per SIMD 32 KB per CU, about half of what
+// 8 TB/s x the loaded memory latency asks for -- and has no registers for more (256 VGPRs).  Here every wave owns a ring of eight 1 KB
+// slots, slot = row tile: at row tile mt the request of the tile that will next use the slot just consumed is issued (tile 7 of this
+// column tile at mt = 0, tile mt - 1 of the NEXT column tile otherwise), i.e. seven tiles = 7 KB per wave are in flight, 56 KB per CU.
+// A tile is one contiguous KB of the blocked T, so its LDS image is the memory image and lane (li, lq) reads its four values at
+// 64 li + 16 lq.  The sixteen columns' x, |x|^2, U and y of the next column tile come the same way (three requests, double-buffered).
+// Waits are counted: requests retire in order, so "all but the youngest N" is exact -- N = the requests issued behind the one needed
+// (the compiler's own memory operations -- the dX atomics of the previous column tile -- are counted when they are known to be there,
+// anything uncounted only makes a wait stricter).
+template <int KIND, bool FULL, bool F16, bool DMAT = false>       // FULL: M % MF_RB == 0 and SB % 64 == 0 (no ragged tiles: no masks); F16: RBF only
 __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_kernel(BwdMfmaArgs a) {
     static_assert(!F16 || KIND == MXF_K_RBF, "the f16 accumulation is scaled for the RBF weights");
+    static_assert(!DMAT || (FULL && F16 && MF_MT == 8), "the LDS-DMA form: full tiles, f16 accumulation, eight row tiles (slot = row tile)");
+    __shared__ __attribute__((aligned(16))) float tring[DMAT ? 4 : 1][DMAT ? 8 * 256 : 4];       // per wave: eight T tiles
+    __shared__ __attribute__((aligned(16))) float cbuf[DMAT ? 4 : 1][2][DMAT ? 192 : 4];        // per wave, two buffers: [x 16 x 8 | |x|^2 16 | U 16 | y 16 | -]
     constexpr int QT = 8;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     __shared__ float rowacc[MF_RB][10];
     __shared__ __attribute__((aligned(16))) float wt[4][2][16][20];  // per wave, double-buffered: the W tile, transposed on the way through (20-word rows)
     __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = DMAT ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, li = lane & 15, lq = lane >> 4;
     const int64_t band0 = (int64_t)blockIdx.y * MF_RB;
     const int Q = a.Q;
     const float* __restrict__ Xs = a.Xs;
@@ -602,7 +628,46 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
     f32x4 tq[PD];
     int smp_w = nt0 / bsz, smp_end = (smp_w + 1) * bsz;       // sample of the tile at nt0 and the first column behind it (< 2^31 + B: unsigned compare)
     auto advance_smp = [&](int nt0_) { while ((unsigned)nt0_ >= (unsigned)smp_end) { ++smp_w; smp_end += bsz; } return smp_w; };
-    if constexpr (AHEAD) {
+    // DMAT: request side
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const unsigned lds_t = DMAT ? __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)&tring[DMAT ? wave : 0][0]) : 0u;
+    const unsigned lds_c = DMAT ? __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)&cbuf[DMAT ? wave : 0][0][0]) : 0u;
+    const unsigned voff16 = (unsigned)lane * 16u, voff4 = (unsigned)lane * 4u;
+    const bool hasdx = a.dX != nullptr;
+    auto tile_base = [&](int nt0_) -> const float* {              // the wave's column block of T at the band's first row (wave-uniform: SGPRs)
+        const int64_t off = ((int64_t)(nt0_ >> 4) * a.M + band0) * 16;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uint64_t)off), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)off >> 32));
+        return Tm + (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto issue_cols = [&](int nt0_, int smp_, int buf) {
+        const unsigned nts = __builtin_amdgcn_readfirstlane((unsigned)nt0_);
+        const float* xb = Xs + (int64_t)nts * QT;
+        bw_dma4(xb, voff4, lds_c + buf * 768);
+        bw_dma4(xb, voff4 + 256u, lds_c + buf * 768 + 256);
+        // lanes 0..15 |x|^2, 16..31 U, 32..47 y, 48..63 |x|^2 again (padding)
+        const float* p = (lq == 1 ? a.U + nt0_ : lq == 2 ? a.Y + (int64_t)smp_ * a.sY + (nt0_ - (int64_t)smp_ * a.B) : a.Xn + nt0_) + li;
+        bw_dma4v(p, lds_c + buf * 768 + 512);
+    };
+    auto read_cols = [&](int buf, int smp_) -> Cols {
+        Cols c;
+        const float* cb = &cbuf[DMAT ? wave : 0][DMAT ? buf : 0][0];
+        c.smp = smp_;
+        c.xa0 = cb[li * 8 + lq]; c.xa1 = cb[li * 8 + 4 + lq];
+        c.xx = *reinterpret_cast<const f32x4*>(cb + 128 + 4 * lq);
+        c.uu = *reinterpret_cast<const f32x4*>(cb + 144 + 4 * lq);
+        c.yy = *reinterpret_cast<const f32x4*>(cb + 160 + 4 * lq);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c.xv[t] = cb[(4 * lq + t) * 8 + (li & 7)];
+        return c;
+    };
+    if constexpr (DMAT) {
+        issue_cols(nt0, smp_w, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur = read_cols(0, smp_w);
+        tb_c = tile_base(nt0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bw_dma16(tb_c + j * 256, voff16, lds_t + j * 1024);
+    } else if constexpr (AHEAD) {
         cur = load_cols(nt0, smp_w);
         tb_c = tbase(nt0, tl_c);
 #pragma unroll
@@ -614,7 +679,15 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
         Cols nxt;
         const float* tl_n = tl_c;
         const float* tb_n = tb_c;
-        if constexpr (!AHEAD) {         // everything this column tile needs is requested here, at its top
+        int smp_n = cur.smp;
+        if constexpr (DMAT) {
+            nt0n = col_nt0(it + 1);
+            has_next = it + 1 < a.CT && nt0n < sb;
+            if (!has_next) nt0n = nt0;                        // (no next tile: harmless requests of this one again -- the counts stay the same)
+            smp_n = has_next ? advance_smp(nt0n) : cur.smp;
+            issue_cols(nt0n, smp_n, (it + 1) & 1);
+            tb_n = tile_base(nt0n);
+        } else if constexpr (!AHEAD) {         // everything this column tile needs is requested here, at its top
             cur = load_cols(nt0, advance_smp(nt0));
             tb_c = tbase(nt0, tl_c);
 #pragma unroll
@@ -670,10 +743,23 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             const int rl = mt * 16 + li;
             asm volatile("" ::: "memory");
             BT_STAMP(0, rl);
-            f32x4 tv = tq[mt % PD];
+            f32x4 tv;
+            if constexpr (DMAT) {
+                // request into the slot consumed one row tile ago, then wait for this row tile's slot: requests behind it = the six others
+                // of the ring + this one + the three column requests issued at the top (mt < 7; at mt = 7 the slot was requested at mt = 0,
+                // seven tile requests ago) + the four dX atomics of the previous column tile when the caller wants dX
+                if (mt == 0) bw_dma16(tb_c + 7 * 256, voff16, lds_t + 7 * 1024);
+                else bw_dma16(tb_n + (mt - 1) * 256, voff16, lds_t + (mt - 1) * 1024);
+                if (mt == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                else if (hasdx && it > 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                tv = *reinterpret_cast<const f32x4*>(&tring[DMAT ? wave : 0][DMAT ? mt * 256 + li * 16 + 4 * lq : 0]);
+            } else {
+            tv = tq[mt % PD];
             BT_STAMP(1, tv[0]);
             if (mt + PD < MF_MT) tq[mt % PD] = tget(tb_c, tl_c, mt + PD);                               // PD row tiles ahead
             else if constexpr (AHEAD) tq[mt % PD] = tget(tb_n, tl_n, mt + PD - MF_MT);                  // ... into the next column tile
+            }
             if (!FULL) { const bool ok = cval && rowl + 16 * mt < a.M; tv = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f}; }
             f32x4 dotn = dotc;
             const f32x2 zwv = zwc;
@@ -802,7 +888,11 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             }
         }
         BT_STAMP2(7, 7, dl3);
-        if constexpr (AHEAD) {
+        if constexpr (DMAT) {
+            if (!has_next) break;
+            cur = read_cols((it + 1) & 1, smp_n);     // (landed: the wait of row tile 7 covers everything but the seven youngest requests)
+            nt0 = nt0n; tb_c = tb_n;
+        } else if constexpr (AHEAD) {
             if (!has_next) break;
             cur = nxt; nt0 = nt0n; tb_c = tb_n; tl_c = tl_n;
         } else {
@@ -810,6 +900,7 @@ __global__ __launch_bounds__(256, MXF_MF_MT <= 4 ? 3 : 2) void svgp_bwd_mfma_ker
             if (it + 1 >= a.CT || nt0 >= sb) break;
         }
     }
+    if constexpr (DMAT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no request may land in LDS after the workgroup has gone
     }
     flush_scal();
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -1059,6 +1150,15 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     dim3 g((unsigned)((quads + ct - 1) / ct), (unsigned)bands, 1);
     if (g.y > 65535u) MXF_FAIL(h, -3, "svgp reverse pass: too many row bands");
     const bool full = (M % MF_RB == 0) && (SB % 64 == 0);
+    // MXF_BWD_DMAT=1 (probe builds only): T tiles and column values through LDS-DMA (svgp_bwd_mfma_kernel DMAT) -- VERDICT r05 item 7's experiment.
+    // Correct (tests/test_gpu_fullsize_oracle.py, test_gpu_sweep.py pass with it) and NOT faster: the pass alone 2.99-3.06 against 2.63-2.74 ms,
+    // the step 22.1-22.5 either way (tests/probes/r06_bwd_dmat.sh).  With 56 instead of 32 KB per CU in flight nothing moves, i.e. the pass
+    // does not wait for memory: at 2 waves per SIMD a row tile costs a SIMD ~630 cycles, about the sum of its ~340 VALU cycles (exp2, the
+    // weights, two f16 splits) and its 8 MFMAs of 32 cycles -- the two do not overlap inside a wave's dependent chain, and the LDS read of
+    // the tile is one more exposed latency per step.  What would help is fewer instructions per element (a 16 x 32 tile on
+    // v_mfma_f32_16x16x32_f16), not deeper queues.
+    static const int dmat_env = (int)MXF_KNOB("MXF_BWD_DMAT", 0);
+    (void)dmat_env;
 #define MF_GO(KIND)                                                                                             \
     do {                                                                                                        \
         if (full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<KIND, true, false>), g, dim3(256), 0, st, a);       \
@@ -1066,6 +1166,10 @@ int launch_mfma(mxf_ctx* h, int kind, int64_t M, int64_t SB, int64_t B, int Q, c
     } while (0)
     switch (kind) {
         case MXF_K_RBF:
+#ifdef MXF_PROBES
+            if (f16 && full && dmat_env && t_blocked && MF_MT == 8) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<MXF_K_RBF, true, true, true>), g, dim3(256), 0, st, a);
+            else
+#endif
             if (f16 && full) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<MXF_K_RBF, true, true>), g, dim3(256), 0, st, a);
             else if (f16) hipLaunchKernelGGL((svgp_bwd_mfma_kernel<MXF_K_RBF, false, true>), g, dim3(256), 0, st, a);
             else MF_GO(MXF_K_RBF);
