@@ -931,8 +931,10 @@ int trtri_row_block_p2(mxf_ctx* h, int dtype, int64_t c0, int64_t pe, T* Li, int
 // trtri(8192) afterwards took 3.9 ms of a 15 ms MAP step.  *eager_done tells the caller whether Ie was filled (else: call trtri afterwards).
 template <typename T>
 int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info,
-                T* Ie = nullptr, int64_t ldie = 0, bool* eager_done = nullptr) {
+                T* Ie = nullptr, int64_t ldie = 0, bool* eager_done = nullptr, T* Kacc = nullptr, int64_t ldk = 0, double kcoef = 0.0,
+                bool* kacc_done = nullptr) {
     if (eager_done) *eager_done = false;
+    if (kacc_done) *kacc_done = false;
     if (info && zero_info) MXF_HIP(h, hipMemsetAsync(info, 0, sizeof(int) * S, st));
     // Look-ahead (n >= 2048): the trailing update after an outer panel is split into the part that touches the NEXT outer panel's columns
     // (on the caller's stream, so that panel's latency-bound factorisation starts right away) and the rest (on an auxiliary stream, next to
@@ -963,6 +965,14 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool look = look_env && n >= 2048 && cap == hipStreamCaptureStatusNone && mxf_potrf_aux_init(h);
+    // MXF_POTRF_CUMASK (common.h): CU-masked bulk streams are blocking streams -- the chain moves to a non-blocking stream of its own
+    hipStream_t st_user = st;
+    const bool own_chain = look && (h->potrf_masked || h->potrf_chain_always) && h->potrf_chain;
+    if (own_chain) {
+        MXF_HIP(h, hipEventRecord(h->ev_pk, st_user));
+        MXF_HIP(h, hipStreamWaitEvent(h->potrf_chain, h->ev_pk, 0));
+        st = h->potrf_chain;
+    }
     hipStream_t ax = look ? h->potrf_aux : st;
     bool pending_b = false, pending_h = false, pending_r = false;
     // r06, measured and NOT kept -- probe knob MXF_POTRF_ROWS2=1: only the NEXT panel's eight block rows of the rows below
@@ -979,8 +989,25 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
     // r06: with the row blocks in split pieces (MXF_POTRF_EAGER_SPLIT below) blocks of TWO panels are best: 14.10-14.15 ms against 14.42-14.44
     // (four), 15.0 (three: ragged last block), 14.72 for the r05 form
     static const int eager_env = MXF_KNOB("MXF_POTRF_EAGER_INV", 2);
+    // r06 (session 4), measured and NOT kept -- probe knob MXF_POTRF_KACC=1: kcoef L^-T L^-1 = sum over row blocks b of Linv[b, :]^T Linv[b, :],
+    // each share accumulated into the caller's zeroed buffer (lower triangle) on a stream of its own as soon as row block b of the eager inverse
+    // is final -- 2.6 ms of products moved under the factorisation, leaving 1.2 ms (the last block's share) instead of the 2.9 ms product behind it.
+    // Correct (the exact-GP tests pass with it), but the MAP step at n = 8192 goes 13.82-13.87 -> 15.73-15.84 ms (same box, alternating,
+    // tests/probes/r06_kacc_ab*.sh): the chain pays ~4 ms for the 1.7 ms the tail saves.  What the chain suffers from is not a lack of free
+    // CUs: with the bulk streams CU-masked so that 2 / 4 / 8 CUs of every XCD stay free for it (MXF_POTRF_CUMASK, common.h; the masked streams
+    // are blocking streams, so the chain then runs on a non-blocking stream of its own) the step takes 18.5-18.7 ms (22.3-24.0 with the
+    // accumulation), and the chain alone on a most-urgent stream (MXF_POTRF_CHAIN_PRIO=1) 16.8 ms; GPU_MAX_HW_QUEUES 4 / 8 changes nothing.
+    // Its tile hand-offs go through L2 / the fabric, and that is what the products next to it load.
+    static const int kacc_env = MXF_KNOB("MXF_POTRF_KACC", 0);
     const bool eager = Ie != nullptr && eager_env && sizeof(T) == 8 && S == 1 && panel_tiles && look && n % NBO == 0 && n >= 16 * NBO &&
                        n >= 4 * (eager_env >= 100 ? n / 8 : (int64_t)eager_env * NBO);
+    static const int esplit_env0 = MXF_KNOB("MXF_POTRF_EAGER_SPLIT", 1);
+    const bool kacc = eager && Kacc != nullptr && kacc_env && esplit_env0 && !rows2_env && h->potrf_acc;
+    if (kacc) {     // (the buffer is zeroed on the accumulation stream, behind whatever the caller's stream did with it before)
+        MXF_HIP(h, hipEventRecord(h->ev_pq, st));
+        MXF_HIP(h, hipStreamWaitEvent(h->potrf_acc, h->ev_pq, 0));
+        MXF_HIP(h, hipMemsetAsync(Kacc, 0, sizeof(T) * (size_t)n * (size_t)ldk, h->potrf_acc));
+    }
     static const int split_rows_g = MXF_KNOB("MXF_POTRF_SPLIT_ROWS", 64);
     static const int rows_env_g = MXF_KNOB("MXF_POTRF_ROWS_KERNEL", 1);     // 0: the rows below through potrf_tiles_kernel (r02)
     static const int head_split_env = MXF_KNOB("MXF_POTRF_HEAD_SPLIT", 1);  // 1: the next panel's rows-below head update on the auxiliary stream
@@ -1070,6 +1097,15 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
                     MXF_HIP(h, hipEventRecord(h->ev_pc, qd));
                     MXF_HIP(h, hipStreamWaitEvent(qp, h->ev_pc, 0));       // (block 0: p1 of block 1 reads this inverse)
                     if (rb0 > 0) { rc = trtri_row_block_p2<T>(h, dtype, rb0, pe, Ie, ldie, qp); if (rc) return rc; }
+                    if (kacc) {
+                        // rows [rb0, pe) of L^-1 are final (columns < pe; zero beyond): their share of kcoef L^-T L^-1, on a stream of its own so
+                        // that the next block's p1 is not held up behind it (the shares update the same tiles: one stream keeps them in order)
+                        MXF_HIP(h, hipEventRecord(h->ev_pq, qp));
+                        MXF_HIP(h, hipStreamWaitEvent(h->potrf_acc, h->ev_pq, 0));
+                        rc = mxf_gemm_internal(h, dtype, 1, 0, pe, pe, pe - rb0, kcoef, Ie + rb0 * ldie, ldie, 0, Ie + rb0 * ldie, ldie, 0, 1.0, Kacc, ldk, 0,
+                                               1, 1, h->potrf_acc, 0, 0);
+                        if (rc) return rc;
+                    }
                     if (pe < n) {
                         MXF_HIP(h, hipStreamWaitEvent(qp, h->ev_pi, 0));   // the rows below the panel that just ended
                         int64_t ne = pe + NBO;                           // the end of the next row block = the next firing point
@@ -1149,12 +1185,21 @@ int potrf_typed(mxf_ctx* h, int dtype, int S, int64_t n, T* A, int64_t lda, int6
         MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pj, 0));
         if (eager_done) *eager_done = true;
     }
+    if (kacc) {
+        MXF_HIP(h, hipEventRecord(h->ev_pz, h->potrf_acc));
+        MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pz, 0));
+        if (kacc_done) *kacc_done = true;
+    }
     if (pending_r) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_rb, 0));
     if (pending_b) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_pb, 0));
     if (pending_h) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_ph, 0));      // (never pending here today: the last panel has no successor; kept so that the caller's stream always joins the auxiliary one)
     if (n > 1 && zero_upper) {      // (internal callers that only ever read the lower triangle skip this pass)
         if (n > 65535) MXF_FAIL(h, -3, "mxf_potrf: n too large");
         hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)n, S), dim3(256), 0, st, A, n, lda, sA);
+    }
+    if (own_chain) {
+        MXF_HIP(h, hipEventRecord(h->ev_pk, st));
+        MXF_HIP(h, hipStreamWaitEvent(st_user, h->ev_pk, 0));
     }
     MXF_LAUNCH_CHECK(h);
     return 0;
@@ -1199,11 +1244,13 @@ int trsm_typed(mxf_ctx* h, int dtype, int transpose, int S, int64_t n, int64_t n
 }  // namespace
 
 int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper, bool zero_info,
-                       void* Linv_eager, int64_t ldie, bool* eager_done) {
+                       void* Linv_eager, int64_t ldie, bool* eager_done, void* Kacc, int64_t ldk, double kcoef, bool* kacc_done) {
     if (eager_done) *eager_done = false;
+    if (kacc_done) *kacc_done = false;
     if (n <= 0 || S <= 0) return 0;
     if (dtype == MXF_F32) return potrf_typed<float>(h, dtype, S, n, (float*)A, lda, sA, info, st, zero_upper, zero_info);
-    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper, zero_info, (double*)Linv_eager, ldie, eager_done);
+    if (dtype == MXF_F64) return potrf_typed<double>(h, dtype, S, n, (double*)A, lda, sA, info, st, zero_upper, zero_info, (double*)Linv_eager, ldie, eager_done,
+                                                     (double*)Kacc, ldk, kcoef, kacc_done);
     MXF_FAIL(h, -2, "mxf_potrf: bad dtype %d", dtype);
 }
 

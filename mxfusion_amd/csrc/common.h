@@ -80,6 +80,12 @@ struct mxf_ctx {
     hipEvent_t ev_pi = nullptr, ev_pj = nullptr;
     hipStream_t potrf_rows = nullptr;                       // r06: the rows FAR below an outer panel are solved here, next to the next panel's chain
     hipEvent_t ev_pc = nullptr, ev_rb = nullptr;
+    hipStream_t potrf_acc = nullptr;                        // r06: kcoef L^-T L^-1 accumulated row block by row block of the eager inverse
+    hipEvent_t ev_pq = nullptr, ev_pz = nullptr;
+    hipStream_t potrf_chain = nullptr;                      // r06 (MXF_POTRF_CUMASK): the factorisation's own chain stream when the bulk streams are CU-masked
+    hipEvent_t ev_pk = nullptr;
+    bool potrf_chain_always = false;
+    bool potrf_masked = false;                              // potrf_aux / potrf_inv were created with a CU mask (blocking streams: see mxf_potrf_aux_init)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
     hipEvent_t ev_tg = nullptr;       // the T product has been enqueued / finished (whitened few-sample form: Phi runs behind it)
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
@@ -202,17 +208,51 @@ static inline void* mxf_ws(mxf_ctx* h, size_t bytes) {
 static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
     if (h->potrf_aux_ready) return true;
     // all or nothing: a partial failure leaves NO auxiliary stream / event behind (the callers gate look-ahead on the return value)
-    bool ok = hipStreamCreateWithFlags(&h->potrf_aux, hipStreamNonBlocking) == hipSuccess;
+    // MXF_POTRF_CUMASK = c > 0: the two streams that carry the bulk products next to the factorisation (trailing updates, eager inverse)
+    // are created with a CU mask that leaves c CUs of every XCD to the caller's stream -- the latency chain's few workgroups (76 KB of LDS
+    // each) cannot share a CU with a 133 KB product workgroup and otherwise queue behind whole product workgroups.  The excluded set
+    // {32 x + (x + 8 j) % 32 : x < 8, j < c} holds c CUs per XCD whether mask bit i means (XCD i % 8, CU i / 8) or (XCD i / 32, CU i % 32).
+    static const int cumask_env = (int)MXF_KNOB("MXF_POTRF_CUMASK", 0);
+    auto make_stream = [&](hipStream_t* s_) -> bool {
+        if (cumask_env > 0 && cumask_env < 32) {
+            uint32_t mask[8];
+            for (int x = 0; x < 8; ++x) {
+                mask[x] = 0xffffffffu;
+                for (int j = 0; j < cumask_env; ++j) mask[x] &= ~(1u << ((x + 8 * (j % 4) + (j / 4)) % 32));
+            }
+            if (hipExtStreamCreateWithCUMask(s_, 8, mask) == hipSuccess) { h->potrf_masked = true; return true; }
+            (void)hipGetLastError();
+        }
+        return hipStreamCreateWithFlags(s_, hipStreamNonBlocking) == hipSuccess;
+    };
+    bool ok = make_stream(&h->potrf_aux);
     if (!ok) h->potrf_aux = nullptr;
-    ok = ok && hipStreamCreateWithFlags(&h->potrf_inv, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && make_stream(&h->potrf_inv);
     if (!ok) h->potrf_inv = nullptr;
     ok = ok && hipStreamCreateWithFlags(&h->potrf_rows, hipStreamNonBlocking) == hipSuccess;
     if (!ok) h->potrf_rows = nullptr;
-    hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj, &h->ev_pc, &h->ev_rb};
+    // CU-masked streams are created WITHOUT hipStreamNonBlocking (the API has no flags): they synchronise with the legacy default stream,
+    // which is PyTorch's default stream -- so in that mode the factorisation's chain runs on a non-blocking stream of its own, forked from
+    // and joined to the caller's stream, and nothing is launched on the caller's stream in between
+    // MXF_POTRF_CHAIN_PRIO=1 (probe): the chain on a most-urgent stream of its own even without the masks
+    static const int chain_prio_env = (int)MXF_KNOB("MXF_POTRF_CHAIN_PRIO", 0);
+    if (chain_prio_env) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        ok = ok && hipStreamCreateWithPriority(&h->potrf_chain, hipStreamNonBlocking, hi) == hipSuccess;
+        if (ok) h->potrf_chain_always = true;
+    } else
+    ok = ok && hipStreamCreateWithFlags(&h->potrf_chain, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) h->potrf_chain = nullptr;
+    ok = ok && make_stream(&h->potrf_acc);
+    if (!ok) h->potrf_acc = nullptr;
+    hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj, &h->ev_pc, &h->ev_rb, &h->ev_pk, &h->ev_pq, &h->ev_pz};
     for (hipEvent_t* e : evs)
         if (ok && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; ok = false; }
     if (!ok) {
         for (hipEvent_t* e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        if (h->potrf_acc) { (void)hipStreamDestroy(h->potrf_acc); h->potrf_acc = nullptr; }
+        if (h->potrf_chain) { (void)hipStreamDestroy(h->potrf_chain); h->potrf_chain = nullptr; }
         if (h->potrf_rows) { (void)hipStreamDestroy(h->potrf_rows); h->potrf_rows = nullptr; }
         if (h->potrf_inv) { (void)hipStreamDestroy(h->potrf_inv); h->potrf_inv = nullptr; }
         if (h->potrf_aux) { (void)hipStreamDestroy(h->potrf_aux); h->potrf_aux = nullptr; }

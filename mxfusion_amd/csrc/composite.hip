@@ -253,8 +253,12 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
     static const int tri_skinny_env = (int)MXF_KNOB("MXF_GP_TRI_SKINNY", 1);
     const bool tri_skinny = via_inverse && S == 1 && P <= 8 && tri_skinny_env != 0;
     // (r05) float64, one matrix: the factorisation forms L^-1 itself, row block by row block on a third stream next to its serial chain
-    bool inv_done = false;
-    rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st, true, true, (via_inverse && S == 1 && sizeof(T) == 8) ? (void*)Linv : nullptr, N, &inv_done);   // :61
+    // (r06) ... and -P/2 L^-T L^-1, the bulk of dlogL/dK, is accumulated row block by row block of that inverse as well (the chip is half idle
+    // under the factorisation's serial chain; behind it only the last row block's share is left)
+    bool inv_done = false, kacc_done = false;
+    T* dK_early = (tri_skinny && sizeof(T) == 8) ? cv.take<T>((size_t)S * NN) : nullptr;
+    rc = mxf_potrf_internal(h, dtype, S, N, L, N, NN, info, st, true, true, (via_inverse && S == 1 && sizeof(T) == 8) ? (void*)Linv : nullptr, N, &inv_done,
+                            dK_early, N, -0.5 * P, &kacc_done);   // :61
     if (rc) return rc;
     if (via_inverse) {
         if (!inv_done) rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
@@ -282,14 +286,16 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
         rc = mxf_trtri_internal(h, dtype, S, N, L, N, NN, Linv, N, NN, st);
         if (rc) return rc;
     }
-    T* dK = cv.take<T>((size_t)S * NN);
+    T* dK = dK_early ? dK_early : cv.take<T>((size_t)S * NN);
     T* alpha = cv.take<T>((size_t)S * NP);
     if (tri_skinny) {
         MXF_HIP(h, hipMemsetAsync(alpha, 0, sizeof(T) * NP, st));
         hipLaunchKernelGGL((trmv_lower_t_kernel<T>), dim3((unsigned)((N + 255) / 256), (unsigned)((N + 127) / 128)), dim3(256), 0, st, N, P, (const T*)Linv, N,
                            (const T*)LinvY, alpha);                                                                 // alpha = Linv^T LinvY
+        if (!kacc_done) {
         rc = mxf_gemm_internal(h, dtype, 1, 0, N, N, N, -0.5 * P, Linv, N, NN, Linv, N, NN, 0.0, dK, N, NN, S, 1, st, 0, 1);
         if (rc) return rc;
+        }
         hipLaunchKernelGGL((symmetrize_rankp_kernel<T>), dim3((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, dK, N, N, (const T*)alpha, P, (T)0.5);
     } else {
     rc = mxf_gemm_internal(h, dtype, 1, 0, N, P, N, 1.0, Linv, N, NN, LinvY, P, NP, 0.0, alpha, P, NP, S, 0, st);   // alpha = Linv^T LinvY

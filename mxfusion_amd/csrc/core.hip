@@ -47,6 +47,11 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->potrf_rows) (void)hipStreamDestroy(h->potrf_rows);
     if (h->ev_pc) (void)hipEventDestroy(h->ev_pc);
     if (h->ev_rb) (void)hipEventDestroy(h->ev_rb);
+    if (h->potrf_acc) (void)hipStreamDestroy(h->potrf_acc);
+    if (h->ev_pq) (void)hipEventDestroy(h->ev_pq);
+    if (h->ev_pz) (void)hipEventDestroy(h->ev_pz);
+    if (h->potrf_chain) (void)hipStreamDestroy(h->potrf_chain);
+    if (h->ev_pk) (void)hipEventDestroy(h->ev_pk);
     delete h;
     return 0;
 }

@@ -12,7 +12,10 @@ int mxf_gemm_internal(mxf_ctx* h, int dtype, int ta, int tb, int64_t M, int64_t 
 // zero_upper = false: leave the strict upper triangle outside the 64 x 64 diagonal blocks as it was (callers that only read the lower part)
 // zero_info = false: the caller has zeroed `info` already (the SVGP composite clears its status words in one launch off the critical path)
 int mxf_potrf_internal(mxf_ctx* h, int dtype, int S, int64_t n, void* A, int64_t lda, int64_t sA, int* info, hipStream_t st, bool zero_upper = true,
-                       bool zero_info = true, void* Linv_eager = nullptr, int64_t ldie = 0, bool* eager_done = nullptr);
+                       bool zero_info = true, void* Linv_eager = nullptr, int64_t ldie = 0, bool* eager_done = nullptr,
+                       void* Kacc = nullptr, int64_t ldk = 0, double kcoef = 0.0, bool* kacc_done = nullptr);
+// (Kacc, with Linv_eager: kcoef L^-T L^-1 (lower triangle) is accumulated into this ZEROED n x n buffer row block by row block of L^-1, next to
+//  the factorisation as well -- L^-T L^-1 = sum over row blocks b of Linv[b, :]^T Linv[b, :]; *kacc_done says whether it was)
 // (Linv_eager: float64, S = 1, large n: L^-1 is formed into this (n x n, leading dimension ldie) buffer NEXT TO the factorisation, row block by row
 //  block on a third stream; *eager_done says whether it was -- if not, the caller runs mxf_trtri_internal as before)
 // rhs_lower: B is block-lower-triangular (trtri); only columns < (k+1)*64 of block row k are touched
