@@ -495,8 +495,37 @@ __global__ void aki_kernel(int64_t M, int P, const double* __restrict__ G, const
         const int64_t i = idx / M, j = idx % M;
         double v = G[idx] - T1[idx] - T1[j * M + i];
         double r1 = 0, mm = 0;
-        for (int p = 0; p < P; ++p) { r1 += Gw[i * P + p] * mu[j * P + p] + mu[i * P + p] * Gw[j * P + p]; mm += mu[i * P + p] * mu[j * P + p]; }
+        for (int p = 0; p < P; ++p) { if (Gw) r1 += Gw[i * P + p] * mu[j * P + p] + mu[i * P + p] * Gw[j * P + p]; mm += mu[i * P + p] * mu[j * P + p]; }
         A[idx] = v + 0.5 * r1 - b * (0.5 * P * Su[idx] + 0.5 * mm);
+    }
+}
+// (r06) dSu = -X + c (Su^-1 - Ki)
+__global__ void dsu_kernel(int64_t n, const double* __restrict__ X, const double* __restrict__ Sui, const double* __restrict__ Ki, double c, double* __restrict__ dSu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dSu[i] = c * (Sui[i] - Ki[i]) - X[i];
+}
+// (r06) dKuu0 = -X + Y + Y^T + b (P/2 KSK + 1/2 w w^T) - bP/2 Ki,  KSK = Ki Su Ki given or = Ki - H0
+__global__ void dkuu0_kernel(int64_t M, int P, const double* __restrict__ X, const double* __restrict__ Y, const double* __restrict__ Ki, const double* __restrict__ KSK,
+                             const double* __restrict__ H0, const double* __restrict__ w, double b, double* __restrict__ dKuu) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * M; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / M, j = idx % M;
+        double ww = 0;
+        for (int p = 0; p < P; ++p) ww += w[i * P + p] * w[j * P + p];
+        const double ksk = KSK ? KSK[idx] : Ki[idx] - H0[idx];
+        dKuu[idx] = -X[idx] + Y[idx] + Y[j * M + i] + b * (0.5 * P * ksk + 0.5 * ww) - 0.5 * b * P * Ki[idx];
+    }
+}
+// (r06) Gw == nullptr above: the part A0 of A_Ki that does not depend on the reverse pass's R.  -Ki A_Ki Ki is linear in A_Ki and
+// Ki (Gw mu^T) Ki = (Ki Gw)(Ki mu)^T = v w^T, so the two M^3 products run on A0 under the T product / the reverse pass and what is left for the
+// step's tail is the rank-2P term:  dKuu -= 1/2 (v w^T + w v^T),  v = Ki Gw = dmu + b w  (dmu = Ki Gw - b w is formed anyway)
+__global__ void dkuu_rank_kernel(int64_t M, int P, const double* __restrict__ dmu, const double* __restrict__ w, double b, double* __restrict__ dKuu) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * M; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / M, j = idx % M;
+        double r = 0;
+        for (int p = 0; p < P; ++p) {
+            const double vi = dmu[i * P + p] + b * w[i * P + p], vj = dmu[j * P + p] + b * w[j * P + p];
+            r += vi * w[j * P + p] + w[i * P + p] * vj;
+        }
+        dKuu[idx] -= 0.5 * r;
     }
 }
 // G' = (P/2 * a1 * beta) * Psi2 ; Gw = a1*beta*R   (beta on device)
@@ -1333,6 +1362,13 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // the part of the core reverse mode that depends on Psi2 only (not on R): dSu = -Ki G Ki + bP/2 (Su^-1 - Ki), dW = 2 dSu W,
     // dSdiag = diag(dSu), T1 = G Ki Su.  Streaming path: queued on the side stream right behind Psi2, so it runs under the T GEMM /
     // the reverse pass instead of in the step's tail.
+    // (r06) float32 mode: the whole R-independent part of the core's reverse mode -- dKuu0 included -- on the side stream, from X = Ki G Ki (below).
+    // float64 mode keeps the r05 flow: forming A_Ki = G - G Ki Su - ... FIRST and multiplying by Ki afterwards cancels before it amplifies; the X form
+    // multiplies first and loses ~2 digits on ill-conditioned Kuu (uncertain-input toy of tests/test_gpu_config4.py, cond ~ 1e6: float64 lengthscale
+    // gradient 8.6e-10 -> 5.8e-8 against the oracle, tests/probes/r06_early_kuu_accuracy.py) -- nothing next to float32 streaming (1e-5), but the
+    // float64 path is the parity path.  Probe knob MXF_SVGP_EARLY_KUU: 0 = r05 flow everywhere, 2 = X form in float64 too.
+    static const int early_kuu_env = (int)MXF_KNOB("MXF_SVGP_EARLY_KUU", 1);
+    const bool early_kuu = early_kuu_env == 2 || (early_kuu_env != 0 && sizeof(T) == 4);
     auto su_reverse = [&](hipStream_t s_, bool with_t1) -> int {
         int r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, s_);            // T3 = Ki G
         if (r_) return r_;
@@ -1348,7 +1384,49 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (with_t1) r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, s_);           // T1 = G Ki Su
         return r_;
     };
-    if (want_grad && !het) {
+    if (want_grad && !het && early_kuu) {
+        // r06: the whole R-independent part of the core's reverse mode from X = Ki G Ki (G = c Psi2, c = P a1 beta / 2):
+        //   dSu   = -X + bP/2 (Su^-1 - Ki)                                  (as before)
+        //   dKuu0 = -Ki A0 Ki - bP/2 Ki,  A0 = G - T1 - T1^T - b (P/2 Su + 1/2 mu mu^T),  T1 = G Ki Su
+        //         = -X + Y + Y^T + b (P/2 Ki Su Ki + 1/2 w w^T) - bP/2 Ki,  Y = X (Ki Su)^T,  Ki Su Ki = Ki - H0 (explicit form)
+        // i.e. FOUR M^3 products (Ki G, . Ki, dSu W, X (Ki Su)^T) where the r05 flow took six (Ki G, . Ki, dSu W, G Ki Su, Ki A, . Ki), the last two
+        // of them in the step's tail behind the reverse pass.  Whitened form: X = c L^-T Phi L^-1 directly (Phi = V V^T; G = c L Phi L^T is never
+        // formed) + Ki Su Ki as a product: five instead of eight.  These products run on the CUs the T product leaves free (few samples: 40), so
+        // their number is the length of the side stream: stage stamps at 4 samples, r05 flow: Su reverse ends 3.70 ms, reverse pass 3.54, end 3.97.
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu, H0 (main)
+        MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
+        D* Xb = whiten ? G : T2;
+        if (whiten) {
+            hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, T2);   // c Phi
+            hipLaunchKernelGGL((trace_kernel<D>), dim3(1), dim3(256), 0, sd_, M, (const D*)T2, M, (int64_t)0, sc + 6);                                 // c tr(Phi)
+            rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, T2, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);       // L^-T (c Phi)
+            if (rc) return rc;
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Linv, M, 0, 0.0, Xb, M, 0, 1, 0, sd_);       // X = c L^-T Phi L^-1
+            if (rc) return rc;
+            hipLaunchKernelGGL(dot_t_kernel, dim3(dotgrid(MM)), dim3(256), 0, sd_, M, (const D*)Su, (const D*)Xb, sc + 7);   // tr(Su X): the accurate total of the q_n
+        } else {
+            hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);           // Ki G
+            if (rc) return rc;
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Ki, M, 0, 0.0, Xb, M, 0, 1, 0, sd_);          // X = Ki G Ki
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(dsu_kernel, dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const D*)Xb, (const D*)Sui, (const D*)Ki, 0.5 * bw * P, dSu);
+        if (dW) {
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, Lsinv, M, 0, 1, 0, sd_);     // dW = 2 dSu W (Lsinv buffer is free)
+            if (rc) return rc;
+            hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (T)1, (const D*)Lsinv, dW, 0);
+        }
+        if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, sd_, M, (const D*)dSu, M, dSdiag);
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Xb, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, sd_);             // Y = X (Ki Su)^T
+        if (rc) return rc;
+        if (whiten) {
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, KiSu, M, 0, Ki, M, 0, 0.0, AKi, M, 0, 1, 0, sd_);        // Ki Su Ki (H0 holds Hh in this form)
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(dkuu0_kernel, dim3(gridn(MM)), dim3(256), 0, sd_, M, P, (const D*)Xb, (const D*)T1, (const D*)Ki, whiten ? (const D*)AKi : (const D*)nullptr,
+                           (const D*)H0, (const D*)wd, bw, dKuu);
+    } else if (want_grad && !het) {
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu (main)
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
         if (whiten) {
@@ -1369,8 +1447,10 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             hipLaunchKernelGGL((trace_kernel<D>), dim3(1), dim3(256), 0, sd_, M, (const D*)T2, M, (int64_t)0, sc + 6);
             hipLaunchKernelGGL(dot_t_kernel, dim3(dotgrid(MM)), dim3(256), 0, sd_, M, (const D*)KiSu, (const D*)tmp, sc + 7);
         }
+    }
+    if (want_grad && !het) {
         MXF_STAGE(h, "Su reverse (sd)", sd_);
-        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs
+        MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs (early_kuu: dKuu0 as well)
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
@@ -1459,15 +1539,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
     }
     // main: dKuu = -Ki A_Ki Ki - bP/2 Ki; dmu = Ki Gw - b w
+    if (!(early_kuu && !het)) {
     hipLaunchKernelGGL(aki_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)G, (const D*)T1, (const D*)Gw, (const D*)mud, (const D*)Su, bw, AKi);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, AKi, M, 0, 0.0, T2, M, 0, 1, 0, st);           // T2 = Ki A_Ki
     if (rc) return rc;
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, dKuu, MM);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);
     if (rc) return rc;
+    }
     hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);
     if (rc) return rc;
+    if (early_kuu && !het) hipLaunchKernelGGL(dkuu_rank_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)dmud, (const D*)wd, bw, dKuu);
     // Kuu-side reverse mode in float64, then added to the streaming-side gradients
     FinishArgs fa;
     fa.cnt = 0;
