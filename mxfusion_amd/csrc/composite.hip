@@ -1396,20 +1396,24 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu, H0 (main)
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
         D* Xb = whiten ? G : T2;
+        static const int xlow_env = (int)MXF_KNOB("MXF_SVGP_X_LOWER", 1);
+        const int xlow = xlow_env ? 1 : 0;
         if (whiten) {
             hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, T2);   // c Phi
             hipLaunchKernelGGL((trace_kernel<D>), dim3(1), dim3(256), 0, sd_, M, (const D*)T2, M, (int64_t)0, sc + 6);                                 // c tr(Phi)
             rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, T2, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);       // L^-T (c Phi)
             if (rc) return rc;
-            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Linv, M, 0, 0.0, Xb, M, 0, 1, 0, sd_);       // X = c L^-T Phi L^-1
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Linv, M, 0, 0.0, Xb, M, 0, 1, xlow, sd_);    // X = c L^-T Phi L^-1 (symmetric: lower tiles, mirrored)
             if (rc) return rc;
+            if (xlow) hipLaunchKernelGGL((symmetrize_kernel<D>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Xb, M, M, MM);
             hipLaunchKernelGGL(dot_t_kernel, dim3(dotgrid(MM)), dim3(256), 0, sd_, M, (const D*)Su, (const D*)Xb, sc + 7);   // tr(Su X): the accurate total of the q_n
         } else {
             hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const T*)Psi2, (const D*)noised, 0.5 * P * a1, G);
             rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, Ki, M, 0, G, M, 0, 0.0, tmp, M, 0, 1, 0, sd_);           // Ki G
             if (rc) return rc;
-            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Ki, M, 0, 0.0, Xb, M, 0, 1, 0, sd_);          // X = Ki G Ki
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, tmp, M, 0, Ki, M, 0, 0.0, Xb, M, 0, 1, xlow, sd_);       // X = Ki G Ki (symmetric: lower tiles, mirrored)
             if (rc) return rc;
+            if (xlow) hipLaunchKernelGGL((symmetrize_kernel<D>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Xb, M, M, MM);
         }
         hipLaunchKernelGGL(dsu_kernel, dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const D*)Xb, (const D*)Sui, (const D*)Ki, 0.5 * bw * P, dSu);
         if (dW) {
