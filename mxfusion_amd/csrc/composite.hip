@@ -1351,8 +1351,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         constexpr int VEC = Vec16<T>::n;
         dim3 gu((unsigned)((SB + 256 * VEC - 1) / (256 * VEC)));
 #ifndef MXF_NO_WTSPLIT
-        if (gu.x < 128 && M >= 64) {             // few columns: split the rows as well (the kernel then adds into U)
-            int64_t ch = 512 / gu.x; if (ch > M / 16) ch = M / 16; if (ch > 64) ch = 64;
+        if (gu.x <= 256 && M >= 64) {            // few columns: split the rows as well (the kernel then adds into U)
+            // (r06: up to one workgroup per CU -- 512 x 131 072, the deep GP's first layer, was 128 workgroups walking 512 dependent rows: 0.24 ms)
+            int64_t ch = 1024 / gu.x; if (ch > M / 16) ch = M / 16; if (ch > 64) ch = 64;
             if (ch > 1) { gu.y = (unsigned)ch; MXF_HIP(h, hipMemsetAsync(Text + M * SB, 0, sizeof(T) * (size_t)P * SB, st)); }
         }
 #endif

@@ -18,6 +18,9 @@ python $R/profiles/timeline.py $(find $O/trace_s4 -name "*kernel_trace.csv") 0.0
 # 4. the exact-GP MAP step (BASELINE configs[1])
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_gp -o bench -- python $R/bench.py --workload gp --dtype float64 --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_trace_gp.log 2>&1
 python $R/profiles/timeline.py $(find $O/trace_gp -name "*kernel_trace.csv") 0.1 > $O/r06_exact_gp_timeline.txt 2>&1
+# 4b. the deep GP step (BASELINE configs[4])
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dgp -o bench -- python $R/bench.py --workload deepgp --samples 32 --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_trace_dgp.log 2>&1
+python $R/profiles/timeline.py $(find $O/trace_dgp -name "*kernel_trace.csv") 0.25 > $O/r06_deepgp_timeline.txt 2>&1
 for d in full step whitened s4 gp; do cp $(find $O/trace_$d -name "*kernel_stats.csv" | head -1) $O/r06_kernel_stats_$d.csv; done
 # 5. PMC passes: the Gram kernel (HBM traffic per launch), the T product of r05 (t), the K-major T product of r06 with its U row (tbt), Psi2
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_gram_write -o gram -- python $R/tests/probes/gram_f32.py > $O/pmc_gram_write.log 2>&1
@@ -55,4 +58,7 @@ try:
 except Exception as e: print(sys.argv[1], 'ERR', e)
 PY
 done
+python tests/probes/svgp_stages.py 32 > $O/r06_stage_stamps.txt 2>&1
+python tests/probes/svgp_stages.py 4 > $O/r06_stage_stamps_4samples.txt 2>&1
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > $O/r06_gpu_suite_summary.txt
 ls $O
