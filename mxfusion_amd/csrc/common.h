@@ -87,6 +87,7 @@ struct mxf_ctx {
     bool potrf_chain_always = false;
     bool potrf_masked = false;                              // potrf_aux / potrf_inv were created with a CU mask (blocking streams: see mxf_potrf_aux_init)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_su = nullptr;
+    hipEvent_t ev_k1 = nullptr, ev_k2 = nullptr, ev_k3 = nullptr;   // r06: the SVGP call's condition norms and value scalars leave the caller's stream (composite.hip)
     hipEvent_t ev_tg = nullptr;       // the T product has been enqueued / finished (whitened few-sample form: Phi runs behind it)
     void* gram_ws = nullptr;   // pre-scaled coordinates of mxf_gram (separate: composites hold `ws` while calling mxf_gram)
     size_t gram_ws_bytes = 0;
@@ -283,7 +284,10 @@ static inline bool mxf_side_init(mxf_ctx* h) {
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_tg, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess) return false;
+        hipEventCreateWithFlags(&h->ev_su, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_k1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_k2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_k3, hipEventDisableTiming) != hipSuccess) return false;
     return true;
 }
 

@@ -161,6 +161,28 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(int64_t n, int P, const
         if (p < P) { const T t = wave_sum(acc[p]); if (lane == 0) y[r * P + p] = t; }
     }
 }
+// y = A x for a full (n x n) matrix, one wave per row (r06: w = Ki mu of the SVGP chain -- the small-product kernel with its split-K pre-scale took 0.2 ms
+// of the few-sample step's critical path for an 8 MB read)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int64_t n, int P, const T* __restrict__ A, int64_t lda, const T* __restrict__ x, int64_t ldx, T* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    T acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = 0;
+    const T* a = A + r * lda;
+#pragma unroll 4
+    for (int64_t c = lane; c < n; c += 64) {
+        const T v = a[c];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (p < P) acc[p] = fma(v, x[c * ldx + p], acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p < P) { const T t = wave_sum(acc[p]); if (lane == 0) y[r * P + p] = t; }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_lower_t_kernel(int64_t n, int P, const T* __restrict__ A, int64_t lda, const T* __restrict__ x, T* __restrict__ y) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, r0 = (int64_t)blockIdx.y * 128;
@@ -1143,6 +1165,17 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     static const int chain_late = (int)MXF_KNOB("MXF_SVGP_CHAIN_LATE", 0);
     const bool late = chain_late && bt_path && want_grad && SB > 2 * 192 * M;
     if (late) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));
+    // r06 (MXF_SVGP_OFFPATH, default on): what the T product does not need leaves the caller's stream -- the two condition norms (64 workgroups walking
+    // 16 rows each: 0.05 ms alone, 0.22 ms in front of the factorisation while the planes pass holds every CU), mu.w, tr(Ki Su), log|Kuu| go to
+    // the second side stream; w = Ki mu is a one-wave-per-row kernel.  Kuu is copied for its norm (the factorisation works in place).
+    static const int offpath_env = (int)MXF_KNOB("MXF_SVGP_OFFPATH", 1);
+    const bool offpath = offpath_env != 0;
+    if (offpath) {
+        hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Lm, MM, Sui, MM);     // (Su^-1's buffer: written at the end of the Su chain, on the same stream as the norm)
+        MXF_HIP(h, hipEventRecord(h->ev_k1, st));
+        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_k1, 0));
+        hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s2_, M, (const double*)Sui, M, h->cond_dev);
+    } else
     hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Lm, M, h->cond_dev);
     rc = mxf_potrf_internal(h, MXF_F64, 1, M, Lm, M, MM, info, st, false, false);                     // L :83 (trtri / sumlogdiag read the lower triangle only)
     if (rc) return rc;
@@ -1184,8 +1217,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
         // a = L^-1 mu (float64, then the streaming dtype): the V product's epilogue forms U = a^T V from it
         MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                              // mu (second side stream)
+        if (offpath) hipLaunchKernelGGL((trmv_lower_kernel<D>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, P, (const D*)Linv, M, (const D*)mud, (int64_t)P, ad);
+        else {
         rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Linv, M, 0, mud, P, 0, 0.0, ad, P, 0, 1, 0, st);
         if (rc) return rc;
+        }
         hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)ad, MP, aT, MP);
         MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                                                   // L^-1 planes and a ready
         // side stream: V = L^-1 Kuf, written as the planes of the (m, k = n) operand holding V / sigma * 2^14 (|v_n|^2 <= k_nn = sigma^2):
@@ -1223,16 +1259,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
     if (rc) return rc;
-    hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
+    if (!offpath) hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
+    if (offpath) hipLaunchKernelGGL((gemv_rows_kernel<D>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, P, (const D*)Ki, M, (const D*)mud, (int64_t)P, wd);   // w = Ki mu
+    else {
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, mud, P, 0, 0.0, wd, P, 0, 1, 0, st);       // w = Ki mu
     if (rc) return rc;
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+    }
+    if (!offpath) hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, st, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, (int64_t)1, MP, (const D*)wd, MP, wT, MP);      // w in the streaming dtype
     MXF_STAGE(h, "Ki, w", st);
     if (use_split && !whiten) MXF_HIP(h, hipEventRecord(h->ev_aux2, st));                             // w ready: the Kfu planes + U pass may start
-    rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st);
-    if (rc) return rc;
+    if (!offpath) { rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, st); if (rc) return rc; }
     // ---- second side stream: Su -> Ls -> Su^-1 ----------------------------------------------------------------------------------
     // (a plain kernel, not hipMemcpyAsync: the runtime's copy path sat idle for ~1 ms before it started next to busy queues -- r02 timeline:
     //  the Su chain did not begin until 1.66 ms although nothing in the Kuu chain feeds it)
@@ -1279,7 +1317,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
     }
-    hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
+    if (!offpath) hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
     // A_ext = [H0 ; w^T] in the streaming dtype
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
     hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
@@ -1298,6 +1336,15 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     MXF_T1(h, MXF_T_CHAIN, st);
     MXF_STAGE(h, "H0 planes", st);
     MXF_HIP(h, hipEventRecord(h->ev_fork, st));                                                       // core (Ki, KiSu, H0, w) ready
+    if (offpath) {      // |Ki|_1, mu.w, tr(Ki Su), log|Kuu| behind the Su chain on the second side stream; the caller's stream picks them up behind the T product
+        MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_fork, 0));
+        hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s2_, M, (const double*)Ki, M, h->cond_dev + 1);
+        hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MP)), dim3(256), 0, s2_, MP, (const D*)mud, (const D*)wd, 1.0, sc + 3);
+        hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, s2_, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
+        rc = mxf_sumlogdiag_internal(h, MXF_F64, 1, M, Lm, M, MM, sc + 0, s2_);
+        if (rc) return rc;
+        MXF_HIP(h, hipEventRecord(h->ev_k3, s2_));
+    }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_aux, 0));                                                 // Kuf_all from the side stream
     // (in-step timing only: the T product is held until Psi2 has finished, so that `t_gemm` is the product's own duration -- untimed, its
     //  first workgroups take the CUs Psi2's last work items free, and the event pair would count that queueing)
@@ -1458,6 +1505,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_HIP(h, hipEventRecord(h->ev_join2, sd_));            // Psi2, G, T1, dSu outputs (early_kuu: dKuu0 as well)
     }
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));      // Su chain complete (log-det for the value, Su^-1 for the reverse mode); hidden under the T GEMM
+    if (offpath) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_k3, 0));      // ... and the condition norms and value scalars behind it
     const int dY_shared = (sY == 0 && SS > 1) ? 1 : 0;
     D* dnz = nullptr; D* dvdir = nullptr;
     if (het) {

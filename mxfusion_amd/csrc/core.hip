@@ -35,6 +35,9 @@ extern "C" int mxf_destroy(mxf_handle h) {
     if (h->ev_aux2) (void)hipEventDestroy(h->ev_aux2);
     if (h->ev_tg) (void)hipEventDestroy(h->ev_tg);
     if (h->ev_su) (void)hipEventDestroy(h->ev_su);
+    if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
+    if (h->ev_k2) (void)hipEventDestroy(h->ev_k2);
+    if (h->ev_k3) (void)hipEventDestroy(h->ev_k3);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->potrf_aux) (void)hipStreamDestroy(h->potrf_aux);
