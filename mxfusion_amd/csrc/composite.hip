@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(int64_t n, int P, const
 // y = A x for a full (n x n) matrix, one wave per row (r06: w = Ki mu of the SVGP chain -- the small-product kernel with its split-K pre-scale took 0.2 ms
 // of the few-sample step's critical path for an 8 MB read)
 template <typename T>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(int64_t n, int P, const T* __restrict__ A, int64_t lda, const T* __restrict__ x, int64_t ldx, T* __restrict__ y) {
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int64_t n, int P, const T* __restrict__ A, int64_t lda, const T* __restrict__ x, int64_t ldx, T* __restrict__ y,
+                                                        T c = 0, const T* __restrict__ z = nullptr /* y = A x + c z */) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int64_t n, int P, const 
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-        if (p < P) { const T t = wave_sum(acc[p]); if (lane == 0) y[r * P + p] = t; }
+        if (p < P) { const T t = wave_sum(acc[p]); if (lane == 0) y[r * P + p] = z ? t + c * z[r * P + p] : t; }
     }
 }
 template <typename T>
@@ -1600,9 +1601,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, T2, M, 0, Ki, M, 0, -0.5 * bw * P, dKuu, M, 0, 1, 0, st);
     if (rc) return rc;
     }
+    if (offpath) hipLaunchKernelGGL((gemv_rows_kernel<D>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, P, (const D*)Ki, M, (const D*)Gw, (int64_t)P, dmud, -bw, (const D*)wd);
+    else {
     hipLaunchKernelGGL((axpby_kernel<D>), dim3(gridn(MP)), dim3(256), 0, st, MP, -bw, (const D*)wd, 0.0, (const D*)nullptr, dmud);
     rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, P, M, 1.0, Ki, M, 0, Gw, P, 0, 1.0, dmud, P, 0, 1, 0, st);
     if (rc) return rc;
+    }
     if (early_kuu && !het) hipLaunchKernelGGL(dkuu_rank_kernel, dim3(gridn(MM)), dim3(256), 0, st, M, P, (const D*)dmud, (const D*)wd, bw, dKuu);
     // Kuu-side reverse mode in float64, then added to the streaming-side gradients
     FinishArgs fa;
