@@ -950,6 +950,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const bool bt_wh = bt_env && whiten && P == 1 && M <= 2048 && mxf_gemm_bt_ok(M, SB, M);
     if (bt_path || bt_wh) acc(2 * (size_t)M + 8, 2);
     if (het_stream) { acc(B, 4); acc(B, 4); acc((size_t)(sY == 0 ? B : SB), 4); acc(4, 8); acc(S, 8); acc(4, 4); }
+    // r06: the generic (materialised-Gram / heteroscedastic) float32 path's two big products on the f16 matrix pipe as well: T = H0 Kuf through the
+    // K-major product from the planes of Kuf (split from the float32 Gram: one maxabs + one split pass, 0.17 ms at 512 x 131 072), and
+    // G' = Ksc Kuf^T from the planes of Ksc and the same Kuf planes -- f32-equivalent like the streaming path's products (three f16 products, f32
+    // accumulation) where the generic kernel ran true-f32 MFMAs at 100 TF: the deep GP's first layer 0.68 + 0.66 ms -> planes 0.35 + products 0.3.
+    static const int het_split_env = (int)MXF_KNOB("MXF_SVGP_HET_SPLIT", 1);
+    const bool het_split = het_split_env && het && sizeof(T) == 4 && want_grad && split_env && split_mode == MXF_SPLIT_F16X2 && mxf_gemm_bt_ok(M, SB, M) &&
+                           (int64_t)M * SB >= (int64_t)1 << 24;
+    if (het_split) { acc(2 * pl_h0, 2); acc(2 * pl_big, 2); acc(2 * pl_big, 2); acc(4, sizeof(unsigned)); }
     if (want_grad) { acc(MM, sizeof(T)); acc(MP, sizeof(T)); acc((size_t)SB * P, sizeof(T)); for (int i = 0; i < 6; ++i) acc(MM, 8); acc(MP, 8); acc(MP, 8); acc(M * Q, 8); acc(lsn, 8); acc(4, 8); }
     void* ws = mxf_ws(h, need);
     if (!ws) MXF_FAIL(h, -4, "mxf_svgp_logpdf: cannot allocate %zu bytes of scratch", need);
@@ -979,6 +987,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const int64_t pVt = whiten ? (int64_t)((plKuf + 2 * pl_big) - plVt) : 0;
     float* hcs = nullptr; float* hrs = nullptr; float* hys = nullptr; D* hhs = nullptr; D* hbe2 = nullptr; float* hnz = nullptr;
     if (het_stream) { hcs = cv.take<float>(B); hrs = cv.take<float>(B); hys = cv.take<float>((size_t)(sY == 0 ? B : SB)); hhs = cv.take<D>(4); hbe2 = cv.take<D>(S); hnz = cv.take<float>(4); }
+    unsigned short* hsA = nullptr; unsigned short* hsK = nullptr; unsigned short* hsS = nullptr; unsigned* hsw = nullptr;
+    if (het_split) { hsA = cv.take<unsigned short>(2 * pl_h0); hsK = cv.take<unsigned short>(2 * pl_big); hsS = cv.take<unsigned short>(2 * pl_big); hsw = cv.take<unsigned>(4); }
     if (want_grad) { Psi2 = cv.take<T>(MM); R = cv.take<T>(MP); Eb = cv.take<T>((size_t)SB * P); }
     D* G = nullptr; D* T1 = nullptr; D* AKi = nullptr; D* T2 = nullptr; D* dKuu = nullptr; D* dSu = nullptr;
     D* Gw = nullptr; D* dmud = nullptr; D* dZc = nullptr; D* dlsc = nullptr; D* dvc = nullptr;
@@ -1073,7 +1083,8 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     // the bulk of the device work (Grams, Psi2), then the latency-critical Kuu chain, then the Su chain.
     // ---- side stream: Kuf_all, Kfu_all, Psi2 --------------------------------------------------------------------------------
     if (use_mat) {
-        MXF_HIP(h, hipMemcpyAsync(Kuf, mat.Kuf, sizeof(T) * (size_t)M * SB, hipMemcpyDeviceToDevice, sd_));
+        // (r06: the caller's Gram is only ever read -- no copy into the scratch (268 MB, 0.13 ms at 512 x 131 072))
+        Kuf = const_cast<T*>(mat.Kuf);
     } else if (whiten) {
         // whitened tier: only the Kfu planes (operand (n, k = m) of V = L^-1 Kuf); they need nothing from the core, so they are written
         // first; V, its transposition (+ U = a^T V) and Phi = V V^T follow on this stream once L^-1 exists (below, after the Kuu chain
@@ -1382,7 +1393,14 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         rc = mxf_gemm_split_internal(h, M, SB, M, (double)split_ga, plH0, (int64_t)pl_h0, plKfu, (int64_t)pl_big, 0.0, (float*)Text, SB, 0, st, 0, split_mode,
                                      split_var, 1, split_mode == MXF_SPLIT_F16X2 ? (const unsigned*)(info2 + 2) : nullptr, nullptr, t_blocked,
                                      (unsigned*)(info2 + 3));       // max |T| for the reverse pass (word cleared by svgp_init_kernel)
-    else
+    else if (het_split) {
+        rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, hsw + 0, st);
+        if (!rc) rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, hsA, st, MXF_SPLIT_F16X2, hsw + 0);
+        if (!rc) rc = mxf_maxabs_internal(h, M, SB, (const float*)Kuf, SB, hsw + 1, st);
+        if (!rc) rc = mxf_split_planes_internal(h, M, SB, (const float*)Kuf, SB, hsK, st, MXF_SPLIT_F16X2, hsw + 1);      // (m, k = n): the K-major operand of T, the row operand of G'
+        if (!rc) rc = mxf_gemm_bt_internal(h, M, SB, M, 1.0, hsA, (int64_t)pl_h0, hsK, (int64_t)pl_big, M, (float*)Text, SB, 0, st, 0, nullptr, hsw + 0, nullptr,
+                                           nullptr, nullptr, 1.0, nullptr, hsw + 1);
+    } else
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, SB, M, 1.0, Aext, M, 0, Kuf, SB, 0, 0.0, Text, SB, 0, 1, 0, st);   // T = H0 Kuf (MFMA)
     if (rc) return rc;
     MXF_T1(h, MXF_T_TGEMM, st);
@@ -1530,6 +1548,12 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         MXF_LAUNCH_CHECK(h);
         if (!want_grad) { hipLaunchKernelGGL(cond_publish_kernel, dim3(1), dim3(1), 0, st, h->cond_dev, cond_slot); return 0; }
         // G' = 1/2 a1 Kuf diag(bs) Kuf^T (-> Psi2 slot), Gw = Kuf (a1 beta.e) (-> R slot), Kuf-side reverse mode from dKuf = Text
+        if (het_split) {
+            rc = mxf_maxabs_internal(h, M, SB, (const float*)Ksc, SB, hsw + 2, st);
+            if (!rc) rc = mxf_split_planes_internal(h, M, SB, (const float*)Ksc, SB, hsS, st, MXF_SPLIT_F16X2, hsw + 2);
+            if (!rc) rc = mxf_gemm_split_internal(h, M, M, SB, 1.0, hsS, (int64_t)pl_big, hsK, (int64_t)pl_big, 0.0, (float*)Psi2, M, 0, st, 0, MXF_SPLIT_F16X2, nullptr, 0,
+                                                  hsw + 2, hsw + 1);
+        } else
         rc = mxf_gemm_internal(h, dtype, 0, 1, M, M, SB, 1.0, Ksc, SB, 0, Kuf, SB, 0, 0.0, Psi2, M, 0, 1, 0, st);
         if (rc) return rc;
         rc = mxf_gemm_internal(h, dtype, 0, 0, M, P, SB, 1.0, Kuf, SB, 0, Eb, P, 0, 0.0, R, P, 0, 1, 0, st);
