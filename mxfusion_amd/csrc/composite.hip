@@ -341,7 +341,7 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
         rc = mxf_gram_bwd_internal(h, kind, dtype, 1, N, N, Q, X + (int64_t)s * sX, 0, nullptr, 0, ls + (int64_t)s * sls, ard, 0,
                                    var + (int64_t)s * svar, 0, dK + (int64_t)s * NN, N, NN,
                                    dX ? dX + (int64_t)s * N * Q : nullptr, nullptr, dls ? dls + (int64_t)s * lsn : nullptr,
-                                   dvar ? dvar + s : nullptr, st);
+                                   dvar ? dvar + s : nullptr, st, 1 /* dK was symmetrised above */);
         if (rc) return rc;
     }
     MXF_LAUNCH_CHECK(h);
@@ -1647,7 +1647,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             MXF_HIP(h, hipMemsetAsync(dlsc, 0, sizeof(D) * lsn, st));
             MXF_HIP(h, hipMemsetAsync(dvc, 0, sizeof(D) * 4, st));
         }
-        rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st);
+        // (float32 mode: dKuu is symmetric up to the rounding of its float64 products -- the row side of its reverse pass is skipped; float64 keeps both sides)
+        rc = mxf_gram_bwd_internal(h, kind, MXF_F64, 1, M, M, Q, Zd, 0, nullptr, 0, lsd, ard, 0, vard, 0, dKuu, M, 0, dZc, nullptr, dlsc, dvc, st,
+                                   (early_kuu && !het) ? 1 : 0);
         if (rc) return rc;
         if (dZ) fin(dZc, nullptr, dZ, M * Q, 1);
         if (dls) fin(dlsc, nullptr, dls, lsn, 1);

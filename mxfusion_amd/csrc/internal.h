@@ -27,7 +27,8 @@ int mxf_sumlogdiag_internal(mxf_ctx* h, int dtype, int S, int64_t n, const void*
 
 int mxf_gram_bwd_internal(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int64_t N2, int Q, const void* X, int64_t sX,
                           const void* X2, int64_t sX2, const void* ls, int ard, int64_t sls, const void* var, int64_t svar,
-                          const void* dK, int64_t lddk, int64_t sdK, void* dX, void* dX2, void* dls, void* dvar, hipStream_t st);
+                          const void* dK, int64_t lddk, int64_t sdK, void* dX, void* dX2, void* dls, void* dvar, hipStream_t st, int dk_symmetric = 0);
+// (dk_symmetric, square case only: the caller vouches that dK is symmetric -- the row-side sums are skipped and the column side counts twice)
 
 // true if mxf_svgp_bwd_fused_internal takes the matrix-pipe pass for these arguments; that pass reads T in 16-column blocks
 // (element (m, n) at ((n / 16) * M + m) * 16 + n % 16: mxf_gemm_split_internal's c_blocked output) when called with t_blocked = 1
