@@ -237,15 +237,17 @@ static inline bool mxf_potrf_aux_init(mxf_ctx* h) {
     // and joined to the caller's stream, and nothing is launched on the caller's stream in between
     // MXF_POTRF_CHAIN_PRIO=1 (probe): the chain on a most-urgent stream of its own even without the masks
     static const int chain_prio_env = (int)MXF_KNOB("MXF_POTRF_CHAIN_PRIO", 0);
+    // (both experiment streams exist only when their probe knob asks for them: the product build never creates them)
     if (chain_prio_env) {
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
         ok = ok && hipStreamCreateWithPriority(&h->potrf_chain, hipStreamNonBlocking, hi) == hipSuccess;
         if (ok) h->potrf_chain_always = true;
-    } else
+    } else if (cumask_env > 0)
     ok = ok && hipStreamCreateWithFlags(&h->potrf_chain, hipStreamNonBlocking) == hipSuccess;
     if (!ok) h->potrf_chain = nullptr;
-    ok = ok && make_stream(&h->potrf_acc);
+    static const int kacc_env_ = (int)MXF_KNOB("MXF_POTRF_KACC", 0);
+    if (kacc_env_) ok = ok && make_stream(&h->potrf_acc);
     if (!ok) h->potrf_acc = nullptr;
     hipEvent_t* evs[] = {&h->ev_pa, &h->ev_pb, &h->ev_ph, &h->ev_pi, &h->ev_pj, &h->ev_pc, &h->ev_rb, &h->ev_pk, &h->ev_pq, &h->ev_pz};
     for (hipEvent_t* e : evs)
