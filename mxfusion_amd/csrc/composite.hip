@@ -1269,8 +1269,15 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         // for it; whitened parity tests pass either way.  Off.
         if (!phi_late) { rc = launch_phi(few); if (rc) return rc; }
     }
-    rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, 0, st);   // Ki = Linv^T Linv
+    // r06 (MXF_SVGP_SYM_LOWER): the symmetric products of the chain -- Ki here, H0 below -- as lower tiles + mirror (half the work of a product that
+    // runs on the 88 CUs Psi2 leaves in the few-sample regime; the results become exactly symmetric)
+    static const int symlow_env = (int)MXF_KNOB("MXF_SVGP_SYM_LOWER", 1);
+    // (float32 mode only: the float64 path is the parity path and stays operation for operation what the trajectory tests were recorded with --
+    //  tests/test_svgp_notebook.py's 100-epoch float64 run moved its learned noise by 12 % with exactly symmetric Ki / H0, past its 10 % band)
+    const int symlow = (symlow_env && sizeof(T) == 4) ? 1 : 0;
+    rc = mxf_gemm_internal(h, MXF_F64, 1, 0, M, M, M, 1.0, Linv, M, 0, Linv, M, 0, 0.0, Ki, M, 0, 1, symlow, st);   // Ki = Linv^T Linv
     if (rc) return rc;
+    if (symlow) hipLaunchKernelGGL((symmetrize_kernel<D>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, Ki, M, M, MM);
     if (!offpath) hipLaunchKernelGGL(norm1_sym16_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, M, (const double*)Ki, M, h->cond_dev + 1);
     MXF_HIP(h, hipStreamWaitEvent(st, h->ev_su, 0));                                                  // Su, mu, noise, accumulators (second side stream)
     if (offpath) hipLaunchKernelGGL((gemv_rows_kernel<D>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, P, (const D*)Ki, M, (const D*)mud, (int64_t)P, wd);   // w = Ki mu
@@ -1326,8 +1333,9 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL((convert_kernel<D, D>), dim3(gridn(MM)), dim3(256), 0, st, (int64_t)1, MM, (const D*)Ki, MM, H0, MM);     // H0 <- Ki (a plain kernel: the runtime's copy engine path costs ~10x as much next to busy queues)
-    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, 0, st);     // H0 = Ki - Ki Su Ki
+    rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, -1.0, KiSu, M, 0, Ki, M, 0, 1.0, H0, M, 0, 1, symlow, st);     // H0 = Ki - Ki Su Ki
     if (rc) return rc;
+    if (symlow) hipLaunchKernelGGL((symmetrize_kernel<D>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, st, H0, M, M, MM);
     }
     if (!offpath) hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
     // A_ext = [H0 ; w^T] in the streaming dtype
