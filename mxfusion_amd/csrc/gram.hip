@@ -641,7 +641,10 @@ __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int
                                                               int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
                                                               int64_t ldU, const float* __restrict__ ls = nullptr, int ard = 0, int Q = 0,
                                                               const float* __restrict__ majs = nullptr, const float* __restrict__ mins = nullptr,
-                                                              int64_t period = 1) {
+                                                              int64_t period = 1, int64_t pnbx = 0, int pnby = 0) {
+    // pnbx > 0 (r06, PT == 0 only): PERSISTENT form -- gridDim.x waves walk the pnbx x pnby (row block, k chunk) items, row block fastest.  The
+    // launcher sizes the grid to fewer waves than the chip holds, so that the float64 workgroups of the Kuu chain that runs next to this pass
+    // (four waves + LDS each) find room on every CU instead of waiting for four wave slots of one CU to drain at the same moment.
     // majs / mins (ACC form only; the streaming heteroscedastic SVGP bound, svgp_regression.py:61-67): every covariance is multiplied by
     // majs[major index % period] (wave-uniform) and / or mins[minor index % period] (per lane) before it is split into planes -- and before
     // it enters the fused row U -- i.e. the planes hold K diag(s) resp. diag(s) K for per-row weights s <= 1
@@ -654,7 +657,12 @@ __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int
             s2[q] = m * m;
         }
     }
-    const int64_t r0 = (int64_t)blockIdx.x * 64, r = r0 + lane;
+    const bool pers = PT == 0 && pnbx > 0;
+    int64_t item = blockIdx.x;
+    do {
+    const int64_t bxi = pers ? item % pnbx : (int64_t)blockIdx.x;
+    const int byi = pers ? (int)(item / pnbx) : (int)blockIdx.y;
+    const int64_t r0 = bxi * 64, r = r0 + lane;
     float z[QT];
 #pragma unroll
     for (int q = 0; q < QT; q += 4) *reinterpret_cast<f32x4_t*>(&z[q]) = *reinterpret_cast<const f32x4_t*>(Xmin_s + r * QT + q);   // padded
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int
 #pragma unroll
     for (int p = 0; p < (PT > 0 ? PT : 1); ++p) uacc[p] = 0.f;
     const int64_t K16 = (Kn + 15) / 16;
-    const int64_t kb_begin = (int64_t)blockIdx.y * kb_per_block;
+    const int64_t kb_begin = (int64_t)byi * kb_per_block;
     const int64_t kb_end = (kb_begin + kb_per_block) < K16 ? (kb_begin + kb_per_block) : K16;
     // store targets after the swap: instruction 1 <-> row r0 + lane % 32, instruction 2 <-> 32 rows further; the half is lane / 32
     const int64_t ra = r0 + (lane & 31), rb = ra + 32;
@@ -740,6 +748,8 @@ __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int
             for (int p = 0; p < PT; ++p) if (p < Pw) U[(int64_t)p * ldU + r] = uacc[p] * sc;
         }
     }
+    item += gridDim.x;
+    } while (pers && item < pnbx * (int64_t)pnby);
 }
 
 template <int KIND>
@@ -770,6 +780,13 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
     int kbpb = fuse_u ? (int)K16 : (int)MXF_KNOB("MXF_PLANES_KB", 8);
     while (!fuse_u && (K16 + kbpb - 1) / kbpb > 65535) kbpb *= 2;
     dim3 lgrid((unsigned)((R + 63) / 64), (unsigned)((K16 + kbpb - 1) / kbpb));
+    // MXF_PLANES_PERSIST = w > 0 (r06, probe builds): the pass as w persistent waves per CU (gram_planes_lean_kernel pnbx) once it has more items than
+    // that.  Measured and NOT kept (same box, alternating, tests/probes/r06_planes_persist.sh; parity tests pass with it): whitened 32-sample step
+    // 31.4-31.6 ms without, 31.3-31.7 with 28 waves per CU, 31.9 with 16, 34 with 24; the explicit 32-sample step 22.5-22.9 -> 24.5-24.8 (28) --
+    // the chain next to the pass does not get faster and the pass itself loses its dispatch-order store pattern.
+    static const int pers_env = (int)MXF_KNOB("MXF_PLANES_PERSIST", 0);
+    int64_t pers_grid = 0;
+    if (pers_env > 0 && !fuse_u && (int64_t)lgrid.x * lgrid.y > (int64_t)256 * pers_env * 2) pers_grid = (int64_t)256 * pers_env;
 #define GO(QTV)                                                                                                                       \
     do {                                                                                                                              \
         hipLaunchKernelGGL((prescale_kernel<float, QTV, KIND>), dim3((unsigned)((padr * QTV + 255) / 256), 1), dim3(256), 0, st, Xmin, (int64_t)0, ls, \
@@ -780,6 +797,8 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 1, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && raw && fuse_u)                                                                                               \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
+        else if (lean && raw && pers_grid > 0)                                                                                        \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), dim3((unsigned)pers_grid), dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period, (int64_t)lgrid.x, (int)lgrid.y); \
         else if (lean && raw)                                                                                                         \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && fuse_u && Pw == 1)                                                                                           \
