@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void gram_planes_kernel(int64_t R, int64_t Kn,
 #else
 #define MXF_PLANES_OCC
 #endif
-template <int QT, int KIND, int PT, bool ACC = false>
+template <int QT, int KIND, int PT, bool ACC = false, bool PERS = false>
 __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int64_t R, int64_t Kn, const float* __restrict__ Xmin_s, const float* __restrict__ Xmaj_s,
                                                               const float* __restrict__ var, unsigned short* __restrict__ P, int64_t pstride,
                                                               int kb_per_block, const float* __restrict__ wk, int Pw, float* __restrict__ U,
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) MXF_PLANES_OCC void gram_planes_lean_kernel(int
             s2[q] = m * m;
         }
     }
-    const bool pers = PT == 0 && pnbx > 0;
+    constexpr bool pers = PERS && PT == 0;      // (a compile-time form: the loop around the body cost the plain instance 7 % -- 1.72 -> 1.85 ms in the step)
     int64_t item = blockIdx.x;
     do {
     const int64_t bxi = pers ? item % pnbx : (int64_t)blockIdx.x;
@@ -798,7 +798,7 @@ int gram_planes_kind(mxf_ctx* h, int64_t R, int64_t Kn, int Q, const float* Xmin
         else if (lean && raw && fuse_u)                                                                                               \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 8, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && raw && pers_grid > 0)                                                                                        \
-            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), dim3((unsigned)pers_grid), dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period, (int64_t)lgrid.x, (int)lgrid.y); \
+            hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true, true>), dim3((unsigned)pers_grid), dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period, (int64_t)lgrid.x, (int)lgrid.y); \
         else if (lean && raw)                                                                                                         \
             hipLaunchKernelGGL((gram_planes_lean_kernel<QTV, KIND, 0, true>), lgrid, dim3(64), 0, st, R, Kn, (const float*)buf, (const float*)bmaj, var, planes, pstride, kbpb, wk, Pw, U, ldU, ls, ard, Q, majs, mins, period); \
         else if (lean && fuse_u && Pw == 1)                                                                                           \
