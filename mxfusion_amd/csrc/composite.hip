@@ -32,6 +32,25 @@ __global__ void convert_kernel(int64_t rows, int64_t cols, const TI* __restrict_
         dst[r * ldd + c] = (TO)src[r * lds_ + c];
     }
 }
+// float64 -> float32 copy of a contiguous array AND the bit pattern of max |dst| (out: cleared by the caller; non-negative floats order like
+// unsigned integers) in one launch -- the M x M operands of the split products went through a convert and a max|x| launch on the chain's critical path
+__global__ __launch_bounds__(256) void convert_max_kernel(int64_t n, const double* __restrict__ src, float* __restrict__ dst, unsigned* __restrict__ out) {
+    __shared__ unsigned wm[4];
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = (float)src[i];
+        dst[i] = v;
+        const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = wm[w] > m ? wm[w] : m;
+        atomicMax(out, m);
+    }
+}
 // dst[c][r] = src[r][c]
 template <typename TI, typename TO>
 __global__ void transpose_convert_kernel(int64_t rows, int64_t cols, const TI* __restrict__ src, int64_t lds_, TO* __restrict__ dst, int64_t ldd) {
@@ -1339,8 +1358,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     }
     if (!offpath) hipLaunchKernelGGL((dot_kernel<D>), dim3(dotgrid(MM)), dim3(256), 0, st, MM, (const D*)Ki, (const D*)Su, 1.0, sc + 2);
     // A_ext = [H0 ; w^T] in the streaming dtype
+    // (the w^T row that used to follow H0 in A_ext was read by nothing since U = w^T Kuf left the product: its launch is gone)
+    const bool fused_h0max = use_split && split_mode == MXF_SPLIT_F16X2 && sizeof(T) == 4;
+    if (fused_h0max) hipLaunchKernelGGL(convert_max_kernel, dim3((unsigned)(gridn(MM) > 256 ? 256 : gridn(MM))), dim3(256), 0, st, MM, (const D*)H0, (float*)Aext, (unsigned*)(info2 + 2));
+    else
     hipLaunchKernelGGL((convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, st, M, M, (const D*)H0, M, Aext, M);
-    hipLaunchKernelGGL((transpose_convert_kernel<D, T>), dim3(gridn(MP)), dim3(256), 0, st, M, (int64_t)P, (const D*)wd, (int64_t)P, Aext + MM, M);
 
     // ---- streaming part -----------------------------------------------------------------------------------
     // [T; U] = [H0; w^T] Kuf_all
@@ -1349,7 +1371,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
     const int t_blocked = (use_split && want_grad && !het && SB % 16 == 0 && mxf_svgp_bwd_reads_blocked(kind, dtype, SB, B, Q, P, Text)) ? 1 : 0;
     if (use_split) {
         unsigned* h0max = (unsigned*)(info2 + 2);       // bit pattern of max |H0|: the power-of-two scale of its f16x2 planes
-        if (split_mode == MXF_SPLIT_F16X2) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st, false); if (rc) return rc; }      // (word cleared by svgp_init_kernel)
+        if (split_mode == MXF_SPLIT_F16X2 && !fused_h0max) { rc = mxf_maxabs_internal(h, M, M, (const float*)Aext, M, h0max, st, false); if (rc) return rc; }      // (word cleared by svgp_init_kernel)
         rc = mxf_split_planes_internal(h, M, M, (const float*)Aext, M, plH0, st, split_mode, split_mode == MXF_SPLIT_F16X2 ? h0max : nullptr);
         if (rc) return rc;
     }
