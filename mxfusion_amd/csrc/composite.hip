@@ -1501,6 +1501,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (with_t1) r_ = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, G, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, s_);           // T1 = G Ki Su
         return r_;
     };
+    bool side_split = false;
     if (want_grad && !het && early_kuu) {
         // r06: the whole R-independent part of the core's reverse mode from X = Ki G Ki (G = c Psi2, c = P a1 beta / 2):
         //   dSu   = -X + bP/2 (Su^-1 - Ki)                                  (as before)
@@ -1532,6 +1533,11 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             if (rc) return rc;
             if (xlow) hipLaunchKernelGGL((symmetrize_kernel<D>), dim3((unsigned)((M + 31) / 32), (unsigned)((M + 31) / 32), 1), dim3(256), 0, sd_, Xb, M, M, MM);
         }
+        // (probe knob, off: measured neutral to slower -- per-rank step 3.79-3.84 ms without, 3.85-3.90 with it, tests/probes/r06_side_split.sh: the two
+        //  branches then share the CUs the reverse pass leaves, and the tail still waits for the later of them)
+        static const int side_split_env = (int)MXF_KNOB("MXF_SVGP_SIDE_SPLIT", 0);
+        side_split = side_split_env != 0;
+        if (side_split) { MXF_HIP(h, hipEventRecord(h->ev_k1, sd_)); MXF_HIP(h, hipStreamWaitEvent(s2_, h->ev_k1, 0)); }      // X ready
         hipLaunchKernelGGL(dsu_kernel, dim3(gridn(MM)), dim3(256), 0, sd_, MM, (const D*)Xb, (const D*)Sui, (const D*)Ki, 0.5 * bw * P, dSu);
         if (dW) {
             rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 2.0, dSu, M, 0, Wd, M, 0, 0.0, Lsinv, M, 0, 1, 0, sd_);     // dW = 2 dSu W (Lsinv buffer is free)
@@ -1539,14 +1545,18 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
             hipLaunchKernelGGL((add_convert_kernel<D, T>), dim3(gridn(MM)), dim3(256), 0, sd_, MM, (T)1, (const D*)Lsinv, dW, 0);
         }
         if (dSdiag) hipLaunchKernelGGL((diag_extract_kernel<D, T>), dim3(gridn(M)), dim3(256), 0, sd_, M, (const D*)dSu, M, dSdiag);
-        rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Xb, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, sd_);             // Y = X (Ki Su)^T
+        // the dKuu0 branch (Y, Ki Su Ki, dKuu0) needs X only: it runs on the second side stream next to the dSu / dW branch (MXF_SVGP_SIDE_SPLIT) --
+        // in the few-sample regime this stream ends after the reverse pass, and the step's tail waits for it
+        hipStream_t sk_ = side_split ? s2_ : sd_;
+        rc = mxf_gemm_internal(h, MXF_F64, 0, 1, M, M, M, 1.0, Xb, M, 0, KiSu, M, 0, 0.0, T1, M, 0, 1, 0, sk_);             // Y = X (Ki Su)^T
         if (rc) return rc;
         if (whiten) {
-            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, KiSu, M, 0, Ki, M, 0, 0.0, AKi, M, 0, 1, 0, sd_);        // Ki Su Ki (H0 holds Hh in this form)
+            rc = mxf_gemm_internal(h, MXF_F64, 0, 0, M, M, M, 1.0, KiSu, M, 0, Ki, M, 0, 0.0, AKi, M, 0, 1, 0, sk_);        // Ki Su Ki (H0 holds Hh in this form)
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(dkuu0_kernel, dim3(gridn(MM)), dim3(256), 0, sd_, M, P, (const D*)Xb, (const D*)T1, (const D*)Ki, whiten ? (const D*)AKi : (const D*)nullptr,
+        hipLaunchKernelGGL(dkuu0_kernel, dim3(gridn(MM)), dim3(256), 0, sk_, M, P, (const D*)Xb, (const D*)T1, (const D*)Ki, whiten ? (const D*)AKi : (const D*)nullptr,
                            (const D*)H0, (const D*)wd, bw, dKuu);
+        if (side_split) MXF_HIP(h, hipEventRecord(h->ev_k2, s2_));
     } else if (want_grad && !het) {
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_fork, 0));      // Ki, KiSu (main)
         MXF_HIP(h, hipStreamWaitEvent(sd_, h->ev_join, 0));      // Su^-1; `tmp` (chol(Su)) is free from here on
@@ -1666,6 +1676,7 @@ int svgp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t B, int64_t
         if (rc) return rc;
     } else {
         MXF_HIP(h, hipStreamWaitEvent(st, h->ev_join2, 0));      // side stream: Psi2 -> G, T1, dSu / dW / dSdiag (already done)
+        if (side_split) MXF_HIP(h, hipStreamWaitEvent(st, h->ev_k2, 0));      // ... and dKuu0 from the second side stream
         hipLaunchKernelGGL((scale_beta_kernel<T>), dim3(gridn(MP)), dim3(256), 0, st, MP, (const T*)R, (const D*)noised, a1, Gw);
     }
     // main: dKuu = -Ki A_Ki Ki - bP/2 Ki; dmu = Ki Gw - b w
