@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, int6
 // The same with a rank-P term folded in (r06, exact GP):  A <- sym(lower(A)) + c v v^T,  v (n x P) -- the reverse mode's 1/2 alpha alpha^T
 // without a pass of its own over the n x n matrix
 template <typename T>
-__global__ __launch_bounds__(256) void symmetrize_rankp_kernel(T* __restrict__ A, int64_t n, int64_t lda, const T* __restrict__ v, int P, T c) {
+__global__ __launch_bounds__(256) void symmetrize_rankp_kernel(T* __restrict__ A, int64_t n, int64_t lda, const T* __restrict__ v, int P, T c, int mirror = 1) {
     __shared__ T tile[32][33];
     const int bx = blockIdx.x, by = blockIdx.y;
     if (bx > by) return;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void symmetrize_rankp_kernel(T* __restrict__ A
         }
         tile[r][tx] = x;
     }
+    if (!mirror) return;         // (block-uniform: the reverse pass reads the lower triangle only)
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int64_t row = (int64_t)bx * 32 + r, col = (int64_t)by * 32 + tx;
@@ -349,6 +350,11 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
         if (rc) return rc;
     }
     T* dK = dK_early ? dK_early : cv.take<T>((size_t)S * NN);
+    // (r06, probe knob, off) one matrix, Q <= 16: dK stays a LOWER triangle (no mirror pass) and the Gram's reverse pass walks the lower pairs only, twice
+    // each, with both sides.  Correct (exact-GP tests pass with it), not faster: MAP step 13.71-13.75 ms without, 13.74-13.77 with -- half the pairs, but the
+    // row side is back and the early row bands' blocks leave the chip half empty.
+    static const int lower_bwd_env = (int)MXF_KNOB("MXF_GP_LOWER_BWD", 0);
+    const bool lower_bwd = lower_bwd_env && tri_skinny && Q <= 16;
     T* alpha = cv.take<T>((size_t)S * NP);
     if (tri_skinny) {
         MXF_HIP(h, hipMemsetAsync(alpha, 0, sizeof(T) * NP, st));
@@ -358,7 +364,8 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
         rc = mxf_gemm_internal(h, dtype, 1, 0, N, N, N, -0.5 * P, Linv, N, NN, Linv, N, NN, 0.0, dK, N, NN, S, 1, st, 0, 1);
         if (rc) return rc;
         }
-        hipLaunchKernelGGL((symmetrize_rankp_kernel<T>), dim3((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, dK, N, N, (const T*)alpha, P, (T)0.5);
+        hipLaunchKernelGGL((symmetrize_rankp_kernel<T>), dim3((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, dK, N, N, (const T*)alpha, P, (T)0.5,
+                           lower_bwd ? 0 : 1);
     } else {
     rc = mxf_gemm_internal(h, dtype, 1, 0, N, P, N, 1.0, Linv, N, NN, LinvY, P, NP, 0.0, alpha, P, NP, S, 0, st);   // alpha = Linv^T LinvY
     if (rc) return rc;
@@ -380,7 +387,7 @@ int gp_logpdf_typed(mxf_ctx* h, int kind, int dtype, int S, int64_t N, int Q, in
         rc = mxf_gram_bwd_internal(h, kind, dtype, 1, N, N, Q, X + (int64_t)s * sX, 0, nullptr, 0, ls + (int64_t)s * sls, ard, 0,
                                    var + (int64_t)s * svar, 0, dK + (int64_t)s * NN, N, NN,
                                    dX ? dX + (int64_t)s * N * Q : nullptr, nullptr, dls ? dls + (int64_t)s * lsn : nullptr,
-                                   dvar ? dvar + s : nullptr, st, 1 /* dK was symmetrised above */);
+                                   dvar ? dvar + s : nullptr, st, lower_bwd ? 2 : 1 /* dK was symmetrised above, or only its lower triangle is read */);
         if (rc) return rc;
     }
     MXF_LAUNCH_CHECK(h);

@@ -37,7 +37,9 @@ struct GramBwdArgs {
     int tblk;        // fused: T (= dK) in 16-column blocks, element (m, n) at ((n / 16) * N + m) * 16 + n % 16 (the split GEMM's blocked output)
     int sym;         // r06, square case: the caller vouches that dK is symmetric -- the row-side sum of row i then equals the column-side sum of
                      // column i, so the row side (a reduce-scatter and an LDS atomic per row and wave: what bounds this kernel) is skipped and
-                     // the column side counts twice (exact GP N = 8192 float64: 0.59 -> 0.3 ms)
+                     // the column side counts twice (exact GP N = 8192 float64: 0.59 -> 0.51 ms).
+                     // sym == 2: only the LOWER triangle of dK is valid (the upper one may hold anything): pairs (row, col < row) count twice, the
+                     // diagonal once, the rest not at all -- half the pairs, both sides; column tiles above a block's row band are skipped (tiled kernel, Q <= 16 only)
 };
 
 __device__ __forceinline__ void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -102,11 +104,13 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
     T gvar = 0;
     const T beta = FUSED ? (T)1 / a.noise[0] : (T)0;
     const T c1 = FUSED ? (T)a.a1 * beta : (T)0;
-    const bool rowside = a.dX != nullptr && !(a.square && a.sym);
+    const bool rowside = a.dX != nullptr && !(a.square && a.sym == 1);
+    const bool lower = a.square && a.sym == 2;
 
     for (int ct = 0; ct < a.CT; ++ct) {
         const int64_t tile0 = ((int64_t)blockIdx.x * a.CT + ct) * 256;
         if (tile0 >= a.N2) break;
+        if (lower && tile0 >= rend) break;                 // the rest of this block's column tiles lie above its row band
         const int64_t col = tile0 + tid;
         const bool cvalid = col < a.N2;
         T z[QT], gz[QT];
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
                     g = c1 * ((T)P * t_in + we);
                 } else {
                     g = pre[u];
+                    if (lower) g = (col < row) ? (T)2 * g : (col == row ? g : (T)0);      // (a select, not a product: the upper triangle may hold NaN bits)
                 }
                 gvar = fma(g, k, gvar);
                 const T W2 = (T)2 * g * w * variance;   // 2 dL/d(r2)
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs<T> a) {
         const int64_t sXc = a.square ? a.sX : a.sX2;
         if (dXc && cvalid) {
             const bool plain = !a.square && gridDim.y == 1 && (sXc != 0 || gridDim.z == 1);   // this block owns the column
-            const T cside = (a.square && a.sym) ? (T)2 : (T)1;
+            const T cside = (a.square && a.sym == 1) ? (T)2 : (T)1;
 #pragma unroll
             for (int q = 0; q < QT; ++q) {
                 if (q < Q) {
@@ -1048,7 +1053,8 @@ int bwd_typed(mxf_ctx* h, int kind, int S, int64_t N, int64_t N2, int Q, const v
     GramBwdArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.square = (X2 == nullptr);
-    a.sym = (dk_symmetric && a.square) ? 1 : 0;
+    a.sym = a.square ? dk_symmetric : 0;
+    if (a.sym == 2 && Q > 16) MXF_FAIL(h, -3, "mxf_gram_bwd: the lower-triangle form needs Q <= 16");
     a.X = (const T*)X; a.X2 = a.square ? (const T*)X : (const T*)X2; a.sX = sX; a.sX2 = a.square ? sX : sX2;
     a.ls = (const T*)ls; a.sls = sls; a.var = (const T*)var; a.svar = svar; a.dK = (const T*)dK; a.lddk = lddk; a.sdK = sdK;
     a.dX = (T*)dX; a.dX2 = (T*)dX2; a.dls = (T*)dls; a.dvar = (T*)dvar;
